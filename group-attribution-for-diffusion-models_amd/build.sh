@@ -1,0 +1,19 @@
+#!/bin/bash
+# Build libgad_hip.so for gfx950 in-tree (the .so travels to the GPU box with the snapshot).
+set -e
+HERE="$(cd "$(dirname "$0")" && pwd)"
+OUT="$HERE/gad/libgad_hip.so"
+HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
+FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$HERE/../include -I$HERE/csrc -Wno-unused-result"
+mkdir -p "$HERE/build"
+pids=()
+for f in gemm_f32 norm elementwise optim; do
+  src="$HERE/csrc/$f.hip"; obj="$HERE/build/$f.o"
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/gad_common.h" -nt "$obj" ] || [ "$HERE/../include/gad.h" -nt "$obj" ]; then
+    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    pids+=($!)
+  fi
+done
+for p in "${pids[@]}"; do wait $p; done
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{gemm_f32,norm,elementwise,optim}.o
+echo "built $OUT"

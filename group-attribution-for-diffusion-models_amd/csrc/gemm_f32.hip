@@ -1,0 +1,652 @@
+// f32-input MFMA contraction engine for gfx950 (MI355X).
+//
+// One templated kernel covers every matmul-shaped op on the U-Net hot path:
+//   conv2d forward   (A = im2col gather of NHWC x,  B = weight [Cout][KH*KW*Cin])
+//   conv2d dgrad     (A = transposed gather of dy,   B = weight read as [(r,s,co)][ci])
+//   conv2d wgrad     (A = dy^T,                      B = im2col gather as [pixel][(r,s,ci)])
+//   Linear fwd/dgrad/wgrad, attention QK^T / PV and their gradients (dense, batched)
+// v_mfma_f32_32x32x2_f32 is an exact-fp32 fmaf chain (64 FLOP/clk/SIMD = 157.3 TF/s
+// chip peak), so the result matches a CPU fp32 reference to summation-order noise.
+//
+// Structure (per 256-thread workgroup = 4 waves in a 2x2 arrangement):
+//   * block tile BMxBN (128x128 or 64x64), K step 32, two LDS buffers;
+//   * global -> registers (float4, coalesced along the contiguous dim) for tile t+1 is
+//     issued before the MFMAs of tile t and written to the other LDS buffer after them
+//     (one barrier per K step);
+//   * "KC" tiles ([row][k], k contiguous, row stride 36 floats -> conflict-free
+//     ds_read_b128 of 4 consecutive k) and "MC" tiles ([k][row], ds_read_b32);
+//     the k -> (MFMA step, lane half) assignment is the same permutation for both
+//     operands so any A/B layout pair composes;
+//   * 1-D grid with an XCD-aware bijective remap so that tiles sharing an A panel sit
+//     on one XCD's L2; split-K through a caller-owned workspace + deterministic reduce.
+#include "gad_common.h"
+
+namespace {
+
+constexpr int BK = 32;
+constexpr int KC_LD = BK + 4;  // 36 floats: 16 distinct 16-B slots for 16 consecutive rows
+constexpr int NTHREADS = 256;
+
+struct DevArgs {
+  const float* A;
+  const float* B;
+  float* C;
+  int M, N, K;
+  int lda, ldb, ldc;
+  int batch_inner;
+  long sA0, sA1, sB0, sB1, sC0, sC1;
+  gad_conv_geom g;
+  float alpha;
+  const float* bias;
+  const float* rowadd;
+  int rows_per_group, ld_rowadd;
+  const float* residual;
+  int ldr;
+  float* ws;
+  int tiles_m, tiles_n, splitk, ktiles_per_split;
+};
+
+__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+
+// ------------------------------------------------------------------------------------
+// Tile loaders.  Each thread owns NS float4 slots of the tile; `load` fetches them for
+// the K step starting at k0 (global -> registers), `store` writes them into LDS.
+// KC-type: slot i = (row (tid>>3)+32 i, float4 column tid&7)
+// MC-type: slot i = (k row tid/F4 + (256/F4) i, float4 column tid%F4),  F4 = ROWS/4
+// ------------------------------------------------------------------------------------
+template <int ROWS>
+struct KCSlots {
+  static constexpr int NS = ROWS / 32;
+  __device__ static int row(int i) { return (threadIdx.x >> 3) + 32 * i; }
+  __device__ static int kq4() { return (threadIdx.x & 7) * 4; }
+  __device__ static void store(float* lds, const f32x4* v) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(lds + row(i) * KC_LD + kq4()) = v[i];
+  }
+};
+template <int ROWS>
+struct MCSlots {
+  static constexpr int NS = ROWS / 32;
+  static constexpr int F4 = ROWS / 4;
+  static constexpr int KSTEP = NTHREADS / F4;
+  __device__ static int krow(int i) { return threadIdx.x / F4 + KSTEP * i; }
+  __device__ static int rq4() { return (threadIdx.x % F4) * 4; }
+  __device__ static void store(float* lds, const f32x4* v) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(lds + krow(i) * ROWS + rq4()) = v[i];
+  }
+};
+
+// dense [row][k]
+template <int ROWS>
+struct LoadKCDense : KCSlots<ROWS> {
+  using S = KCSlots<ROWS>;
+  const float* ptr[S::NS];
+  int kend;
+  __device__ void init(const float* base, int ld, int row0, int nrows, int kend_) {
+    kend = kend_;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int r = row0 + S::row(i);
+      ptr[i] = r < nrows ? base + (long)r * ld : nullptr;
+    }
+  }
+  __device__ void load(int k0, f32x4* v) const {
+    int k = k0 + S::kq4();
+    bool kok = k < kend;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) v[i] = (kok && ptr[i]) ? ldg4(ptr[i] + k) : zero4();
+  }
+};
+
+// dense [k][row]   (VEC == 1: scalar loads, any row count / leading dimension)
+template <int ROWS, int VEC>
+struct LoadMCDense : MCSlots<ROWS> {
+  using S = MCSlots<ROWS>;
+  const float* base;
+  int ld, kend, c0, nrows;
+  __device__ void init(const float* b, int ld_, int row0, int nrows_, int kend_) {
+    ld = ld_;
+    kend = kend_;
+    nrows = nrows_;
+    c0 = row0 + S::rq4();
+    base = b + c0;
+  }
+  __device__ void load(int k0, f32x4* v) const {
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int k = k0 + S::krow(i);
+      if (VEC == 4) {
+        v[i] = (c0 < nrows && k < kend) ? ldg4(base + (long)k * ld) : zero4();
+      } else {
+        f32x4 t = zero4();
+        if (k < kend) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (c0 + e < nrows) t[e] = base[(long)k * ld + e];
+        }
+        v[i] = t;
+      }
+    }
+  }
+};
+
+// im2col gather, rows = output pixels, k = (r, s, c).  TRANSPOSED = dgrad form:
+// rows = pixels of the conv INPUT grid, source = dy, src = (row + pad - tap)/stride.
+template <int ROWS, bool TRANSPOSED, int VEC>
+struct LoadConvRows : KCSlots<ROWS> {
+  using S = KCSlots<ROWS>;
+  const float* x;
+  gad_conv_geom g;
+  int bh[S::NS], bw[S::NS], boff[S::NS];  // per row: base h, base w, image pixel offset (or -1)
+  int kend, hlim, wlim;
+  __device__ void init(const float* x_, const gad_conv_geom& g_, int row0, int nrows, int kend_) {
+    x = x_;
+    g = g_;
+    kend = kend_;
+    hlim = g.upsample ? 2 * g.H : g.H;
+    wlim = g.upsample ? 2 * g.W : g.W;
+    int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int m = row0 + S::row(i);
+      if (m < nrows) {
+        int img = m / hw, rem = m - img * hw;
+        int oh = rem / g.Wo, ow = rem - oh * g.Wo;
+        boff[i] = img * g.H * g.W;
+        if (TRANSPOSED) {
+          bh[i] = oh + g.pad_t;
+          bw[i] = ow + g.pad_l;
+        } else {
+          bh[i] = oh * g.stride - g.pad_t;
+          bw[i] = ow * g.stride - g.pad_l;
+        }
+      } else {
+        boff[i] = -1;
+        bh[i] = bw[i] = 0;
+      }
+    }
+  }
+  __device__ __forceinline__ const float* addr(int i, int r, int s, int c) const {
+    if (boff[i] < 0) return nullptr;
+    int ih, iw;
+    if (TRANSPOSED) {
+      int nh = bh[i] - r, nw = bw[i] - s;
+      if (nh < 0 || nw < 0) return nullptr;
+      if (g.stride == 2) {
+        if ((nh | nw) & 1) return nullptr;
+        nh >>= 1;
+        nw >>= 1;
+      } else if (g.stride != 1) {
+        if (nh % g.stride || nw % g.stride) return nullptr;
+        nh /= g.stride;
+        nw /= g.stride;
+      }
+      ih = nh;
+      iw = nw;
+    } else {
+      ih = bh[i] + r;
+      iw = bw[i] + s;
+      if (ih < 0 || iw < 0) return nullptr;
+    }
+    if (ih >= hlim || iw >= wlim) return nullptr;
+    if (g.upsample) {
+      ih >>= 1;
+      iw >>= 1;
+    }
+    return x + (long)(boff[i] + ih * g.W + iw) * g.ldx + c;
+  }
+  __device__ void load(int k0, f32x4* v) const {
+    int k = k0 + S::kq4();
+    if (VEC == 4) {
+      int tap = k / g.C, c = k - tap * g.C;
+      int r = tap / g.KW, s = tap - r * g.KW;
+      bool kok = k < kend;
+#pragma unroll
+      for (int i = 0; i < S::NS; ++i) {
+        const float* p = kok ? addr(i, r, s, c) : nullptr;
+        v[i] = p ? ldg4(p) : zero4();
+      }
+    } else {
+#pragma unroll
+      for (int i = 0; i < S::NS; ++i) {
+        f32x4 t = zero4();
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          int ke = k + e;
+          if (ke < kend) {
+            int tap = ke / g.C, c = ke - tap * g.C;
+            int r = tap / g.KW, s = tap - r * g.KW;
+            const float* p = addr(i, r, s, c);
+            if (p) t[e] = *p;
+          }
+        }
+        v[i] = t;
+      }
+    }
+  }
+};
+
+// conv weight W[co][tap][ci] read as B[k = tap*Cout + co][n = ci]   (MC-type)
+template <int ROWS>
+struct LoadWDgrad : MCSlots<ROWS> {
+  using S = MCSlots<ROWS>;
+  const float* base;
+  int Cout, taps, ncols, kend;
+  bool cok;
+  __device__ void init(const float* w, const gad_conv_geom& g, int col0, int ncols_, int kend_) {
+    Cout = g.C;
+    taps = g.KH * g.KW;
+    ncols = ncols_;
+    kend = kend_;
+    int c = col0 + S::rq4();
+    cok = c < ncols;
+    base = w + c;
+  }
+  __device__ void load(int k0, f32x4* v) const {
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int k = k0 + S::krow(i);
+      if (cok && k < kend) {
+        int tap = k / Cout, co = k - tap * Cout;
+        v[i] = ldg4(base + ((long)co * taps + tap) * ncols);
+      } else {
+        v[i] = zero4();
+      }
+    }
+  }
+};
+
+// im2col gather as B[k = pixel][n = (r,s,c)]   (MC-type, wgrad)
+template <int ROWS, int VEC>
+struct LoadConvCols : MCSlots<ROWS> {
+  using S = MCSlots<ROWS>;
+  const float* x;
+  gad_conv_geom g;
+  int r[VEC == 4 ? 1 : 4], s[VEC == 4 ? 1 : 4], c[VEC == 4 ? 1 : 4];
+  bool nok[VEC == 4 ? 1 : 4];
+  int kend, hlim, wlim;
+  __device__ void init(const float* x_, const gad_conv_geom& g_, int col0, int ncols, int kend_) {
+    x = x_;
+    g = g_;
+    kend = kend_;
+    hlim = g.upsample ? 2 * g.H : g.H;
+    wlim = g.upsample ? 2 * g.W : g.W;
+    int n = col0 + S::rq4();
+#pragma unroll
+    for (int e = 0; e < (VEC == 4 ? 1 : 4); ++e) {
+      int ne = n + e;
+      nok[e] = ne < ncols;
+      int tap = ne / g.C;
+      c[e] = ne - tap * g.C;
+      r[e] = tap / g.KW;
+      s[e] = tap - r[e] * g.KW;
+    }
+  }
+  __device__ void load(int k0, f32x4* v) const {
+    int hw = g.Ho * g.Wo;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int m = k0 + S::krow(i);
+      f32x4 t = zero4();
+      if (m < kend) {
+        int img = m / hw, rem = m - img * hw;
+        int oh = rem / g.Wo, ow = rem - oh * g.Wo;
+#pragma unroll
+        for (int e = 0; e < (VEC == 4 ? 1 : 4); ++e) {
+          int ih = oh * g.stride - g.pad_t + r[e], iw = ow * g.stride - g.pad_l + s[e];
+          if (nok[e] && ih >= 0 && iw >= 0 && ih < hlim && iw < wlim) {
+            if (g.upsample) {
+              ih >>= 1;
+              iw >>= 1;
+            }
+            const float* p = x + (long)(img * g.H * g.W + ih * g.W + iw) * g.ldx + c[e];
+            if (VEC == 4)
+              t = ldg4(p);
+            else
+              t[e] = *p;
+          }
+        }
+      }
+      v[i] = t;
+    }
+  }
+};
+
+template <int MODE, int ROWS, int VEC>
+struct ALoader;
+template <int ROWS, int VEC>
+struct ALoader<GAD_A_KC, ROWS, VEC> : LoadKCDense<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.lda, row0, p.M, kend); }
+};
+template <int ROWS, int VEC>
+struct ALoader<GAD_A_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.lda, row0, p.M, kend); }
+};
+template <int ROWS, int VEC>
+struct ALoader<GAD_A_CONV, ROWS, VEC> : LoadConvRows<ROWS, false, VEC> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.g, row0, p.M, kend); }
+};
+template <int ROWS, int VEC>
+struct ALoader<GAD_A_CONVT, ROWS, VEC> : LoadConvRows<ROWS, true, VEC> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.g, row0, p.M, kend); }
+};
+
+template <int MODE, int ROWS, int VEC>
+struct BLoader;
+template <int ROWS, int VEC>
+struct BLoader<GAD_B_KC, ROWS, VEC> : LoadKCDense<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
+};
+template <int ROWS, int VEC>
+struct BLoader<GAD_B_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
+};
+template <int ROWS, int VEC>
+struct BLoader<GAD_B_WDGRAD, ROWS, VEC> : LoadWDgrad<ROWS> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.g, col0, p.N, kend); }
+};
+template <int ROWS, int VEC>
+struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.g, col0, p.N, kend); }
+};
+
+// ------------------------------------------------------------------------------------
+// Fragment reads.  K step of 32 = 4 groups of 8; in group g, MFMA step j (0..3) feeds
+// lane half h with k = 8g + 4h + j  (so a KC tile is read as one b128 per group).
+// ------------------------------------------------------------------------------------
+template <bool KC, int ROWS>
+__device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int g, int h) {
+  if (KC) {
+    return *reinterpret_cast<const f32x4*>(lds + row * KC_LD + 8 * g + 4 * h);
+  } else {
+    const float* p = lds + (8 * g + 4 * h) * ROWS + row;
+    return f32x4{p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]};
+  }
+}
+
+template <int AM, int BMODE, int BM, int BN, int VEC>
+__global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using AL = ALoader<AM, BM, VEC>;
+  using BL = BLoader<BMODE, BN, VEC>;
+  constexpr int A_TILE = AL::KC ? BM * KC_LD : BK * BM;
+  constexpr int B_TILE = BL::KC ? BN * KC_LD : BK * BN;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+
+  // ---- block -> (batch z, split, tile_m, tile_n), XCD-aware (bijective) ----
+  int nwg = gridDim.x, bid = blockIdx.x;
+  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  int tiles = p.tiles_m * p.tiles_n;
+  int zs = t / tiles, rem = t - zs * tiles;
+  int tile_m = rem / p.tiles_n, tile_n = rem - tile_m * p.tiles_n;
+  int z = zs / p.splitk, split = zs - z * p.splitk;
+  int z0 = z / p.batch_inner, z1 = z - z0 * p.batch_inner;
+  const float* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+  const float* B = p.B + z0 * p.sB0 + z1 * p.sB1;
+
+  int row0 = tile_m * BM, col0 = tile_n * BN;
+  int kbeg = split * p.ktiles_per_split * BK;
+  int kend = min(p.K, kbeg + p.ktiles_per_split * BK);
+  int nkt = (kend - kbeg + BK - 1) / BK;
+
+  AL al;
+  BL bl;
+  al.setup(p, A, row0, kend);
+  bl.setup(p, B, col0, kend);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[AL::NS], rb[BL::NS];
+  if (nkt > 0) {
+    al.load(kbeg, ra);
+    bl.load(kbeg, rb);
+    AL::store(lds, ra);
+    BL::store(lds + A_TILE, rb);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
+    const float* lb = la + A_TILE;
+    const bool more = kt + 1 < nkt;
+    if (more) {
+      al.load(kbeg + (kt + 1) * BK, ra);
+      bl.load(kbeg + (kt + 1) * BK, rb);
+    }
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+      f32x4 fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = read_frag<AL::KC, BM>(la, wm * (BM / 2) + i * 32 + l31, g, h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, g, h);
+#pragma unroll
+      for (int s = 0; s < 4; ++s)
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+    }
+    if (more) {
+      float* na = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
+      AL::store(na, ra);
+      BL::store(na + A_TILE, rb);
+    }
+    __syncthreads();
+  }
+
+  // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
+  const bool direct = p.splitk == 1;
+  float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
+  const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
+  const int ldc = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e];
+        if (direct) {
+          v = v * p.alpha + bias;
+          if (p.rowadd) v += p.rowadd[(long)(m / p.rows_per_group) * p.ld_rowadd + n];
+          if (R) v += R[(long)m * p.ldr + n];
+        }
+        C[(long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
+// split-K: C = epilogue(sum_s ws[z][s][m][n])
+__global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
+  long total = (long)batch * p.M * p.N;
+  for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
+    long mn = (long)p.M * p.N;
+    int z = (int)(idx / mn);
+    long r = idx - (long)z * mn;
+    int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
+    const float* w = p.ws + (long)z * p.splitk * mn + r;
+    float v = 0.f;
+    for (int s = 0; s < p.splitk; ++s) v += w[(long)s * mn];
+    v *= p.alpha;
+    if (p.bias) v += p.bias[n];
+    if (p.rowadd) v += p.rowadd[(long)(m / p.rows_per_group) * p.ld_rowadd + n];
+    int z0 = z / p.batch_inner, z1 = z - z0 * p.batch_inner;
+    long coff = z0 * p.sC0 + z1 * p.sC1;
+    if (p.residual) v += p.residual[coff + (long)m * p.ldr + n];
+    p.C[coff + (long)m * p.ldc + n] = v;
+  }
+}
+
+struct Plan {
+  int bm, tiles_m, tiles_n, splitk, ktiles_per_split;
+  long nblocks;
+};
+
+static Plan make_plan(const gad_gemm_args* a) {
+  Plan pl;
+  long batch = a->batch > 0 ? a->batch : 1;
+  long t128 = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, 128) * batch;
+  int bm = (t128 >= 512) ? 128 : 64;
+  if (a->tile_hint == 1) bm = 128;
+  if (a->tile_hint == 2) bm = 64;
+  pl.bm = bm;
+  pl.tiles_m = (int)gad_ceil_div(a->M, bm);
+  pl.tiles_n = (int)gad_ceil_div(a->N, bm);
+  long tiles = (long)pl.tiles_m * pl.tiles_n * batch;
+  int kt = (int)gad_ceil_div(a->K, BK);
+  int sk = 1;
+  if (tiles < 384 && kt >= 16) {
+    sk = (int)gad_ceil_div(768, tiles);
+    int maxsk = kt / 8;
+    if (sk > maxsk) sk = maxsk;
+    if (sk > 32) sk = 32;
+    if (sk < 1) sk = 1;
+  }
+  if (a->splitk_hint > 0) sk = a->splitk_hint;
+  if (sk > kt) sk = kt > 0 ? kt : 1;
+  pl.ktiles_per_split = (int)gad_ceil_div(kt > 0 ? kt : 1, sk);
+  pl.splitk = (int)gad_ceil_div(kt > 0 ? kt : 1, pl.ktiles_per_split);
+  pl.nblocks = tiles * pl.splitk;
+  return pl;
+}
+
+template <int AM, int BMODE, int VEC>
+static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
+  dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
+  if (pl.bm == 128)
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC>), grid, block, 0, st, d);
+  else
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC>), grid, block, 0, st, d);
+}
+
+}  // namespace
+
+extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
+  Plan pl = make_plan(a);
+  if (pl.splitk == 1) return 0;
+  long batch = a->batch > 0 ? a->batch : 1;
+  return (int64_t)batch * pl.splitk * a->M * a->N * (int64_t)sizeof(float);
+}
+
+extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
+  GAD_CHECK(a && a->A && a->B && a->C, "gad_gemm: null pointer");
+  GAD_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gad_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+  const int am = a->a_mode, bmode = a->b_mode;
+  const bool convA = am == GAD_A_CONV || am == GAD_A_CONVT;
+  const bool geomB = bmode == GAD_B_CONV || bmode == GAD_B_WDGRAD;
+  int vec = 4;
+  // --- shape / alignment contracts of the float4 paths (checked on the host so that a
+  //     mismatch is an error, never an out-of-bounds access on the device) ---
+  GAD_CHECK(gad_aligned16(a->A) && gad_aligned16(a->B), "gad_gemm: A/B must be 16-byte aligned");
+  if (am == GAD_A_KC) GAD_CHECK(a->K % 4 == 0 && a->lda % 4 == 0 && a->lda >= a->K, "gad_gemm: A_KC needs K%%4==0, lda%%4==0 (K=%d lda=%d)", a->K, a->lda);
+  if (am == GAD_A_MC) {
+    GAD_CHECK(a->lda >= a->M, "gad_gemm: A_MC needs lda >= M (M=%d lda=%d)", a->M, a->lda);
+    if (a->M % 4 != 0 || a->lda % 4 != 0) vec = 1;
+  }
+  if (bmode == GAD_B_KC) GAD_CHECK(a->K % 4 == 0 && a->ldb % 4 == 0 && a->ldb >= a->K, "gad_gemm: B_KC needs K%%4==0, ldb%%4==0 (K=%d ldb=%d)", a->K, a->ldb);
+  if (bmode == GAD_B_MC) {
+    GAD_CHECK(a->ldb >= a->N, "gad_gemm: B_MC needs ldb >= N (N=%d ldb=%d)", a->N, a->ldb);
+    if (a->N % 4 != 0 || a->ldb % 4 != 0) vec = 1;
+  }
+  if (convA || geomB) {
+    const gad_conv_geom& g = a->g;
+    GAD_CHECK(g.H > 0 && g.W > 0 && g.C > 0 && g.Ho > 0 && g.Wo > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0 && g.ldx >= g.C,
+              "gad_gemm: bad conv geometry");
+    GAD_CHECK((long)g.H * g.W * g.ldx < (1L << 31), "gad_gemm: image too large for 32-bit pixel offsets");
+    if (convA) {
+      GAD_CHECK(a->K == g.KH * g.KW * g.C, "gad_gemm: conv K=%d != KH*KW*C=%d", a->K, g.KH * g.KW * g.C);
+      GAD_CHECK(a->M % (g.Ho * g.Wo) == 0, "gad_gemm: conv M=%d not a multiple of Ho*Wo", a->M);
+      GAD_CHECK((long)(a->M / (g.Ho * g.Wo)) * g.H * g.W < (1L << 31), "gad_gemm: too many pixels");
+      if (g.C % 4 != 0 || g.ldx % 4 != 0) vec = 1;
+    }
+    if (bmode == GAD_B_WDGRAD) {
+      GAD_CHECK(am == GAD_A_CONVT, "gad_gemm: B_WDGRAD pairs with A_CONVT");
+      GAD_CHECK(a->N % 4 == 0, "gad_gemm: B_WDGRAD needs N%%4==0 (N=%d)", a->N);
+    }
+    if (bmode == GAD_B_CONV) {
+      GAD_CHECK(a->N == g.KH * g.KW * g.C, "gad_gemm: wgrad N=%d != KH*KW*C=%d", a->N, g.KH * g.KW * g.C);
+      GAD_CHECK(a->K % (g.Ho * g.Wo) == 0, "gad_gemm: wgrad K=%d not a multiple of Ho*Wo", a->K);
+      GAD_CHECK((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W < (1L << 31), "gad_gemm: too many pixels");
+      if (g.C % 4 != 0 || g.ldx % 4 != 0) vec = 1;
+    }
+  }
+  if (a->rowadd) GAD_CHECK(a->rows_per_group > 0 && a->ld_rowadd >= a->N, "gad_gemm: bad rowadd");
+  if (a->residual) GAD_CHECK(a->ldr >= a->N, "gad_gemm: bad residual stride");
+  GAD_CHECK(a->ldc >= a->N, "gad_gemm: ldc < N");
+
+  Plan pl = make_plan(a);
+  long batch = a->batch > 0 ? a->batch : 1;
+  GAD_CHECK(pl.nblocks > 0 && pl.nblocks < (1L << 31), "gad_gemm: grid too large");
+  if (pl.splitk > 1) {
+    int64_t need = (int64_t)batch * pl.splitk * a->M * a->N * (int64_t)sizeof(float);
+    GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: split-K workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
+  }
+
+  DevArgs d;
+  d.A = a->A; d.B = a->B; d.C = a->C;
+  d.M = a->M; d.N = a->N; d.K = a->K;
+  d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
+  d.batch_inner = a->batch_inner > 0 ? a->batch_inner : 1;
+  d.sA0 = a->strideA0; d.sA1 = a->strideA1; d.sB0 = a->strideB0; d.sB1 = a->strideB1;
+  d.sC0 = a->strideC0; d.sC1 = a->strideC1;
+  d.g = a->g;
+  d.alpha = a->alpha;
+  d.bias = a->bias; d.rowadd = a->rowadd; d.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
+  d.ld_rowadd = a->ld_rowadd; d.residual = a->residual; d.ldr = a->ldr;
+  d.ws = (float*)a->ws;
+  d.tiles_m = pl.tiles_m; d.tiles_n = pl.tiles_n; d.splitk = pl.splitk; d.ktiles_per_split = pl.ktiles_per_split;
+
+  hipStream_t st = (hipStream_t)stream;
+#define GAD_CASE(AMODE, BMODE_)                                                        \
+  if (am == AMODE && bmode == BMODE_) {                                                \
+    if (vec == 4) launch_mode<AMODE, BMODE_, 4>(d, pl, st);                            \
+    else launch_mode<AMODE, BMODE_, 1>(d, pl, st);                                     \
+  } else
+  GAD_CASE(GAD_A_KC, GAD_B_KC)
+  GAD_CASE(GAD_A_KC, GAD_B_MC)
+  GAD_CASE(GAD_A_MC, GAD_B_MC)
+  GAD_CASE(GAD_A_CONV, GAD_B_KC)
+  GAD_CASE(GAD_A_CONVT, GAD_B_WDGRAD)
+  GAD_CASE(GAD_A_MC, GAD_B_CONV)
+  {
+    gad_set_error("gad_gemm: unsupported mode pair a_mode=%d b_mode=%d", am, bmode);
+    return 1;
+  }
+#undef GAD_CASE
+  GAD_LAUNCH_CHECK("gad_gemm");
+  if (pl.splitk > 1) {
+    long total = batch * (long)a->M * a->N;
+    int blocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
+    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, (int)batch);
+    GAD_LAUNCH_CHECK("gad_gemm(splitk reduce)");
+  }
+  return 0;
+}

@@ -1,0 +1,307 @@
+// GroupNorm (+SiLU) forward / backward for NHWC fp32 activations, gfx950.
+//
+// HBM-bound: algorithmic traffic 8 B/elem forward (read x, write y) and 16 B/elem
+// backward (read x, dy, write dx + re-read).  Each image is cut into NCH pixel chunks so
+// that the launch has >= ~1-2k workgroups (256 CUs x 8 XCDs need far more than 256):
+//   pass 1 (stats):  per (image, chunk) partial moments, coalesced float4 reads along C,
+//                    wavefront-free LDS combine; written to the caller's workspace;
+//   pass 2 (apply):  every workgroup re-combines the (tiny) partials of its image with
+//                    Chan's formula - no atomics, deterministic - then normalises its chunk.
+// The second read of x hits the 256 MiB Infinity Cache for the tensors on this path
+// (<= 67 MB at B=128), so HBM traffic stays near the 8 B/elem algorithmic figure.
+#include "gad_common.h"
+
+namespace {
+
+constexpr int NT = 256;
+
+struct Geo {
+  int B, HW, C, G, cpg, C4, rows_par, nch, ppc;  // ppc = pixels per chunk
+};
+
+static Geo make_geo(const gad_groupnorm_args* a) {
+  Geo g;
+  g.B = a->B; g.HW = a->HW; g.C = a->C; g.G = a->G;
+  g.cpg = a->C / a->G;
+  g.C4 = a->C / 4;
+  g.rows_par = NT / g.C4;
+  int nch = 2048 / (a->B > 0 ? a->B : 1);
+  int maxch = a->HW / 8;
+  if (nch > maxch) nch = maxch;
+  if (nch < 1) nch = 1;
+  g.ppc = (a->HW + nch - 1) / nch;
+  g.nch = (a->HW + g.ppc - 1) / g.ppc;
+  return g;
+}
+
+__device__ __forceinline__ float silu_f(float z) { return z / (1.f + expf(-z)); }
+
+// ---------------------------------------------------------------- forward ----
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, Geo g) {
+  __shared__ float red[2 * 1024];  // [rows_par][C] sums then sumsqs; rows_par*C <= 1024
+  int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
+  int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
+  int tid = threadIdx.x;
+  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  if (prow < g.rows_par) {
+    const float* xb = x + ((long)b * g.HW) * g.C + cq * 4;
+    for (int p = p0 + prow; p < p1; p += g.rows_par) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
+      s += v;
+      ss += v * v;
+    }
+    float* r0 = red + prow * g.C + cq * 4;
+    float* r1 = red + g.rows_par * g.C + prow * g.C + cq * 4;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r0[e] = s[e]; r1[e] = ss[e]; }
+  }
+  __syncthreads();
+  for (int grp = tid; grp < g.G; grp += NT) {
+    float S = 0.f, SS = 0.f;
+    for (int r = 0; r < g.rows_par; ++r)
+      for (int c = grp * g.cpg; c < (grp + 1) * g.cpg; ++c) {
+        S += red[r * g.C + c];
+        SS += red[g.rows_par * g.C + r * g.C + c];
+      }
+    float n = (float)((p1 - p0) * g.cpg);
+    float mean = S / n;
+    float m2 = fmaxf(SS - S * mean, 0.f);
+    float* o = part + (((long)b * g.nch + ch) * g.G + grp) * 2;
+    o[0] = mean;
+    o[1] = m2;
+  }
+}
+
+// combine the chunk partials of image b into LDS mean/rstd (Chan et al. parallel variance)
+__device__ __forceinline__ void gn_combine(const float* part, Geo g, int b, float eps, float* s_mean, float* s_rstd) {
+  for (int grp = threadIdx.x; grp < g.G; grp += NT) {
+    float n = 0.f, mean = 0.f, m2 = 0.f;
+    for (int ch = 0; ch < g.nch; ++ch) {
+      int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
+      float nb = (float)((p1 - p0) * g.cpg);
+      const float* o = part + (((long)b * g.nch + ch) * g.G + grp) * 2;
+      float d = o[0] - mean, nt = n + nb;
+      mean += d * (nb / nt);
+      m2 += o[1] + d * d * (n * nb / nt);
+      n = nt;
+    }
+    s_mean[grp] = mean;
+    s_rstd[grp] = rsqrtf(m2 / n + eps);
+  }
+}
+
+__global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      const float* __restrict__ part, float* __restrict__ mean_out,
+                                                      float* __restrict__ rstd_out, Geo g, float eps, int silu) {
+  __shared__ float s_mean[256], s_rstd[256];
+  int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
+  gn_combine(part, g, b, eps, s_mean, s_rstd);
+  __syncthreads();
+  int tid = threadIdx.x;
+  if (ch == 0)
+    for (int grp = tid; grp < g.G; grp += NT) {
+      mean_out[b * g.G + grp] = s_mean[grp];
+      rstd_out[b * g.G + grp] = s_rstd[grp];
+    }
+  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  if (prow >= g.rows_par) return;
+  int c0 = cq * 4;
+  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 mu, rs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int grp = (c0 + e) / g.cpg;
+    mu[e] = s_mean[grp];
+    rs[e] = s_rstd[grp];
+  }
+  f32x4 scale = rs * ga, shift = be - mu * scale;
+  int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
+  long base = ((long)b * g.HW) * g.C + c0;
+  for (int p = p0 + prow; p < p1; p += g.rows_par) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+    f32x4 z = v * scale + shift;
+    if (silu) {
+#pragma unroll
+      for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+    }
+    *reinterpret_cast<f32x4*>(y + base + (long)p * g.C) = z;
+  }
+}
+
+// --------------------------------------------------------------- backward ----
+// g_e = dy * silu'(z) (or dy);  per channel partials  A_c = sum g_e,  Bx_c = sum g_e * xhat_e
+__device__ __forceinline__ float act_grad(float dy, float z, int silu) {
+  if (!silu) return dy;
+  float s = 1.f / (1.f + expf(-z));
+  return dy * s * (1.f + z * (1.f - s));
+}
+
+__global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                          const float* __restrict__ mean, const float* __restrict__ rstd,
+                                                          float* __restrict__ part, Geo g, int silu) {
+  __shared__ float red[2 * 1024];
+  int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
+  int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
+  int tid = threadIdx.x;
+  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  if (prow < g.rows_par) {
+    int c0 = cq * 4;
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 mu, rs;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      int grp = (c0 + e) / g.cpg;
+      mu[e] = mean[b * g.G + grp];
+      rs[e] = rstd[b * g.G + grp];
+    }
+    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+    long base = ((long)b * g.HW) * g.C + c0;
+    for (int p = p0 + prow; p < p1; p += g.rows_par) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
+      f32x4 xh = (v - mu) * rs;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
+        sa[e] += ge;
+        sb[e] += ge * xh[e];
+      }
+    }
+    float* r0 = red + prow * g.C + c0;
+    float* r1 = red + g.rows_par * g.C + prow * g.C + c0;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { r0[e] = sa[e]; r1[e] = sb[e]; }
+  }
+  __syncthreads();
+  for (int c = tid; c < g.C; c += NT) {
+    float A = 0.f, Bx = 0.f;
+    for (int r = 0; r < g.rows_par; ++r) {
+      A += red[r * g.C + c];
+      Bx += red[g.rows_par * g.C + r * g.C + c];
+    }
+    float* o = part + (((long)b * g.nch + ch) * g.C + c) * 2;
+    o[0] = A;
+    o[1] = Bx;
+  }
+}
+
+__global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, const float* __restrict__ part,
+                                                          Geo g, int silu) {
+  __shared__ float s_a[1024], s_b[1024];     // per channel sums (gamma-weighted)
+  __shared__ float s_s1[256], s_s2[256];     // per group
+  int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
+  int tid = threadIdx.x;
+  for (int c = tid; c < g.C; c += NT) {
+    float A = 0.f, Bx = 0.f;
+    for (int k = 0; k < g.nch; ++k) {
+      const float* o = part + (((long)b * g.nch + k) * g.C + c) * 2;
+      A += o[0];
+      Bx += o[1];
+    }
+    float ga = gamma[c];
+    s_a[c] = A * ga;
+    s_b[c] = Bx * ga;
+  }
+  __syncthreads();
+  for (int grp = tid; grp < g.G; grp += NT) {
+    float s1 = 0.f, s2 = 0.f;
+    for (int c = grp * g.cpg; c < (grp + 1) * g.cpg; ++c) {
+      s1 += s_a[c];
+      s2 += s_b[c];
+    }
+    float inv_n = 1.f / (float)((long)g.HW * g.cpg);
+    s_s1[grp] = s1 * inv_n;
+    s_s2[grp] = s2 * inv_n;
+  }
+  __syncthreads();
+  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  if (prow >= g.rows_par) return;
+  int c0 = cq * 4;
+  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 mu, rs, m1, m2;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    int grp = (c0 + e) / g.cpg;
+    mu[e] = mean[b * g.G + grp];
+    rs[e] = rstd[b * g.G + grp];
+    m1[e] = s_s1[grp];
+    m2[e] = s_s2[grp];
+  }
+  int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
+  long base = ((long)b * g.HW) * g.C + c0;
+  for (int p = p0 + prow; p < p1; p += g.rows_par) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+    f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
+    f32x4 xh = (v - mu) * rs, o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
+      o[e] = rs[e] * (ge * ga[e] - m1[e] - xh[e] * m2[e]);
+    }
+    *reinterpret_cast<f32x4*>(dx + base + (long)p * g.C) = o;
+  }
+}
+
+__global__ void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
+                                    int nparts, int C) {
+  int c = blockIdx.x * blockDim.x + threadIdx.x;
+  if (c >= C) return;
+  float A = 0.f, Bx = 0.f;
+  for (int k = 0; k < nparts; ++k) {
+    const float* o = part + ((long)k * C + c) * 2;
+    A += o[0];
+    Bx += o[1];
+  }
+  dbeta[c] = A;
+  dgamma[c] = Bx;
+}
+
+static int check(const gad_groupnorm_args* a, const char* who) {
+  GAD_CHECK(a && a->x && a->y && a->gamma && a->beta && a->mean && a->rstd, "%s: null pointer", who);
+  GAD_CHECK(a->B > 0 && a->HW > 0 && a->C > 0 && a->G > 0 && a->C % a->G == 0, "%s: bad shape", who);
+  GAD_CHECK(a->C % 4 == 0 && a->C <= 1024 && a->G <= 256, "%s: needs C%%4==0, C<=1024, G<=256 (C=%d G=%d)", who, a->C, a->G);
+  GAD_CHECK(gad_aligned16(a->x) && gad_aligned16(a->y) && gad_aligned16(a->gamma) && gad_aligned16(a->beta), "%s: pointers must be 16-byte aligned", who);
+  int64_t need = gad_groupnorm_workspace_bytes(a);
+  GAD_CHECK(a->ws && a->ws_bytes >= need, "%s: workspace too small (%lld < %lld)", who, (long long)a->ws_bytes, (long long)need);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
+  Geo g = make_geo(a);
+  return (int64_t)a->B * g.nch * a->C * 2 * (int64_t)sizeof(float);  // covers fwd (G<=C) and bwd
+}
+
+extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream) {
+  if (check(a, "gad_groupnorm_silu_fwd")) return 1;
+  Geo g = make_geo(a);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a->B * g.nch), block(NT);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, a->x, (float*)a->ws, g);
+  GAD_LAUNCH_CHECK("gn_stats");
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, a->x, a->y, a->gamma, a->beta, (const float*)a->ws, a->mean, a->rstd, g, a->eps, a->silu);
+  GAD_LAUNCH_CHECK("gn_apply");
+  return 0;
+}
+
+extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream) {
+  if (check(a, "gad_groupnorm_silu_bwd")) return 1;
+  GAD_CHECK(a->dy && a->dgamma && a->dbeta && gad_aligned16(a->dy), "gad_groupnorm_silu_bwd: null/unaligned grad pointer");
+  Geo g = make_geo(a);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a->B * g.nch), block(NT);
+  hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, st, a->x, a->dy, a->gamma, a->beta, a->mean, a->rstd, (float*)a->ws, g, a->silu);
+  GAD_LAUNCH_CHECK("gn_bwd_stats");
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a->x, a->dy, a->y, a->gamma, a->beta, a->mean, a->rstd, (const float*)a->ws, g, a->silu);
+  GAD_LAUNCH_CHECK("gn_bwd_apply");
+  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, (const float*)a->ws, a->dgamma, a->dbeta, a->B * g.nch, a->C);
+  GAD_LAUNCH_CHECK("gn_bwd_param");
+  return 0;
+}

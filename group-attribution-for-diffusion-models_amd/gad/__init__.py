@@ -1,0 +1,12 @@
+"""gad - MI355X-native (gfx950) hot path of the Shapley data-attribution engine.
+
+The names exported here are the ones the reference takes from `diffusers`
+(main.py:22-24, src/diffusion_utils.py:15-23): entry points import this module in place of
+diffusers for the objects on the hot path."""
+from . import _capi, ops  # noqa: F401
+from .nn import LoRALinearLayer, UNet2DModel  # noqa: F401
+from .pipelines import DDIMPipeline, DDPMPipeline  # noqa: F401
+from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
+from .training import EMAModel, FusedTrainer  # noqa: F401
+
+__version__ = "0.1.0"

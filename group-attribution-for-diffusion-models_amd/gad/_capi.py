@@ -1,0 +1,108 @@
+"""ctypes binding of libgad_hip.so (C ABI declared in include/gad.h).
+
+The product path has NO fallback: if the shared library is missing or a call fails the
+caller gets an exception.  Loading the library needs no GPU (used by the CPU test that
+checks every declared symbol is exported)."""
+import ctypes as C
+import os
+
+_HERE = os.path.dirname(os.path.abspath(__file__))
+LIB_PATH = os.path.join(_HERE, "libgad_hip.so")
+
+
+class GadError(RuntimeError):
+    pass
+
+
+class ConvGeom(C.Structure):
+    _fields_ = [("H", C.c_int32), ("W", C.c_int32), ("C", C.c_int32), ("ldx", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32),
+                ("stride", C.c_int32), ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("upsample", C.c_int32)]
+
+
+class GemmArgs(C.Structure):
+    _fields_ = [("A", C.c_void_p), ("B", C.c_void_p), ("C", C.c_void_p),
+                ("a_mode", C.c_int32), ("b_mode", C.c_int32),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("ldb", C.c_int32), ("ldc", C.c_int32),
+                ("batch", C.c_int32), ("batch_inner", C.c_int32),
+                ("strideA0", C.c_int64), ("strideA1", C.c_int64), ("strideB0", C.c_int64),
+                ("strideB1", C.c_int64), ("strideC0", C.c_int64), ("strideC1", C.c_int64),
+                ("g", ConvGeom),
+                ("alpha", C.c_float), ("bias", C.c_void_p), ("rowadd", C.c_void_p),
+                ("rows_per_group", C.c_int32), ("ld_rowadd", C.c_int32),
+                ("residual", C.c_void_p), ("ldr", C.c_int32),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32)]
+
+
+class GroupNormArgs(C.Structure):
+    _fields_ = [("x", C.c_void_p), ("y", C.c_void_p), ("gamma", C.c_void_p), ("beta", C.c_void_p),
+                ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dy", C.c_void_p),
+                ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
+                ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("G", C.c_int32),
+                ("eps", C.c_float), ("silu", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+
+
+class AdamArgs(C.Structure):
+    _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
+                ("n", C.c_int64), ("sumsq", C.c_void_p), ("max_norm", C.c_float),
+                ("lr", C.c_float), ("beta1", C.c_float), ("beta2", C.c_float), ("eps", C.c_float),
+                ("weight_decay", C.c_float), ("adamw", C.c_int32), ("step", C.c_int32), ("ema_decay", C.c_float)]
+
+
+A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
+B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
+
+_vp, _i32, _i64, _f32 = C.c_void_p, C.c_int32, C.c_int64, C.c_float
+
+# name -> (restype, argtypes); every symbol include/gad.h declares
+SIGNATURES = {
+    "gad_version": (C.c_int, []),
+    "gad_last_error": (C.c_char_p, []),
+    "gad_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
+    "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
+    "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_softmax_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
+    "gad_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "gad_silu_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gad_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gad_concat_channels": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gad_split_channels": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),
+    "gad_nchw_to_nhwc": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "gad_nhwc_to_nchw": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _vp]),
+    "gad_upsample2x_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gad_colsum": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
+    "gad_add_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
+    "gad_ddim_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
+    "gad_to_image01": (C.c_int, [_vp, _vp, _i64, _vp]),
+    "gad_mse_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp, _i64, _vp]),
+    "gad_sumsq": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
+    "gad_clip_adam_ema": (C.c_int, [C.POINTER(AdamArgs), _vp]),
+    "gad_ema_update": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
+}
+
+_lib = None
+
+
+def load():
+    """Load the shared library (raises GadError if it has not been built)."""
+    global _lib
+    if _lib is None:
+        if not os.path.exists(LIB_PATH):
+            raise GadError(f"{LIB_PATH} not found: build it with `python -c 'import __graft_entry__ as g; g.build()'` "
+                           "(the product path has no CPU fallback)")
+        lib = C.CDLL(LIB_PATH)
+        for name, (res, args) in SIGNATURES.items():
+            fn = getattr(lib, name)     # AttributeError if a declared symbol is not exported
+            fn.restype, fn.argtypes = res, args
+        _lib = lib
+    return _lib
+
+
+def check(rc, what):
+    if rc != 0:
+        raise GadError(f"{what} failed (rc={rc}): {load().gad_last_error().decode()}")

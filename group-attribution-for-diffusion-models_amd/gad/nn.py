@@ -1,0 +1,369 @@
+"""diffusers-0.24-compatible model classes whose forward/backward run on the HIP
+kernels (boundary (i) of SURVEY §8b: same class names, constructor keys, attribute and
+state_dict names as the objects the reference builds at
+unconditional_generation/main.py:234,332 and src/diffusion_utils.py:153).
+
+Internals are MI355X-first: activations NHWC, conv weights stored [Cout,KH,KW,Cin],
+all parameters (optionally) packed into one flat HBM buffer so that gradient clipping,
+Adam and the EMA run as a single fused pass (``flatten_parameters``).
+"""
+from __future__ import annotations
+
+import math
+from types import SimpleNamespace
+
+import torch
+import torch.nn as nn
+
+from . import ops
+
+
+class FrozenConfig(dict):
+    """dict with attribute access (mimics diffusers' FrozenDict ``model.config``)."""
+
+    def __getattr__(self, k):
+        try:
+            return self[k]
+        except KeyError as e:
+            raise AttributeError(k) from e
+
+
+# ----------------------------------------------------------------------------------
+# parameter holders (names match torch/diffusers so state_dicts interchange)
+# ----------------------------------------------------------------------------------
+class Conv2d(nn.Module):
+    def __init__(self, cin, cout, k, stride=1, pad=(1, 1, 1, 1), upsample=False):
+        super().__init__()
+        ref = nn.Conv2d(cin, cout, k)          # torch default init == diffusers default init
+        self.weight = nn.Parameter(ref.weight.detach().contiguous(memory_format=torch.channels_last))
+        self.bias = nn.Parameter(ref.bias.detach().clone())
+        self.stride, self.pad, self.upsample = stride, tuple(pad), upsample
+
+    def forward(self, x, rowadd=None, residual=None):
+        return ops.conv2d(x, self.weight, self.bias, rowadd, residual, self.stride, self.pad, self.upsample)
+
+
+class Linear(nn.Module):
+    def __init__(self, cin, cout, bias=True):
+        super().__init__()
+        ref = nn.Linear(cin, cout, bias=bias)
+        self.weight = nn.Parameter(ref.weight.detach().clone())
+        self.bias = nn.Parameter(ref.bias.detach().clone()) if bias else None
+        self.lora_layer = None
+
+    def set_lora_layer(self, lora_layer):
+        self.lora_layer = lora_layer
+
+    def forward(self, x, residual=None, scale: float = 1.0):
+        if self.lora_layer is None:
+            return ops.linear(x, self.weight, self.bias, residual)
+        # y = xW^T + b + scale * up(down(x)): the rank-r side path accumulates into the base
+        # GEMM's output through the residual epilogue (LoRACompatibleLinear)
+        base = ops.linear(x, self.weight, self.bias, residual)
+        return self.lora_layer(x, residual=base, scale=scale)
+
+
+class LoRALinearLayer(nn.Module):
+    """diffusers.models.lora.LoRALinearLayer: down ~ N(0, 1/rank), up = 0;
+    ranks may differ per projection (text_to_image/prune_lora.py:173-180)."""
+
+    def __init__(self, in_features, out_features, rank=4, network_alpha=None):
+        super().__init__()
+        self.down = Linear(in_features, rank, bias=False)
+        self.up = Linear(rank, out_features, bias=False)
+        nn.init.normal_(self.down.weight, std=1 / rank)
+        nn.init.zeros_(self.up.weight)
+        self.network_alpha, self.rank = network_alpha, rank
+        self.in_features, self.out_features = in_features, out_features
+
+    def forward(self, x, residual=None, scale: float = 1.0):
+        s = scale * (self.network_alpha / self.rank if self.network_alpha is not None else 1.0)
+        mid = self.down(x)
+        if s != 1.0:
+            mid = mid * s
+        return self.up(mid, residual=residual)
+
+
+class GroupNorm(nn.Module):
+    def __init__(self, groups, channels, eps):
+        super().__init__()
+        self.weight = nn.Parameter(torch.ones(channels))
+        self.bias = nn.Parameter(torch.zeros(channels))
+        self.num_groups, self.eps = groups, eps
+
+    def forward(self, x, silu=False):
+        return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+
+
+# ----------------------------------------------------------------------------------
+# blocks
+# ----------------------------------------------------------------------------------
+class ResnetBlock2D(nn.Module):
+    def __init__(self, cin, cout, temb_c, groups, eps):
+        super().__init__()
+        self.norm1 = GroupNorm(groups, cin, eps)
+        self.conv1 = Conv2d(cin, cout, 3)
+        self.time_emb_proj = Linear(temb_c, cout)
+        self.norm2 = GroupNorm(groups, cout, eps)
+        self.conv2 = Conv2d(cout, cout, 3)
+        self.conv_shortcut = Conv2d(cin, cout, 1, pad=(0, 0, 0, 0)) if cin != cout else None
+
+    def forward(self, x, temb_act):
+        h = self.norm1(x, silu=True)
+        h = self.conv1(h, rowadd=self.time_emb_proj(temb_act))       # conv + bias + temb add, one kernel
+        h = self.norm2(h, silu=True)
+        sc = self.conv_shortcut(x) if self.conv_shortcut is not None else x
+        return self.conv2(h, residual=sc)                             # conv + bias + skip add, one kernel
+
+
+class Attention(nn.Module):
+    """Self-attention block with the semantics of AttnProcessor2_0
+    (reference src/diffusers/models/attention_processor.py:1265-1341)."""
+
+    def __init__(self, channels, heads, dim_head, eps, groups):
+        super().__init__()
+        inner = heads * dim_head
+        self.heads = heads
+        self.group_norm = GroupNorm(groups, channels, eps)
+        self.to_q = Linear(channels, inner)
+        self.to_k = Linear(channels, inner)
+        self.to_v = Linear(channels, inner)
+        self.to_out = nn.ModuleList([Linear(inner, channels), nn.Dropout(0.0)])
+
+    def forward(self, x, scale: float = 1.0):
+        b, hh, ww, c = x.shape
+        res = x.view(b, hh * ww, c)
+        h = self.group_norm(x).view(b, hh * ww, c)                   # :1297-1298 (NHWC: no transposes needed)
+        q, k, v = self.to_q(h, scale=scale), self.to_k(h, scale=scale), self.to_v(h, scale=scale)   # :1301-1309
+        o = ops.attention_core(q, k, v, self.heads)                   # :1314-1325
+        o = self.to_out[0](o, residual=res, scale=scale)              # :1329 + residual :1336-1337
+        return o.view(b, hh, ww, c)
+
+
+class DownBlock(nn.Module):
+    def __init__(self, cin, cout, temb_c, layers, eps, groups, add_down, down_pad, head_dim=None):
+        super().__init__()
+        resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_c, groups, eps)
+                                 for i in range(layers)])
+        # registration order attentions -> resnets as in diffusers (parameters() order == EMA shadow list order)
+        self.attentions = nn.ModuleList([Attention(cout, cout // head_dim, head_dim, eps, groups)
+                                         for _ in range(layers)]) if head_dim is not None else None
+        self.resnets = resnets
+        if add_down:
+            pad = (0, 1, 0, 1) if down_pad == 0 else (down_pad,) * 4   # Downsample2D: F.pad(0,1,0,1) when padding==0
+            self.downsamplers = nn.ModuleList([_Sampler(Conv2d(cout, cout, 3, stride=2, pad=pad))])
+        else:
+            self.downsamplers = None
+
+    def forward(self, h, temb_act):
+        outs = ()
+        for i, r in enumerate(self.resnets):
+            h = r(h, temb_act)
+            if self.attentions is not None:
+                h = self.attentions[i](h)
+            outs += (h,)
+        if self.downsamplers is not None:
+            h = self.downsamplers[0](h)
+            outs += (h,)
+        return h, outs
+
+
+class _Sampler(nn.Module):
+    """Down/Upsample2D wrapper so the parameter is named ``...samplers.0.conv.weight``."""
+
+    def __init__(self, conv):
+        super().__init__()
+        self.conv = conv
+
+    def forward(self, x):
+        return self.conv(x)
+
+
+class UNetMidBlock2D(nn.Module):
+    def __init__(self, c, temb_c, eps, groups, head_dim, add_attention=True):
+        super().__init__()
+        resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps), ResnetBlock2D(c, c, temb_c, groups, eps)])
+        self.attentions = nn.ModuleList([Attention(c, c // head_dim, head_dim, eps, groups) if add_attention else None])
+        self.resnets = resnets
+
+    def forward(self, h, temb_act):
+        h = self.resnets[0](h, temb_act)
+        if self.attentions[0] is not None:
+            h = self.attentions[0](h)
+        return self.resnets[1](h, temb_act)
+
+
+class UpBlock(nn.Module):
+    def __init__(self, cin, prev_c, cout, temb_c, layers, eps, groups, add_up, head_dim=None):
+        super().__init__()
+        res = []
+        for i in range(layers):
+            skip_c = cin if i == layers - 1 else cout
+            r_in = prev_c if i == 0 else cout
+            res.append(ResnetBlock2D(r_in + skip_c, cout, temb_c, groups, eps))
+        self.attentions = nn.ModuleList([Attention(cout, cout // head_dim, head_dim, eps, groups)
+                                         for _ in range(layers)]) if head_dim is not None else None
+        self.resnets = nn.ModuleList(res)
+        self.upsamplers = nn.ModuleList([_Sampler(Conv2d(cout, cout, 3, upsample=True))]) if add_up else None
+
+    def forward(self, h, skips, temb_act):
+        for i, r in enumerate(self.resnets):
+            s, skips = skips[-1], skips[:-1]
+            h = r(ops.concat(h, s), temb_act)
+            if self.attentions is not None:
+                h = self.attentions[i](h)
+        if self.upsamplers is not None:
+            h = self.upsamplers[0](h)                                 # nearest-2x fused into the conv's gather
+        return h
+
+
+class TimestepEmbedding(nn.Module):
+    def __init__(self, cin, dim):
+        super().__init__()
+        self.linear_1 = Linear(cin, dim)
+        self.linear_2 = Linear(dim, dim)
+
+    def forward(self, x):
+        return self.linear_2(ops.silu(self.linear_1(x)))
+
+
+class UNet2DModel(nn.Module):
+    """diffusers.UNet2DModel on HIP kernels.  Accepts every key of the reference config
+    dicts (src/ddpm_config.py:235-269, :423-451); unknown keys are kept in ``.config``."""
+
+    def __init__(self, sample_size=None, in_channels=3, out_channels=3, center_input_sample=False,
+                 time_embedding_type="positional", freq_shift=0, flip_sin_to_cos=True,
+                 down_block_types=("DownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D", "AttnDownBlock2D"),
+                 up_block_types=("AttnUpBlock2D", "AttnUpBlock2D", "AttnUpBlock2D", "UpBlock2D"),
+                 block_out_channels=(224, 448, 672, 896), layers_per_block=2, mid_block_scale_factor=1,
+                 downsample_padding=1, downsample_type="conv", upsample_type="conv", dropout=0.0,
+                 act_fn="silu", attention_head_dim=8, norm_num_groups=32, attn_norm_num_groups=None,
+                 norm_eps=1e-5, resnet_time_scale_shift="default", add_attention=True,
+                 class_embed_type=None, num_class_embeds=None, num_train_timesteps=None, **unused):
+        super().__init__()
+        cfg = dict(locals())
+        for k in ("self", "unused", "__class__"):
+            cfg.pop(k, None)
+        cfg.update(unused)
+        self.config = FrozenConfig(cfg)
+        if not (time_embedding_type == "positional" and act_fn == "silu" and class_embed_type is None
+                and downsample_type == "conv" and upsample_type == "conv" and resnet_time_scale_shift == "default"
+                and dropout == 0.0 and mid_block_scale_factor == 1 and attn_norm_num_groups is None):
+            raise NotImplementedError("UNet2DModel: configuration outside the reference's registry")
+        boc = list(block_out_channels)
+        temb_c = boc[0] * 4
+        self.conv_in = Conv2d(in_channels, boc[0], 3)
+        self.time_proj = SimpleNamespace(num_channels=boc[0], flip_sin_to_cos=flip_sin_to_cos,
+                                         downscale_freq_shift=freq_shift)
+        self.time_embedding = TimestepEmbedding(boc[0], temb_c)
+        self.down_blocks = nn.ModuleList()
+        out_c = boc[0]
+        for i, typ in enumerate(down_block_types):
+            in_c, out_c = out_c, boc[i]
+            hd = None
+            if typ == "AttnDownBlock2D":
+                hd = attention_head_dim if attention_head_dim is not None else out_c
+            elif typ != "DownBlock2D":
+                raise NotImplementedError(typ)
+            self.down_blocks.append(DownBlock(in_c, out_c, temb_c, layers_per_block, norm_eps, norm_num_groups,
+                                              i != len(boc) - 1, downsample_padding, hd))
+        self.mid_block = UNetMidBlock2D(boc[-1], temb_c, norm_eps, norm_num_groups,
+                                        attention_head_dim if attention_head_dim is not None else boc[-1],
+                                        add_attention)
+        self.up_blocks = nn.ModuleList()
+        rev = list(reversed(boc))
+        out_c = rev[0]
+        for i, typ in enumerate(up_block_types):
+            prev_c, out_c = out_c, rev[i]
+            in_c = rev[min(i + 1, len(boc) - 1)]
+            hd = None
+            if typ == "AttnUpBlock2D":
+                hd = attention_head_dim if attention_head_dim is not None else out_c
+            elif typ != "UpBlock2D":
+                raise NotImplementedError(typ)
+            self.up_blocks.append(UpBlock(in_c, prev_c, out_c, temb_c, layers_per_block + 1, norm_eps,
+                                          norm_num_groups, i != len(boc) - 1, hd))
+        g = norm_num_groups if norm_num_groups is not None else min(boc[0] // 4, 32)
+        self.conv_norm_out = GroupNorm(g, boc[0], norm_eps)
+        self.conv_out = Conv2d(boc[0], out_channels, 3)
+        self._flat = None
+
+    # ---- diffusers ModelMixin conveniences used by the reference ----
+    @property
+    def dtype(self):
+        return self.conv_in.bias.dtype
+
+    @property
+    def device(self):
+        return self.conv_in.bias.device
+
+    def forward_nhwc(self, x, timestep):
+        """x: NHWC fp32 device tensor; returns NHWC eps prediction."""
+        t = timestep
+        if not torch.is_tensor(t):
+            t = torch.tensor([t], dtype=torch.long, device=x.device)
+        elif t.ndim == 0:
+            t = t[None]
+        t = t.to(x.device)
+        if t.shape[0] != x.shape[0]:
+            t = t.expand(x.shape[0])
+        tp = self.time_proj
+        emb = ops.timestep_embedding(t, tp.num_channels, tp.flip_sin_to_cos, tp.downscale_freq_shift)
+        temb_act = ops.silu(self.time_embedding(emb))       # SiLU(temb) is shared by every ResnetBlock2D
+        h = self.conv_in(x)
+        skips = (h,)
+        for blk in self.down_blocks:
+            h, outs = blk(h, temb_act)
+            skips += outs
+        h = self.mid_block(h, temb_act)
+        for blk in self.up_blocks:
+            n = len(blk.resnets)
+            res, skips = skips[-n:], skips[:-n]
+            h = blk(h, res, temb_act)
+        h = self.conv_norm_out(h, silu=True)
+        return self.conv_out(h)
+
+    def forward(self, sample, timestep):
+        """sample: NCHW (diffusers convention) -> object with ``.sample`` NCHW."""
+        if not sample.is_cuda:
+            raise ops._capi.GadError("gad.UNet2DModel runs on the MI355X only (no CPU path); got a CPU tensor")
+        x = sample.to(torch.float32).contiguous()
+        if self.config.center_input_sample:
+            x = 2 * x - 1.0
+        y = self.forward_nhwc(ops.nchw_to_nhwc_raw(x), timestep)
+        return SimpleNamespace(sample=ops.to_nchw(y))
+
+    # ---- flat parameter storage ----
+    def flatten_parameters(self):
+        """Re-home every parameter (and its .grad) in one contiguous fp32 buffer; conv weights keep
+        their [Cout,KH,KW,Cin] storage.  Returns (flat_params, flat_grads)."""
+        params = list(self.parameters())
+        dev = params[0].device
+        sizes = [(p.numel() + 3) // 4 * 4 for p in params]           # keep every slice 16-B aligned
+        total = sum(sizes)
+        flat = torch.zeros(total, device=dev, dtype=torch.float32)
+        gflat = torch.zeros(total, device=dev, dtype=torch.float32)
+        off = 0
+        with torch.no_grad():
+            for p, sz in zip(params, sizes):
+                n = p.numel()
+
+                def view_like(buf, p=p, off=off, n=n):
+                    if p.ndim == 4:
+                        o, i, kh, kw = p.shape
+                        return buf[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+                    return buf[off:off + n].view(p.shape)
+
+                v = view_like(flat)
+                v.copy_(p)
+                p.data = v
+                p.grad = view_like(gflat)
+                off += sz
+        self._flat = (flat, gflat)
+        return flat, gflat
+
+    @property
+    def flat(self):
+        if self._flat is None:
+            raise ops._capi.GadError("call model.flatten_parameters() first")
+        return self._flat

@@ -1,0 +1,498 @@
+"""Host-side operators over the C ABI: raw launch wrappers (``*_raw``) and
+``torch.autograd.Function`` s that chain them.  PyTorch supplies device memory, the
+stream and the autograd graph; every FLOP runs in libgad_hip.so.
+
+Layout: activations are contiguous fp32 NHWC tensors ``[B, H, W, C]`` (or ``[M, C]``),
+conv weights are parameters of logical shape ``[Cout, Cin, KH, KW]`` whose storage is
+``[Cout, KH, KW, Cin]`` (torch channels_last), Linear weights ``[out, in]``.
+"""
+from __future__ import annotations
+
+import ctypes as C
+import math
+from typing import Optional
+
+import torch
+
+from . import _capi
+from ._capi import (A_CONV, A_CONVT, A_KC, A_MC, B_CONV, B_KC, B_MC, B_WDGRAD, AdamArgs, ConvGeom, GemmArgs,
+                    GroupNormArgs, check)
+
+# ----------------------------------------------------------------------------------
+# plumbing
+# ----------------------------------------------------------------------------------
+_WS = {}
+WS_BYTES = 1 << 30
+
+
+def _stream():
+    return C.c_void_p(torch.cuda.current_stream().cuda_stream)
+
+
+def workspace(device) -> torch.Tensor:
+    """One caller-owned scratch buffer per device (split-K partials, reduction partials).
+    Allocated once so that hipGraph replays see a fixed address."""
+    key = (device.type, device.index)
+    ws = _WS.get(key)
+    if ws is None:
+        ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)
+        _WS[key] = ws
+    return ws
+
+
+def _ptr(t: Optional[torch.Tensor]):
+    return None if t is None else t.data_ptr()
+
+
+def _req(t: torch.Tensor, name: str):
+    if not (t.is_cuda and t.dtype == torch.float32 and t.is_contiguous()):
+        raise _capi.GadError(f"{name}: expected a contiguous fp32 device tensor, got {t.dtype} {t.device} "
+                             f"contiguous={t.is_contiguous()}")
+    return t
+
+
+def weight_krsc(w: torch.Tensor) -> torch.Tensor:
+    """View of a conv parameter as its physical [Cout, KH, KW, Cin] array (no copy)."""
+    v = w.permute(0, 2, 3, 1)
+    if not v.is_contiguous():
+        raise _capi.GadError("conv weight storage must be [Cout,KH,KW,Cin] (channels_last)")
+    return v
+
+
+# ----------------------------------------------------------------------------------
+# raw contraction launches
+# ----------------------------------------------------------------------------------
+def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
+             bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0):
+    lib = _capi.load()
+    ws = workspace(A.device)
+    a = GemmArgs()
+    a.A, a.B, a.C = A.data_ptr(), B.data_ptr(), Cout.data_ptr()
+    a.a_mode, a.b_mode = a_mode, b_mode
+    a.M, a.N, a.K = M, N, K
+    a.lda, a.ldb, a.ldc = lda, ldb, ldc
+    a.batch, a.batch_inner = batch, batch_inner
+    a.strideA0, a.strideA1 = sA
+    a.strideB0, a.strideB1 = sB
+    a.strideC0, a.strideC1 = sC
+    if geom is not None:
+        a.g = geom
+    a.alpha = alpha
+    a.bias, a.rowadd, a.residual = _ptr(bias), _ptr(rowadd), _ptr(residual)
+    a.rows_per_group = rows_per_group
+    a.ld_rowadd = rowadd.shape[-1] if rowadd is not None else 0
+    a.ldr = ldr
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
+    check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+
+
+def _conv_out_size(h, k, stride, pad_lo, pad_hi):
+    return (h + pad_lo + pad_hi - k) // stride + 1
+
+
+def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowadd=None, residual=None,
+                   tile_hint=0, splitk_hint=0):
+    """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; pad = (top, bottom, left, right)."""
+    _req(x, "conv x")
+    Bn, H, W, Cin = x.shape
+    wk = weight_krsc(w)
+    Cout, KH, KW, _ = wk.shape
+    He, We = (2 * H, 2 * W) if upsample else (H, W)
+    Ho = _conv_out_size(He, KH, stride, pad[0], pad[1])
+    Wo = _conv_out_size(We, KW, stride, pad[2], pad[3])
+    y = torch.empty((Bn, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
+    if residual is not None:
+        _req(residual, "conv residual")
+    gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
+             bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
+             tile_hint=tile_hint, splitk_hint=splitk_hint)
+    return y
+
+
+def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False):
+    """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] (sums the 2x2 replicas if the conv was upsample-fused)."""
+    _req(dy, "conv dy")
+    Bn, H, W, Cin = x_shape
+    wk = weight_krsc(w)
+    Cout, KH, KW, _ = wk.shape
+    _, Ho, Wo, _ = dy.shape
+    He, We = (2 * H, 2 * W) if upsample else (H, W)
+    dxe = torch.empty((Bn, He, We, Cin), device=dy.device, dtype=torch.float32)
+    g = ConvGeom(Ho, Wo, Cout, Cout, He, We, KH, KW, stride, pad[0], pad[2], 0)
+    gemm_raw(dy, wk, dxe, A_CONVT, B_WDGRAD, Bn * He * We, Cin, KH * KW * Cout, 0, 0, Cin, geom=g)
+    if not upsample:
+        return dxe
+    dx = torch.empty((Bn, H, W, Cin), device=dy.device, dtype=torch.float32)
+    check(_capi.load().gad_upsample2x_bwd(dxe.data_ptr(), dx.data_ptr(), Bn, H, W, Cin, _stream()), "gad_upsample2x_bwd")
+    return dx
+
+
+def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False):
+    """dW with the parameter's logical shape [Cout,Cin,KH,KW] and channels_last storage."""
+    _req(dy, "conv dy")
+    _req(x, "conv x")
+    Bn, H, W, Cin = x.shape
+    Cout, _, KH, KW = w_like.shape
+    _, Ho, Wo, _ = dy.shape
+    dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+    g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
+    gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g)
+    return dwk.permute(0, 3, 1, 2)
+
+
+def colsum_raw(dy2d: torch.Tensor, segments=1):
+    """[S*M, N] -> [S, N] column sums per segment."""
+    lib = _capi.load()
+    ws = workspace(dy2d.device)
+    rows, N = dy2d.shape
+    out = torch.empty((segments, N), device=dy2d.device, dtype=torch.float32)
+    check(lib.gad_colsum(dy2d.data_ptr(), out.data_ptr(), segments, rows // segments, N, ws.data_ptr(), ws.numel(),
+                         _stream()), "gad_colsum")
+    return out
+
+
+def linear_fwd_raw(x2d, w, bias=None, residual=None, alpha=1.0):
+    M, K = x2d.shape
+    N = w.shape[0]
+    y = torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    gemm_raw(x2d, w, y, A_KC, B_KC, M, N, K, K, K, N, bias=bias, residual=residual, ldr=N, alpha=alpha)
+    return y
+
+
+def linear_dgrad_raw(dy2d, w):
+    M, N = dy2d.shape
+    K = w.shape[1]
+    dx = torch.empty((M, K), device=dy2d.device, dtype=torch.float32)
+    gemm_raw(dy2d, w, dx, A_KC, B_MC, M, K, N, N, K, K)
+    return dx
+
+
+def linear_wgrad_raw(dy2d, x2d):
+    M, N = dy2d.shape
+    K = x2d.shape[1]
+    dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+    gemm_raw(dy2d, x2d, dw, A_MC, B_MC, N, K, M, N, K, K)
+    return dw
+
+
+# ----------------------------------------------------------------------------------
+# autograd functions
+# ----------------------------------------------------------------------------------
+class Conv2dFn(torch.autograd.Function):
+    """y = conv(x) + bias + rowadd[b] (time-embedding add) + residual, all fused in the
+    contraction epilogue (ResnetBlock2D / Downsample2D / Upsample2D)."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, rowadd, residual, stride, pad, upsample):
+        ctx.save_for_backward(x, w)
+        ctx.cfg = (stride, pad, upsample, bias is not None, rowadd is not None, residual is not None)
+        return conv2d_fwd_raw(x, w, bias, stride, pad, upsample, rowadd, residual)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, w = ctx.saved_tensors
+        stride, pad, upsample, has_b, has_r, has_res = ctx.cfg
+        dy = dy.contiguous()
+        Bn, Ho, Wo, Cout = dy.shape
+        dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample) if ctx.needs_input_grad[0] else None
+        dw = conv2d_wgrad_raw(dy, x, w, stride, pad, upsample) if ctx.needs_input_grad[1] else None
+        db = dr = None
+        if has_r and ctx.needs_input_grad[3]:
+            dr = colsum_raw(dy.view(Bn * Ho * Wo, Cout), segments=Bn)
+            if has_b and ctx.needs_input_grad[2]:
+                db = colsum_raw(dr, 1).view(Cout)
+        elif has_b and ctx.needs_input_grad[2]:
+            db = colsum_raw(dy.view(Bn * Ho * Wo, Cout), 1).view(Cout)
+        dres = dy if (has_res and ctx.needs_input_grad[4]) else None
+        return dx, dw, db, dr, dres, None, None, None
+
+
+def conv2d(x, w, bias=None, rowadd=None, residual=None, stride=1, pad=(1, 1, 1, 1), upsample=False):
+    return Conv2dFn.apply(x, w, bias, rowadd, residual, stride, pad, upsample)
+
+
+class LinearFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, w, bias, residual):
+        shp = x.shape
+        x2 = _req(x, "linear x").view(-1, shp[-1])
+        ctx.save_for_backward(x2, w)
+        ctx.shp = shp
+        ctx.flags = (bias is not None, residual is not None)
+        r2 = residual.view(-1, w.shape[0]) if residual is not None else None
+        return linear_fwd_raw(x2, w, bias, r2).view(*shp[:-1], w.shape[0])
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w = ctx.saved_tensors
+        dy2 = dy.contiguous().view(-1, w.shape[0])
+        dx = linear_dgrad_raw(dy2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
+        dw = linear_wgrad_raw(dy2, x2) if ctx.needs_input_grad[1] else None
+        db = colsum_raw(dy2, 1).view(-1) if (ctx.flags[0] and ctx.needs_input_grad[2]) else None
+        dres = dy if (ctx.flags[1] and ctx.needs_input_grad[3]) else None
+        return dx, dw, db, dres
+
+
+def linear(x, w, bias=None, residual=None):
+    return LinearFn.apply(x, w, bias, residual)
+
+
+def _gn_args(x, y, gamma, beta, mean, rstd, G, eps, silu):
+    a = GroupNormArgs()
+    Bn, C_ = x.shape[0], x.shape[-1]
+    HW = x.numel() // (Bn * C_)
+    ws = workspace(x.device)
+    a.x, a.y, a.gamma, a.beta = x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr()
+    a.mean, a.rstd = mean.data_ptr(), rstd.data_ptr()
+    a.B, a.HW, a.C, a.G = Bn, HW, C_, G
+    a.eps, a.silu = eps, int(silu)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    return a
+
+
+class GroupNormSiluFn(torch.autograd.Function):
+    """y = [SiLU](GroupNorm(x)) on NHWC; x is [B, ..., C]."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, silu):
+        _req(x, "groupnorm x")
+        y = torch.empty_like(x)
+        mean = torch.empty((x.shape[0], G), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        a = _gn_args(x, y, gamma, beta, mean, rstd, G, eps, silu)
+        check(_capi.load().gad_groupnorm_silu_fwd(C.byref(a), _stream()), "gad_groupnorm_silu_fwd")
+        ctx.save_for_backward(x, gamma, beta, mean, rstd)
+        ctx.cfg = (G, eps, silu)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, beta, mean, rstd = ctx.saved_tensors
+        G, eps, silu = ctx.cfg
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
+        a.dy, a.dgamma, a.dbeta = dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
+        return dx, dgamma, dbeta, None, None, None
+
+
+def group_norm(x, gamma, beta, G, eps, silu):
+    return GroupNormSiluFn.apply(x, gamma, beta, G, eps, silu)
+
+
+class SiluFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        _req(x, "silu x")
+        y = torch.empty_like(x)
+        check(_capi.load().gad_silu_fwd(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gad_silu_fwd")
+        ctx.save_for_backward(x)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        (x,) = ctx.saved_tensors
+        dy = dy.contiguous()
+        dx = torch.empty_like(x)
+        check(_capi.load().gad_silu_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), x.numel(), _stream()), "gad_silu_bwd")
+        return dx
+
+
+def silu(x):
+    return SiluFn.apply(x)
+
+
+class ConcatFn(torch.autograd.Function):
+    """torch.cat([h, skip], dim=channel) for NHWC tensors (UpBlock2D skip connections)."""
+
+    @staticmethod
+    def forward(ctx, a, b):
+        _req(a, "concat a")
+        _req(b, "concat b")
+        C1, C2 = a.shape[-1], b.shape[-1]
+        out = torch.empty((*a.shape[:-1], C1 + C2), device=a.device, dtype=torch.float32)
+        check(_capi.load().gad_concat_channels(a.data_ptr(), b.data_ptr(), out.data_ptr(), a.numel() // C1, C1, C2,
+                                               _stream()), "gad_concat_channels")
+        ctx.cs = (C1, C2)
+        return out
+
+    @staticmethod
+    def backward(ctx, d):
+        C1, C2 = ctx.cs
+        d = d.contiguous()
+        da = torch.empty((*d.shape[:-1], C1), device=d.device, dtype=torch.float32)
+        db = torch.empty((*d.shape[:-1], C2), device=d.device, dtype=torch.float32)
+        check(_capi.load().gad_split_channels(d.data_ptr(), da.data_ptr(), db.data_ptr(), d.numel() // (C1 + C2), C1, C2,
+                                              _stream()), "gad_split_channels")
+        return da, db
+
+
+def concat(a, b):
+    return ConcatFn.apply(a, b)
+
+
+def nchw_to_nhwc_raw(x):
+    Bn, C_, H, W = x.shape
+    y = torch.empty((Bn, H, W, C_), device=x.device, dtype=torch.float32)
+    check(_capi.load().gad_nchw_to_nhwc(x.data_ptr(), y.data_ptr(), Bn, C_, H * W, _stream()), "gad_nchw_to_nhwc")
+    return y
+
+
+def nhwc_to_nchw_raw(x):
+    Bn, H, W, C_ = x.shape
+    y = torch.empty((Bn, C_, H, W), device=x.device, dtype=torch.float32)
+    check(_capi.load().gad_nhwc_to_nchw(x.data_ptr(), y.data_ptr(), Bn, C_, H * W, _stream()), "gad_nhwc_to_nchw")
+    return y
+
+
+class ToNCHWFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x):
+        return nhwc_to_nchw_raw(_req(x, "to_nchw x"))
+
+    @staticmethod
+    def backward(ctx, dy):
+        return nchw_to_nhwc_raw(dy.contiguous())
+
+
+def to_nchw(x):
+    return ToNCHWFn.apply(x)
+
+
+def timestep_embedding(t: torch.Tensor, dim, flip_sin_to_cos, freq_shift, max_period=10000.0):
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty((t.shape[0], dim), device=t.device, dtype=torch.float32)
+    check(_capi.load().gad_timestep_embedding(t.data_ptr(), out.data_ptr(), t.shape[0], dim, int(flip_sin_to_cos),
+                                              float(freq_shift), float(max_period), _stream()), "gad_timestep_embedding")
+    return out
+
+
+# ---- attention core: softmax(q k^T / sqrt(d)) v with q,k,v given as [B, T, heads*d] ----
+def _attn_gemm(A, B, Cm, a_mode, b_mode, M, N, K, lda, ldb, ldc, Bn, heads, sA, sB, sC, alpha=1.0):
+    gemm_raw(A, B, Cm, a_mode, b_mode, M, N, K, lda, ldb, ldc, alpha=alpha, batch=Bn * heads, batch_inner=heads,
+             sA=sA, sB=sB, sC=sC)
+
+
+class AttentionCoreFn(torch.autograd.Function):
+    """F.scaled_dot_product_attention(q, k, v) of AttnProcessor2_0
+    (reference src/diffusers/models/attention_processor.py:1314-1325) on [B, T, heads*d]
+    operands: two batched contractions and one row-softmax kernel; P is kept for backward."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        for t_, n_ in ((q, "q"), (k, "k"), (v, "v")):
+            _req(t_, n_)
+        Bn, Tq, Cq = q.shape
+        Tk = k.shape[1]
+        d = Cq // heads
+        scale = 1.0 / math.sqrt(d)
+        S = torch.empty((Bn, heads, Tq, Tk), device=q.device, dtype=torch.float32)
+        _attn_gemm(q, k, S, A_KC, B_KC, Tq, Tk, d, Cq, Cq, Tk, Bn, heads,
+                   (Tq * Cq, d), (Tk * Cq, d), (heads * Tq * Tk, Tq * Tk))
+        check(_capi.load().gad_softmax_fwd(S.data_ptr(), S.data_ptr(), Bn * heads * Tq, Tk, scale, _stream()),
+              "gad_softmax_fwd")
+        o = torch.empty((Bn, Tq, Cq), device=q.device, dtype=torch.float32)
+        _attn_gemm(S, v, o, A_KC, B_MC, Tq, d, Tk, Tk, Cq, Cq, Bn, heads,
+                   (heads * Tq * Tk, Tq * Tk), (Tk * Cq, d), (Tq * Cq, d))
+        ctx.save_for_backward(q, k, v, S)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, P = ctx.saved_tensors
+        heads = ctx.heads
+        do = do.contiguous()
+        Bn, Tq, Cq = q.shape
+        Tk = k.shape[1]
+        d = Cq // heads
+        scale = 1.0 / math.sqrt(d)
+        sP = (heads * Tq * Tk, Tq * Tk)
+        sQ, sK = (Tq * Cq, d), (Tk * Cq, d)
+        # dV[b,h] = P^T dO   (A = P as [k=Tq][m=Tk], B = dO as [k=Tq][n=d])
+        dv = torch.empty_like(v)
+        _attn_gemm(P, do, dv, A_MC, B_MC, Tk, d, Tq, Tk, Cq, Cq, Bn, heads, sP, sQ, sK)
+        # dP = dO V^T
+        dP = torch.empty_like(P)
+        _attn_gemm(do, v, dP, A_KC, B_KC, Tq, Tk, d, Cq, Cq, Tk, Bn, heads, sQ, sK, sP)
+        # dS = scale * P * (dP - rowsum(dP*P))   (in place into dP)
+        check(_capi.load().gad_softmax_bwd(P.data_ptr(), dP.data_ptr(), dP.data_ptr(), Bn * heads * Tq, Tk, scale,
+                                           _stream()), "gad_softmax_bwd")
+        # dQ = dS K ; dK = dS^T Q
+        dq = torch.empty_like(q)
+        _attn_gemm(dP, k, dq, A_KC, B_MC, Tq, d, Tk, Tk, Cq, Cq, Bn, heads, sP, sK, sQ)
+        dk = torch.empty_like(k)
+        _attn_gemm(dP, q, dk, A_MC, B_MC, Tk, d, Tq, Tk, Cq, Cq, Bn, heads, sP, sQ, sK)
+        return dq, dk, dv, None
+
+
+def attention_core(q, k, v, heads):
+    return AttentionCoreFn.apply(q, k, v, heads)
+
+
+# ----------------------------------------------------------------------------------
+# scheduler / loss / optimizer kernels (no autograd)
+# ----------------------------------------------------------------------------------
+def add_noise_raw(x0, eps, t, alphas_cumprod):
+    _req(x0, "add_noise x0")
+    _req(eps, "add_noise eps")
+    t = t.to(torch.int64).contiguous()
+    out = torch.empty_like(x0)
+    check(_capi.load().gad_add_noise(x0.data_ptr(), eps.data_ptr(), t.data_ptr(), alphas_cumprod.data_ptr(),
+                                     out.data_ptr(), x0.shape[0], x0.numel() // x0.shape[0], _stream()), "gad_add_noise")
+    return out
+
+
+def ddim_step_raw(x, eps, alpha_t: float, alpha_prev: float, clip: float, out=None):
+    _req(x, "ddim x")
+    _req(eps, "ddim eps")
+    out = torch.empty_like(x) if out is None else out
+    check(_capi.load().gad_ddim_step(x.data_ptr(), eps.data_ptr(), out.data_ptr(), x.numel(), alpha_t, alpha_prev, clip,
+                                     _stream()), "gad_ddim_step")
+    return out
+
+
+def to_image01_raw(x):
+    _req(x, "to_image01 x")
+    y = torch.empty_like(x)
+    check(_capi.load().gad_to_image01(x.data_ptr(), y.data_ptr(), x.numel(), _stream()), "gad_to_image01")
+    return y
+
+
+def mse_fwd_bwd_raw(pred, target, grad_scale=1.0):
+    """(loss [1], dloss/dpred) for nn.MSELoss(reduction='mean') (reference main.py:602,708)."""
+    _req(pred, "mse pred")
+    _req(target, "mse target")
+    ws = workspace(pred.device)
+    loss = torch.empty(1, device=pred.device, dtype=torch.float32)
+    d = torch.empty_like(pred)
+    check(_capi.load().gad_mse_fwd_bwd(pred.data_ptr(), target.data_ptr(), loss.data_ptr(), d.data_ptr(), pred.numel(),
+                                       grad_scale, ws.data_ptr(), ws.numel(), _stream()), "gad_mse_fwd_bwd")
+    return loss, d
+
+
+def sumsq_raw(g, out=None):
+    ws = workspace(g.device)
+    out = torch.empty(1, device=g.device, dtype=torch.float32) if out is None else out
+    check(_capi.load().gad_sumsq(g.data_ptr(), out.data_ptr(), g.numel(), ws.data_ptr(), ws.numel(), _stream()), "gad_sumsq")
+    return out
+
+
+def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weight_decay, adamw, step, ema_decay):
+    a = AdamArgs()
+    a.p, a.g, a.m, a.v, a.ema = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema)
+    a.n = p.numel()
+    a.sumsq = _ptr(sumsq)
+    a.max_norm = max_norm
+    a.lr, a.beta1, a.beta2, a.eps, a.weight_decay = lr, betas[0], betas[1], eps, weight_decay
+    a.adamw, a.step, a.ema_decay = int(adamw), step, ema_decay
+    check(_capi.load().gad_clip_adam_ema(C.byref(a), _stream()), "gad_clip_adam_ema")
+
+
+def ema_update_raw(ema, p, decay: float):
+    check(_capi.load().gad_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), decay, _stream()), "gad_ema_update")

@@ -1,0 +1,154 @@
+"""EMAModel (diffusers.training_utils API used at main.py:342-351,424,725 and
+src/diffusion_utils.py:193-198) and the fused training step
+(reference hot loop unconditional_generation/main.py:681-725 / unlearn.py:588-636)."""
+from __future__ import annotations
+
+import torch
+
+from . import ops
+
+
+class EMAModel:
+    def __init__(self, parameters, decay=0.9999, min_decay=0.0, update_after_step=0, use_ema_warmup=False,
+                 inv_gamma=1.0, power=2 / 3, model_cls=None, model_config=None, **unused):
+        parameters = list(parameters)
+        self.shadow_params = [p.clone().detach() for p in parameters]
+        self.temp_stored_params = None
+        self.decay, self.min_decay, self.update_after_step = decay, min_decay, update_after_step
+        self.use_ema_warmup, self.inv_gamma, self.power = use_ema_warmup, inv_gamma, power
+        self.optimization_step = 0
+        self.cur_decay_value = None
+        self.model_cls, self.model_config = model_cls, model_config
+        self._flat = None
+
+    def get_decay(self, optimization_step):
+        step = max(0, optimization_step - self.update_after_step - 1)
+        if step <= 0:
+            return 0.0
+        cur = 1 - (1 + step / self.inv_gamma) ** -self.power if self.use_ema_warmup else (1 + step) / (10 + step)
+        return max(min(cur, self.decay), self.min_decay)
+
+    def next_decay(self):
+        """Advance the step counter and return the decay of this update (used by the fused optimizer)."""
+        self.optimization_step += 1
+        self.cur_decay_value = self.get_decay(self.optimization_step)
+        return self.cur_decay_value
+
+    def bind_flat(self, model):
+        """Re-home the shadow parameters in one flat buffer laid out like model.flat so the EMA update
+        fuses into the optimizer pass."""
+        flat, _ = model.flat
+        sflat = torch.empty_like(flat)
+        off = 0
+        new = []
+        for s, p in zip(self.shadow_params, model.parameters()):
+            n = p.numel()
+            if p.ndim == 4:
+                o, i, kh, kw = p.shape
+                v = sflat[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+            else:
+                v = sflat[off:off + n].view(p.shape)
+            v.copy_(s.to(v.device))
+            new.append(v)
+            off += (n + 3) // 4 * 4
+        self.shadow_params = new
+        self._flat = sflat
+        return sflat
+
+    @torch.no_grad()
+    def step(self, parameters):
+        parameters = list(parameters)
+        decay = self.next_decay()
+        for s, p in zip(self.shadow_params, parameters):
+            if s.device != p.device:
+                raise ops._capi.GadError("EMAModel.step: shadow and model parameters live on different devices; "
+                                         "call ema_model.to(device) first")
+            if p.requires_grad:
+                if p.is_cuda:
+                    if s.is_contiguous() and p.is_contiguous():
+                        ops.ema_update_raw(s, p.detach(), decay)
+                    else:   # channels_last conv weights: same storage order on both sides
+                        ops.ema_update_raw(s.permute(0, 2, 3, 1), p.detach().permute(0, 2, 3, 1), decay)
+                else:
+                    s.sub_((1 - decay) * (s - p))
+            else:
+                s.copy_(p)
+
+    def copy_to(self, parameters):
+        for s, p in zip(self.shadow_params, list(parameters)):
+            p.data.copy_(s.to(p.device).data)
+
+    def store(self, parameters):
+        self.temp_stored_params = [p.detach().cpu().clone() for p in parameters]
+
+    def restore(self, parameters):
+        if self.temp_stored_params is None:
+            raise RuntimeError("This ExponentialMovingAverage has no `store()`ed weights to `restore()`")
+        for c, p in zip(self.temp_stored_params, parameters):
+            p.data.copy_(c.data)
+        self.temp_stored_params = None
+
+    def to(self, device=None, dtype=None):
+        self.shadow_params = [p.to(device=device, dtype=dtype) if p.is_floating_point() else p.to(device=device)
+                              for p in self.shadow_params]
+        self._flat = None
+
+    def state_dict(self):
+        return {"decay": self.decay, "min_decay": self.min_decay, "optimization_step": self.optimization_step,
+                "update_after_step": self.update_after_step, "use_ema_warmup": self.use_ema_warmup,
+                "inv_gamma": self.inv_gamma, "power": self.power,
+                "shadow_params": [s.detach().clone().contiguous() for s in self.shadow_params]}
+
+    def load_state_dict(self, sd):
+        for k in ("decay", "min_decay", "optimization_step", "update_after_step", "use_ema_warmup", "inv_gamma",
+                  "power"):
+            setattr(self, k, sd.get(k, getattr(self, k)))
+        sp = sd.get("shadow_params")
+        if sp is not None:
+            if len(sp) != len(self.shadow_params):
+                raise ValueError("shadow_params length mismatch")
+            for dst, src in zip(self.shadow_params, sp):
+                dst.copy_(src.to(dst.device))
+
+
+class FusedTrainer:
+    """One sFT / training step = add_noise -> U-Net fwd -> MSE (+grad) -> U-Net bwd ->
+    [sum g^2] -> fused clip+Adam(W)+EMA, every kernel from libgad_hip.so, no host sync.
+    Mirrors the loop body at main.py:681-725 with the batch, noise and timesteps supplied by
+    the caller (so the RNG policy stays in the entry point)."""
+
+    def __init__(self, model, scheduler, ema: EMAModel | None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                 weight_decay=0.0, adamw=False, max_grad_norm=1.0, loss_sign=1.0):
+        self.model, self.scheduler, self.ema = model, scheduler, ema
+        self.flat, self.gflat = model.flatten_parameters() if model._flat is None else model.flat
+        self.m = torch.zeros_like(self.flat)
+        self.v = torch.zeros_like(self.flat)
+        self.ema_flat = ema.bind_flat(model) if ema is not None else None
+        self.hp = dict(lr=lr, betas=betas, eps=eps, weight_decay=weight_decay, adamw=adamw)
+        self.max_grad_norm, self.loss_sign = max_grad_norm, loss_sign
+        self.step_count = 0
+        self._sumsq = torch.zeros(1, device=self.flat.device)
+        self.last_loss = None
+
+    def step(self, image_nchw, noise_nchw, timesteps):
+        model = self.model
+        self.gflat.zero_()
+        noisy = self.scheduler.add_noise(image_nchw, noise_nchw, timesteps)
+        eps = model(noisy, timesteps).sample
+        loss, d = ops.mse_fwd_bwd_raw(eps.contiguous(), noise_nchw.contiguous(), grad_scale=self.loss_sign)
+        eps.backward(d)
+        self.optimizer_step()
+        self.last_loss = loss
+        return loss
+
+    def optimizer_step(self):
+        self.step_count += 1
+        sumsq = None
+        if self.max_grad_norm is not None:
+            sumsq = ops.sumsq_raw(self.gflat, out=self._sumsq)
+        decay = self.ema.next_decay() if self.ema is not None else 0.0
+        ops.clip_adam_ema_raw(self.flat, self.gflat, self.m, self.v, self.ema_flat, sumsq,
+                              max_norm=self.max_grad_norm or 0.0, step=self.step_count, ema_decay=decay, **self.hp)
+
+    def grad_norm(self):
+        return self._sumsq.sqrt()

@@ -1,0 +1,194 @@
+/* gad.h - C ABI of the MI355X (gfx950) hot-path library `libgad_hip.so`.
+ *
+ * The reference (q8888620002/Group-Attribution-for-Diffusion-Models) has no FFI of
+ * its own: its hot path is reached through the Python API of the third-party
+ * diffusers==0.24.0 wheel, which dispatches to ATen/cuDNN/cuBLAS kernels.  Each entry
+ * point below names the reference call site whose device work it replaces
+ * (paths relative to the reference root).  The Python host layer
+ * (group-attribution-for-diffusion-models_amd/gad) binds these with ctypes; the binding a
+ * reference maintainer would add is shown in INTEGRATION.md.
+ *
+ * Conventions
+ *   - every pointer is a DEVICE pointer to caller-owned memory (PyTorch allocates);
+ *     the library never allocates, frees or retains device memory;
+ *   - every call is asynchronous on `stream` (a hipStream_t passed as void*), never
+ *     synchronises the device and is re-entrant / hipGraph-capturable;
+ *   - returns 0 on success, non-zero on error; gad_last_error() gives the
+ *     thread-local message;
+ *   - activations are fp32 NHWC ([B][H][W][C], "pixel-major"), conv weights are
+ *     [Cout][KH][KW][Cin] (= torch channels_last storage of the diffusers
+ *     [Cout][Cin][KH][KW] parameter), Linear weights [out][in].
+ */
+#ifndef GAD_H
+#define GAD_H
+#include <stdint.h>
+#ifdef __cplusplus
+extern "C" {
+#endif
+
+int gad_version(void);
+const char* gad_last_error(void);
+
+/* ------------------------------------------------------------------------------
+ * Contraction engine (f32-input MFMA v_mfma_f32_32x32x2_f32, exact fp32).
+ * C[z][M][N] = epilogue( alpha * sum_k A[z](m,k) * B[z](k,n) )
+ * Replaces cuDNN conv fwd/dgrad/wgrad and cuBLAS GEMMs under
+ *   diffusers ResnetBlock2D / Downsample2D / Upsample2D / Attention
+ *   (unconditional_generation/main.py:707,713; src/diffusion_utils.py:336-341;
+ *    src/diffusers/models/attention_processor.py:1301-1329).
+ * ---------------------------------------------------------------------------- */
+enum gad_a_mode {
+  GAD_A_KC = 0,     /* dense A[m][k], k contiguous, row stride lda                       */
+  GAD_A_MC = 1,     /* dense A[k][m], m contiguous, row stride lda (i.e. A^T stored)    */
+  GAD_A_CONV = 2,   /* im2col gather of NHWC x: m=(img,oh,ow), k=(r,s,c)   (conv fwd)   */
+  GAD_A_CONVT = 3   /* transposed gather of NHWC dy: m=(img,ih,iw), k=(r,s,co) (dgrad)  */
+};
+enum gad_b_mode {
+  GAD_B_KC = 0,     /* B[n][k], k contiguous, row stride ldb (torch Linear / conv weight)*/
+  GAD_B_MC = 1,     /* B[k][n], n contiguous, row stride ldb                             */
+  GAD_B_WDGRAD = 2, /* conv weight W[co][r][s][ci] read as B[k=(r,s,co)][n=ci]  (dgrad)  */
+  GAD_B_CONV = 3    /* im2col gather of NHWC x as B[k=(img,oh,ow)][n=(r,s,c)]  (wgrad)   */
+};
+
+typedef struct gad_conv_geom {
+  int32_t H, W, C;          /* gathered tensor: spatial size and channels (before upsample)   */
+  int32_t ldx;              /* pixel stride of the gathered tensor in floats (>= C)          */
+  int32_t Ho, Wo;           /* spatial size of the GEMM-row (A) / GEMM-k (B_CONV) pixel grid */
+  int32_t KH, KW;
+  int32_t stride;
+  int32_t pad_t, pad_l;
+  int32_t upsample;         /* 1: gathered tensor is nearest-2x upsampled on the fly         */
+} gad_conv_geom;
+
+typedef struct gad_gemm_args {
+  const float* A;
+  const float* B;
+  float* C;
+  int32_t a_mode, b_mode;
+  int32_t M, N, K;
+  int32_t lda, ldb, ldc;
+  /* batch z = z0 * batch_inner + z1 ; pointer offset = z0*stride?0 + z1*stride?1 (floats) */
+  int32_t batch, batch_inner;
+  int64_t strideA0, strideA1, strideB0, strideB1, strideC0, strideC1;
+  gad_conv_geom g;          /* used by the CONV / CONVT / WDGRAD / B_CONV modes              */
+  /* epilogue: C = alpha*acc + bias[n] + rowadd[m / rows_per_group][n] + residual[m][n]      */
+  float alpha;
+  const float* bias;        /* [N] or NULL                                                   */
+  const float* rowadd;      /* [M / rows_per_group][ld_rowadd] or NULL (time-embedding add)  */
+  int32_t rows_per_group, ld_rowadd;
+  const float* residual;    /* [M][ldr] or NULL (same batch strides as C)                    */
+  int32_t ldr;
+  /* split-K workspace (caller owned). ws_bytes >= gad_gemm_workspace_bytes(args)            */
+  void* ws;
+  int64_t ws_bytes;
+  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64                  */
+  int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
+} gad_gemm_args;
+
+int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
+int gad_gemm(const gad_gemm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in
+ * ResnetBlock2D.norm1/norm2, Attention.group_norm, UNet2DModel.conv_norm_out
+ * (diffusers; semantics SURVEY Appendix A.2/A.6; attention_processor.py:1297-1298).
+ *   y = act( (x - mean_bg) * rstd_bg * gamma_c + beta_c ),  act = SiLU if silu != 0
+ * mean/rstd [B][G] are written for the backward pass.
+ * ws: gad_groupnorm_workspace_bytes() bytes of scratch.
+ * ---------------------------------------------------------------------------- */
+typedef struct gad_groupnorm_args {
+  const float* x;           /* [B][HW][C]                                                    */
+  float* y;                 /* fwd: output. bwd: dx                                          */
+  const float* gamma;       /* [C]                                                           */
+  const float* beta;        /* [C]                                                           */
+  float* mean;              /* [B][G]  (fwd: out, bwd: in)                                   */
+  float* rstd;              /* [B][G]                                                        */
+  const float* dy;          /* bwd only: [B][HW][C]                                          */
+  float* dgamma;            /* bwd only: [C] (overwritten)                                   */
+  float* dbeta;             /* bwd only: [C] (overwritten)                                   */
+  int32_t B, HW, C, G;
+  float eps;
+  int32_t silu;
+  void* ws;
+  int64_t ws_bytes;
+} gad_groupnorm_args;
+
+int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a);
+int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream);
+int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Row softmax (attention probabilities), in place allowed.
+ *   fwd: p = softmax(scale * s) per row of length n
+ *   bwd: ds = scale * p * (dp - sum(dp * p))
+ * Replaces the softmax inside F.scaled_dot_product_attention
+ * (src/diffusers/models/attention_processor.py:1321-1323).
+ * ---------------------------------------------------------------------------- */
+int gad_softmax_fwd(const float* s, float* p, int64_t rows, int32_t n, float scale, void* stream);
+int gad_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, int32_t n, float scale,
+                    void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Elementwise / small kernels (HBM-bound)
+ * ---------------------------------------------------------------------------- */
+/* diffusers get_timestep_embedding: out[b][dim] fp32; t int64 [B] */
+int gad_timestep_embedding(const int64_t* t, float* out, int32_t B, int32_t dim, int32_t flip_sin_to_cos,
+                           float freq_shift, float max_period, void* stream);
+/* y = x*sigmoid(x) ; dx = dy * s(1 + x(1-s)) */
+int gad_silu_fwd(const float* x, float* y, int64_t n, void* stream);
+int gad_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* out[p][0:C1] = a[p][0:C1], out[p][C1:C1+C2] = b[p][0:C2]  (skip-connection concat, NHWC) */
+int gad_concat_channels(const float* a, const float* b, float* out, int64_t pixels, int32_t C1, int32_t C2,
+                        void* stream);
+/* inverse of concat for the gradient: da = d[:, :C1], db = d[:, C1:] */
+int gad_split_channels(const float* d, float* da, float* db, int64_t pixels, int32_t C1, int32_t C2,
+                       void* stream);
+/* NCHW <-> NHWC layout change */
+int gad_nchw_to_nhwc(const float* x, float* y, int32_t B, int32_t C, int32_t HW, void* stream);
+int gad_nhwc_to_nchw(const float* x, float* y, int32_t B, int32_t C, int32_t HW, void* stream);
+/* dx[b][h][w][c] = sum of the 2x2 block of dy[b][2h..2h+1][2w..2w+1][c] (nearest-upsample backward) */
+int gad_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* out[s][n] = sum_m dy[s][m][n] for S segments of M rows (S=1: bias gradient; S=B, M=H*W: gradient of the
+ * per-image time-embedding add) */
+int gad_colsum(const float* dy, float* out, int32_t S, int64_t M, int32_t N, void* ws, int64_t ws_bytes,
+               void* stream);
+
+/* DDPMScheduler.add_noise (main.py:698): xt = sqrt(ac[t_b]) x0 + sqrt(1-ac[t_b]) eps ; per_sample = C*H*W */
+int gad_add_noise(const float* x0, const float* eps, const int64_t* t, const float* alphas_cumprod,
+                  float* xt, int32_t B, int64_t per_sample, void* stream);
+/* DDIMScheduler.step, eta = 0 (src/diffusion_utils.py:336-341 via DDPMPipeline):
+ *   x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); clamp(+-clip) if clip>0; x' = sqrt(a_p) x0 + sqrt(1-a_p) e      */
+int gad_ddim_step(const float* x, const float* eps, float* x_prev, int64_t n, float alpha_t,
+                  float alpha_prev, float clip, void* stream);
+/* final pipeline post-processing: y = clamp(x/2 + 0.5, 0, 1) */
+int gad_to_image01(const float* x, float* y, int64_t n, void* stream);
+/* MSE loss and its gradient in one pass: loss[0] = mean((a-b)^2) ; d = 2 (a-b) * gscale / n */
+int gad_mse_fwd_bwd(const float* a, const float* b, float* loss, float* d, int64_t n, float gscale,
+                    void* ws, int64_t ws_bytes, void* stream);
+
+/* ------------------------------------------------------------------------------
+ * Fused optimizer over the flat parameter buffer
+ * (clip_grad_norm_ main.py:718 + Adam/AdamW :557-561,719 + EMAModel.step :725).
+ *   gad_sumsq: out[0] = sum(g^2)   (deterministic two-stage reduction)
+ *   gad_clip_adam_ema: coef = min(1, max_norm/(sqrt(sumsq[0])+1e-6)); g*=coef;
+ *     Adam(W) update with bias correction for `step`; ema -= (1-ema_decay)(ema-p) if ema != NULL
+ * ---------------------------------------------------------------------------- */
+int gad_sumsq(const float* g, float* out, int64_t n, void* ws, int64_t ws_bytes, void* stream);
+typedef struct gad_adam_args {
+  float* p; const float* g; float* m; float* v; float* ema;
+  int64_t n;
+  const float* sumsq;       /* device scalar from gad_sumsq, or NULL for no clipping          */
+  float max_norm;
+  float lr, beta1, beta2, eps, weight_decay;   /* weight_decay is decoupled (AdamW) if adamw  */
+  int32_t adamw;
+  int32_t step;             /* 1-based                                                        */
+  float ema_decay;
+} gad_adam_args;
+int gad_clip_adam_ema(const gad_adam_args* a, void* stream);
+/* standalone EMAModel.step (diffusers training_utils; main.py:725): ema -= (1-decay) * (ema - p) */
+int gad_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
+
+#ifdef __cplusplus
+}
+#endif
+#endif

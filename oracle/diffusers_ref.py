@@ -195,13 +195,15 @@ class DownBlock(nn.Module):
     def __init__(self, in_c, out_c, temb_c, num_layers, eps, groups, add_downsample, downsample_padding,
                  attn_head_dim=None):
         super().__init__()
-        self.resnets = nn.ModuleList([
+        resnets = nn.ModuleList([
             ResnetBlock2D(in_c if i == 0 else out_c, out_c, temb_c, groups, eps) for i in range(num_layers)])
+        # diffusers registers `attentions` before `resnets` in Attn*Block2D (parameters() order -> EMA list order)
         if attn_head_dim is not None:
             self.attentions = nn.ModuleList([
                 Attention(out_c, out_c // attn_head_dim, attn_head_dim, eps, groups) for _ in range(num_layers)])
         else:
             self.attentions = None
+        self.resnets = resnets
         self.downsamplers = nn.ModuleList([Downsample2D(out_c, downsample_padding)]) if add_downsample else None
 
     def forward(self, h, temb):
@@ -220,10 +222,11 @@ class DownBlock(nn.Module):
 class UNetMidBlock2D(nn.Module):
     def __init__(self, c, temb_c, eps, groups, attn_head_dim, add_attention=True):
         super().__init__()
-        self.resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps),
-                                      ResnetBlock2D(c, c, temb_c, groups, eps)])
+        resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps),
+                                 ResnetBlock2D(c, c, temb_c, groups, eps)])
         self.attentions = nn.ModuleList([
             Attention(c, c // attn_head_dim, attn_head_dim, eps, groups) if add_attention else None])
+        self.resnets = resnets
 
     def forward(self, h, temb):
         h = self.resnets[0](h, temb)
@@ -242,12 +245,12 @@ class UpBlock(nn.Module):
             skip_c = in_c if i == num_layers - 1 else out_c
             r_in = prev_c if i == 0 else out_c
             res.append(ResnetBlock2D(r_in + skip_c, out_c, temb_c, groups, eps))
-        self.resnets = nn.ModuleList(res)
         if attn_head_dim is not None:
             self.attentions = nn.ModuleList([
                 Attention(out_c, out_c // attn_head_dim, attn_head_dim, eps, groups) for _ in range(num_layers)])
         else:
             self.attentions = None
+        self.resnets = nn.ModuleList(res)
         self.upsamplers = nn.ModuleList([Upsample2D(out_c)]) if add_upsample else None
 
     def forward(self, h, skips, temb):

@@ -1,0 +1,352 @@
+"""GPU parity tests (run on the MI355X box: pytest -m gpu): every HIP kernel, called
+through the C ABI, against a CPU fp64 restatement built from stock torch ops on the same
+seeded inputs.  Tolerance for the fp32 MFMA contractions: |err| <= 2e-5 * K^0.5 * rms(A)*rms(B)
+-ish, expressed below as rtol/atol on outputs normalised to O(1)."""
+import math
+
+import numpy as np
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+
+dev = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    if not torch.cuda.is_available():
+        pytest.skip("needs a GPU")
+    from gad import ops as o
+    return o
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    g = torch.Generator().manual_seed(seed)
+    return torch.randn(*shape, generator=g, dtype=torch.float32) * scale
+
+
+def close(got, want, rtol=2e-4, atol=2e-4):
+    got = got.detach().cpu().double()
+    want = want.detach().cpu().double()
+    assert got.shape == want.shape, (got.shape, want.shape)
+    err = (got - want).abs().max().item()
+    ref = want.abs().max().item()
+    assert torch.allclose(got, want, rtol=rtol, atol=atol * max(1.0, ref)), f"max err {err:.3e} (ref max {ref:.3e})"
+
+
+def nhwc(x):  # NCHW cpu -> NHWC gpu
+    return x.permute(0, 2, 3, 1).contiguous().to(dev)
+
+
+def cl_weight(w):  # [O,I,kh,kw] cpu -> channels_last-stored gpu parameter-like tensor
+    return w.to(dev).contiguous(memory_format=torch.channels_last)
+
+
+# ------------------------------------------------------------------ dense contraction ----
+@pytest.mark.parametrize("M,N,K", [(64, 64, 32), (200, 132, 100), (512, 256, 1024), (31 * 4, 3, 64), (1000, 512, 128)])
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 0), (2, 0), (2, 3), (1, 2)])
+def test_gemm_kc_kc(ops, M, N, K, tile, splitk):
+    from gad._capi import A_KC, B_KC
+    a, b = rnd(M, K, seed=1), rnd(N, K, seed=2)
+    bias, res = rnd(N, seed=3), rnd(M, N, seed=4)
+    c = torch.empty(M, N, device=dev)
+    ops.gemm_raw(a.to(dev), b.to(dev), c, A_KC, B_KC, M, N, K, K, K, N, alpha=0.5, bias=bias.to(dev),
+                 residual=res.to(dev), ldr=N, tile_hint=tile, splitk_hint=splitk)
+    want = 0.5 * (a.double() @ b.double().T) + bias.double() + res.double()
+    close(c, want, atol=2e-5 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("M,N,K", [(64, 64, 64), (132, 200, 96), (256, 512, 1000)])
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_other_layouts(ops, M, N, K, tile):
+    from gad._capi import A_KC, A_MC, B_MC
+    a, b = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    want = a.double() @ b.double()
+    c = torch.empty(M, N, device=dev)
+    ops.gemm_raw(a.to(dev), b.to(dev), c, A_KC, B_MC, M, N, K, K, N, N, tile_hint=tile)
+    close(c, want, atol=2e-5 * math.sqrt(K))
+    at = a.T.contiguous()  # stored [K][M]
+    c2 = torch.empty(M, N, device=dev)
+    ops.gemm_raw(at.to(dev), b.to(dev), c2, A_MC, B_MC, M, N, K, M, N, N, tile_hint=tile, splitk_hint=2)
+    close(c2, want, atol=2e-5 * math.sqrt(K))
+
+
+# ------------------------------------------------------------------------------- conv ----
+CONV_CASES = [
+    # B, Cin, Cout, H, k, stride, pad(t,b,l,r), upsample
+    (2, 128, 128, 16, 3, 1, (1, 1, 1, 1), False),
+    (2, 3, 128, 32, 3, 1, (1, 1, 1, 1), False),      # conv_in  (Cin=3 -> scalar gather path)
+    (2, 128, 3, 32, 3, 1, (1, 1, 1, 1), False),      # conv_out (N=3)
+    (3, 128, 128, 32, 3, 2, (0, 1, 0, 1), False),    # Downsample2D padding=0: F.pad(0,1,0,1)
+    (2, 224, 224, 16, 3, 2, (1, 1, 1, 1), False),    # CelebA downsample padding=1, C=224
+    (2, 256, 256, 4, 3, 1, (1, 1, 1, 1), True),      # Upsample2D fused
+    (2, 384, 256, 16, 1, 1, (0, 0, 0, 0), False),    # conv_shortcut 1x1
+    (1, 512, 256, 4, 3, 1, (1, 1, 1, 1), False),     # small M, long K -> split-K
+    (5, 100, 60, 7, 3, 1, (1, 1, 1, 1), False),      # pruned-like odd widths / odd spatial
+]
+
+
+def conv_ref(x, w, b, stride, pad, upsample):
+    x = x.double()
+    if upsample:
+        x = F.interpolate(x, scale_factor=2.0, mode="nearest")
+    x = F.pad(x, (pad[2], pad[3], pad[0], pad[1]))
+    return F.conv2d(x, w.double(), b.double() if b is not None else None, stride=stride)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+@pytest.mark.parametrize("tile,splitk", [(0, 0), (1, 0), (2, 2)])
+def test_conv_fwd(ops, case, tile, splitk):
+    B, Cin, Cout, H, k, stride, pad, ups = case
+    x, w, b = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, k, k, seed=2, scale=1 / math.sqrt(Cin * k * k)), rnd(Cout, seed=3)
+    temb = rnd(B, Cout, seed=4)
+    want = conv_ref(x, w, b, stride, pad, ups) + temb.double()[:, :, None, None]
+    res = rnd(*want.shape, seed=5)
+    want = want + res.double()
+    y = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), stride, pad, ups, rowadd=temb.to(dev), residual=nhwc(res),
+                           tile_hint=tile, splitk_hint=splitk)
+    close(y.permute(0, 3, 1, 2), want, atol=3e-5)
+
+
+@pytest.mark.parametrize("case", CONV_CASES)
+def test_conv_bwd(ops, case):
+    B, Cin, Cout, H, k, stride, pad, ups = case
+    x = rnd(B, Cin, H, H, seed=1).double().requires_grad_(True)
+    w = rnd(Cout, Cin, k, k, seed=2, scale=1 / math.sqrt(Cin * k * k)).double().requires_grad_(True)
+    b = rnd(Cout, seed=3).double().requires_grad_(True)
+    y = conv_ref(x, w, b, stride, pad, ups)
+    dy = rnd(*y.shape, seed=6)
+    y.backward(dy.double())
+    dyg = nhwc(dy)
+    wg = cl_weight(w.detach().float())
+    if Cin % 4 == 0:
+        dx = ops.conv2d_dgrad_raw(dyg, wg, (B, H, H, Cin), stride, pad, ups)
+        close(dx.permute(0, 3, 1, 2), x.grad, atol=3e-5)
+    dw = ops.conv2d_wgrad_raw(dyg, nhwc(x.detach().float()), wg, stride, pad, ups)
+    close(dw, w.grad, atol=3e-5 * math.sqrt(B * y.shape[-1] * y.shape[-2] / 16))
+    db = ops.colsum_raw(dyg.view(-1, Cout), 1).view(-1)
+    close(db, b.grad, atol=1e-5 * math.sqrt(B * y.shape[-1] * y.shape[-2]))
+
+
+def test_conv_autograd_function(ops):
+    B, Cin, Cout, H = 2, 64, 96, 8
+    x, w, b, t, r = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3), rnd(B, Cout, seed=4), rnd(B, Cout, H, H, seed=5)
+    leaves = [v.double().requires_grad_(True) for v in (x, w, b, t, r)]
+    y = F.conv2d(leaves[0], leaves[1], leaves[2], padding=1) + leaves[3][:, :, None, None] + leaves[4]
+    dy = rnd(*y.shape, seed=7)
+    y.backward(dy.double())
+    gx, gw, gb, gt, gr = (nhwc(x).requires_grad_(True), cl_weight(w).requires_grad_(True), b.to(dev).requires_grad_(True),
+                          t.to(dev).requires_grad_(True), nhwc(r).requires_grad_(True))
+    out = ops.conv2d(gx, gw, gb, gt, gr)
+    out.backward(nhwc(dy))
+    close(out.permute(0, 3, 1, 2), y)
+    close(gx.grad.permute(0, 3, 1, 2), leaves[0].grad)
+    close(gw.grad, leaves[1].grad, atol=1e-4)
+    close(gb.grad, leaves[2].grad, atol=1e-4)
+    close(gt.grad, leaves[3].grad, atol=1e-4)
+    close(gr.grad.permute(0, 3, 1, 2), leaves[4].grad)
+
+
+# -------------------------------------------------------------------------- groupnorm ----
+@pytest.mark.parametrize("B,C,H,G,silu", [(2, 128, 32, 32, True), (3, 256, 16, 32, True), (2, 384, 16, 32, True),
+                                          (2, 512, 4, 32, True), (2, 224, 8, 32, False), (1, 896, 8, 32, True),
+                                          (32, 128, 32, 32, True)])
+def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
+    x = (rnd(B, C, H, H, seed=1) * 2 + 0.7).double().requires_grad_(True)   # non-zero mean stresses the variance
+    ga, be = (rnd(C, seed=2) * 0.3 + 1).double().requires_grad_(True), (rnd(C, seed=3) * 0.2).double().requires_grad_(True)
+    eps = 1e-6
+    y = F.group_norm(x, G, ga, be, eps)
+    if silu:
+        y = F.silu(y)
+    dy = rnd(B, C, H, H, seed=4)
+    y.backward(dy.double())
+    gx = nhwc(x.detach().float()).requires_grad_(True)
+    gg, gb = ga.detach().float().to(dev).requires_grad_(True), be.detach().float().to(dev).requires_grad_(True)
+    out = ops.group_norm(gx, gg, gb, G, eps, silu)
+    out.backward(nhwc(dy))
+    close(out.permute(0, 3, 1, 2), y, atol=2e-5)
+    close(gx.grad.permute(0, 3, 1, 2), x.grad, atol=5e-5)
+    close(gg.grad, ga.grad, atol=2e-5 * math.sqrt(B * H * H))
+    close(gb.grad, be.grad, atol=2e-5 * math.sqrt(B * H * H))
+
+
+# -------------------------------------------------------------------------- attention ----
+@pytest.mark.parametrize("B,T,heads,d", [(2, 256, 1, 256), (3, 16, 1, 256), (2, 64, 7, 32), (1, 1024, 2, 32)])
+def test_attention_core(ops, B, T, heads, d):
+    C = heads * d
+    q, k, v = (rnd(B, T, C, seed=s, scale=0.5).double().requires_grad_(True) for s in (1, 2, 3))
+
+    def split(t):
+        return t.view(B, T, heads, d).transpose(1, 2)
+    w = torch.softmax(split(q) @ split(k).transpose(-1, -2) / math.sqrt(d), dim=-1)
+    o = (w @ split(v)).transpose(1, 2).reshape(B, T, C)
+    do = rnd(B, T, C, seed=4)
+    o.backward(do.double())
+    gq, gk, gv = (t.detach().float().to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_core(gq, gk, gv, heads)
+    out.backward(do.to(dev))
+    close(out, o, atol=3e-5)
+    close(gq.grad, q.grad, atol=5e-5)
+    close(gk.grad, k.grad, atol=5e-5)
+    close(gv.grad, v.grad, atol=5e-5)
+
+
+def test_linear_and_lora(ops):
+    from gad import nn as gnn
+    torch.manual_seed(0)
+    lin = gnn.Linear(320, 640).to(dev)
+    lora = gnn.LoRALinearLayer(320, 640, rank=24).to(dev)
+    with torch.no_grad():
+        lora.up.weight.copy_(rnd(640, 24, seed=9, scale=0.1))
+    lin.set_lora_layer(lora)
+    x = rnd(6, 77, 320, seed=1)
+    gx = x.to(dev).requires_grad_(True)
+    y = lin(gx, scale=0.7)
+    dy = rnd(6, 77, 640, seed=2)
+    y.backward(dy.to(dev))
+    xd = x.double().requires_grad_(True)
+    W, b = lin.weight.detach().cpu().double().requires_grad_(True), lin.bias.detach().cpu().double()
+    A, Bm = lora.down.weight.detach().cpu().double().requires_grad_(True), lora.up.weight.detach().cpu().double().requires_grad_(True)
+    want = xd @ W.T + b + 0.7 * ((xd @ A.T) @ Bm.T)
+    want.backward(dy.double())
+    close(y, want)
+    close(gx.grad, xd.grad)
+    close(lin.weight.grad, W.grad, atol=1e-4)
+    close(lora.down.weight.grad, A.grad, atol=1e-4)
+    close(lora.up.weight.grad, Bm.grad, atol=1e-4)
+
+
+# ------------------------------------------------------------------------ elementwise ----
+def test_timestep_embedding(ops):
+    from oracle.diffusers_ref import get_timestep_embedding
+    t = torch.tensor([0, 1, 10, 500, 990, 999])
+    for dim, flip, shift in [(128, False, 1), (224, True, 0)]:
+        got = ops.timestep_embedding(t.to(dev), dim, flip, shift)
+        want = get_timestep_embedding(t, dim, flip, shift)
+        close(got, want, rtol=1e-5, atol=2e-4)   # sin/cos of arguments up to 999 rad in fp32
+
+
+def test_ddim_add_noise_image(ops):
+    from oracle.diffusers_ref import DDIMScheduler, DDPMScheduler
+    sch = DDIMScheduler()
+    sch.set_timesteps(100)
+    x, e = rnd(4, 3, 32, 32, seed=1), rnd(4, 3, 32, 32, seed=2)
+    for t in (990, 500, 10, 0):
+        want = sch.step(e, t, x).prev_sample
+        prev = t - 10
+        a_t = sch.alphas_cumprod[t].item()
+        a_p = sch.alphas_cumprod[prev].item() if prev >= 0 else 1.0
+        got = ops.ddim_step_raw(x.to(dev), e.to(dev), a_t, a_p, 1.0)
+        close(got, want, rtol=1e-5, atol=1e-5)
+    dd = DDPMScheduler()
+    ts = torch.tensor([0, 999, 500, 3])
+    want = dd.add_noise(x, e, ts)
+    got = ops.add_noise_raw(x.to(dev), e.to(dev), ts.to(dev), dd.alphas_cumprod.to(dev))
+    close(got, want, rtol=1e-6, atol=1e-6)
+    close(ops.to_image01_raw(x.to(dev)), (x / 2 + 0.5).clamp(0, 1), rtol=0, atol=1e-7)
+
+
+def test_small_kernels(ops):
+    x, y = rnd(3, 5, 7, 11, seed=1), rnd(3, 5, 7, 11, seed=2)
+    loss, d = ops.mse_fwd_bwd_raw(x.to(dev), y.to(dev))
+    xd = x.double().requires_grad_(True)
+    l = F.mse_loss(xd, y.double())
+    l.backward()
+    close(loss, l.detach().view(1), rtol=1e-5, atol=1e-6)
+    close(d, xd.grad, rtol=1e-5, atol=1e-7)
+    gx = x.to(dev).requires_grad_(True)
+    s = ops.silu(gx)
+    s.backward(y.to(dev))
+    xs = x.double().requires_grad_(True)
+    F.silu(xs).backward(y.double())
+    close(s, F.silu(x.double()), atol=1e-6)
+    close(gx.grad, xs.grad, atol=1e-6)
+    a, b = rnd(2, 4, 4, 128, seed=3), rnd(2, 4, 4, 64, seed=4)
+    ga, gb = a.to(dev).requires_grad_(True), b.to(dev).requires_grad_(True)
+    c = ops.concat(ga, gb)
+    assert torch.equal(c.cpu(), torch.cat([a, b], -1))
+    c.backward(c.detach() * 2)
+    assert torch.equal(ga.grad.cpu(), a * 2) and torch.equal(gb.grad.cpu(), b * 2)
+    z = rnd(3, 5, 6, 7, seed=5)
+    assert torch.equal(ops.nchw_to_nhwc_raw(z.to(dev)).cpu(), z.permute(0, 2, 3, 1).contiguous())
+    assert torch.equal(ops.nhwc_to_nchw_raw(z.to(dev)).cpu(), z.permute(0, 3, 1, 2).contiguous())
+    m = rnd(6 * 50, 36, seed=6)
+    close(ops.colsum_raw(m.to(dev), 6), m.view(6, 50, 36).double().sum(1), atol=1e-5)
+    g = rnd(100003, seed=7)
+    close(ops.sumsq_raw(g.to(dev)), (g.double() ** 2).sum().view(1), rtol=1e-5)
+
+
+def test_fused_clip_adam_ema_matches_torch(ops):
+    from oracle.diffusers_ref import EMAModel
+    n = 10007
+    p0, g_list = rnd(n, seed=1), [rnd(n, seed=10 + i, scale=0.05 * (i + 1)) for i in range(4)]
+    pr = torch.nn.Parameter(p0.clone().double())
+    opt = torch.optim.Adam([pr], lr=1e-4)
+    ema = EMAModel([pr], decay=0.9999)
+    ema.optimization_step = 5000
+    p, m, v = p0.to(dev).clone(), torch.zeros(n, device=dev), torch.zeros(n, device=dev)
+    e = p0.to(dev).clone()
+    for i, g in enumerate(g_list):
+        pr.grad = g.double().clone()
+        torch.nn.utils.clip_grad_norm_([pr], 1.0)
+        opt.step()
+        ema.step([pr])
+        ss = ops.sumsq_raw(g.to(dev))
+        ops.clip_adam_ema_raw(p, g.to(dev), m, v, e, ss, max_norm=1.0, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
+                              weight_decay=0.0, adamw=False, step=i + 1, ema_decay=ema.cur_decay_value)
+    close(p, pr.detach(), rtol=1e-6, atol=1e-6)
+    close(e, ema.shadow_params[0], rtol=1e-6, atol=1e-6)
+
+
+# ------------------------------------------------------------------------- whole U-Net ----
+def _models(cfg_name="cifar100_config", shrink=None):
+    from oracle import diffusers_ref as R
+    from gad import nn as G
+    from src.ddpm_config import DDPMConfig
+    cfg = dict(getattr(DDPMConfig, cfg_name)["unet_config"])
+    if shrink:
+        cfg.update(shrink)
+    torch.manual_seed(0)
+    ref = R.UNet2DModel(**cfg)
+    mine = G.UNet2DModel(**cfg)
+    mine.load_state_dict(ref.state_dict())
+    return ref, mine.to(dev), cfg
+
+
+def test_unet_forward_backward_cifar(ops):
+    ref, mine, cfg = _models()
+    x, t = rnd(2, 3, 32, 32, seed=1), torch.tensor([7, 950])
+    noise = rnd(2, 3, 32, 32, seed=2)
+    want = ref(x, t).sample
+    F.mse_loss(want, noise).backward()
+    got = mine(x.to(dev), t.to(dev)).sample
+    loss, d = ops.mse_fwd_bwd_raw(got.contiguous(), noise.to(dev))
+    got.backward(d)
+    close(got, want, atol=1e-4)
+    gref = dict(ref.named_parameters())
+    worst = 0.0
+    for n, p in mine.named_parameters():
+        a, b = p.grad.detach().cpu().double(), gref[n].grad.double()
+        worst = max(worst, ((a - b).norm() / (b.norm() + 1e-12)).item())
+    assert worst < 2e-3, worst
+
+
+def test_unet_forward_celeba_like(ops):
+    # CelebA topology (head_dim 32 -> multi-head, cpg = 7, symmetric downsample padding) at reduced width/size
+    ref, mine, cfg = _models("celeba_config", dict(block_out_channels=[64, 128, 192, 224], sample_size=16))
+    x, t = rnd(2, 3, 16, 16, seed=1), torch.tensor([3, 700])
+    close(mine(x.to(dev), t.to(dev)).sample, ref(x, t).sample, atol=1e-4)
+
+
+def test_ddim_sampling_matches_oracle(ops):
+    from oracle import diffusers_ref as R
+    from gad import pipelines as P
+    ref, mine, cfg = _models()
+    pr = R.DDPMPipeline(ref, R.DDIMScheduler())
+    pm = P.DDPMPipeline(mine, P.DDIMScheduler()).to(dev)
+    a = pr(batch_size=2, generator=torch.Generator().manual_seed(3), num_inference_steps=4).images
+    b = pm(batch_size=2, generator=torch.Generator().manual_seed(3), num_inference_steps=4, output_type="numpy").images
+    assert a.shape == b.shape == (2, 32, 32, 3)
+    np.testing.assert_allclose(b, a, atol=2e-4)
