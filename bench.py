@@ -1,0 +1,260 @@
+#!/usr/bin/env python3
+"""bench.py - Shapley coalitions/hour on the CIFAR-20 DDPM sFT cycle (BASELINE.json configs[1]).
+
+    python bench.py --gpus N --steps K --warmup W
+    python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+
+Workload (config.workload): one coalition of the reference's CIFAR-20 configuration =
+gd_steps=1000 fine-tuning steps at B=128 (noise, antithetic t, add_noise, U-Net fwd, MSE, bwd,
+clip 1.0, Adam 1e-4, EMA) + 10 240 samples x 100 DDIM steps (U-Net fwd + scheduler step;
+reference batches of 32 with per-batch CPU-generator noise, 4 of them fused per launch), fp32.
+ONE BENCH STEP = 1/1000 of that coalition, in the coalition's own proportions:
+    1 training step (B=128)  +  8 sampler steps at B=128 (= 32 reference batches x 32 images x 1 DDIM step).
+value = coalitions/hour summed over all ranks = K * world / 1000 / hours(max-over-ranks time of the K steps).
+The score tail (FID features + float64 Frechet, ~1 % of the FLOPs, once per coalition) is not part of a
+slice; `--full-coalition` runs one real, complete coalition (train -> EMA -> preview -> sample -> score) instead.
+Each rank works on its own coalition (removal_seed = rank); the only collective is the final all_gather of
+the per-rank records ("scaling": "weak").
+"""
+import argparse
+import json
+import os
+import sys
+import time
+
+ROOT = os.path.dirname(os.path.abspath(__file__))
+for p in (os.path.join(ROOT, "group-attribution-for-diffusion-models_amd"), ROOT):
+    if p not in sys.path:
+        sys.path.insert(0, p)
+os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
+
+import torch  # noqa: E402
+
+GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128, 32, 4
+UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
+F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+def parse():
+    ap = argparse.ArgumentParser()
+    ap.add_argument("--gpus", type=int, default=1)
+    ap.add_argument("--steps", type=int, default=20)
+    ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
+    ap.add_argument("--no-cpu-baseline", action="store_true")
+    ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
+    ap.add_argument("--gd-steps", type=int, default=GD_STEPS)
+    ap.add_argument("--n-samples", type=int, default=N_SAMPLES)
+    return ap.parse_args()
+
+
+class SliceRunner:
+    """Holds one coalition in flight on this rank and advances it one slice at a time."""
+
+    def __init__(self, engine, removal_seed):
+        import gad
+        from gad import ops
+        from gad.coalition import DeviceLoader, FusedSampler, antithetic_timesteps, seed_everything
+        self.ops, self.antithetic = ops, antithetic_timesteps
+        self.engine, self.dev = engine, engine.device
+        remaining, _ = engine.coalition(removal_seed)
+        seed_everything(engine.opt_seed)
+        self.model, self.ema = engine.load_base()
+        self.trainer = engine.make_trainer(self.model, self.ema)
+        self.loader = DeviceLoader(engine.dataset, remaining, TRAIN_B, self.dev)
+        self.it = iter(self.loader)
+        # sampling model = the EMA weights of the base checkpoint (same shapes as the post-sFT EMA model)
+        self.smodel, _ = engine.load_base()
+        self.smodel.eval()
+        self.sampler = FusedSampler(self.smodel, engine.sample_scheduler, SAMPLE_B, FUSE)
+        engine.sample_scheduler.set_timesteps(DDIM_STEPS)
+        self.ts = engine.sample_scheduler.timesteps.tolist()
+        self.noise_pool = [self.sampler.initial_noise(list(range(g * FUSE, (g + 1) * FUSE)), [SAMPLE_B] * FUSE)
+                           for g in range(4)]                       # pre-staged in HBM before the timed region
+        self.group, self.ti = 0, 0
+        self.x = self.noise_pool[0].clone()
+        self.t = torch.empty(self.x.shape[0], device=self.dev, dtype=torch.int64)
+        self.images_done = 0
+        self.n_t = engine.train_scheduler.config.num_train_timesteps
+
+    def train_step(self):
+        try:
+            image, _ = next(self.it)
+        except StopIteration:
+            self.it = iter(self.loader)
+            image, _ = next(self.it)
+        if image.shape[0] != TRAIN_B:                                   # short last batch of an epoch: the
+            self.it = iter(self.loader)                                 # reference trains on it; the bench keeps
+            image, _ = next(self.it)                                    # every step at the quoted B=128
+        noise = torch.randn_like(image)
+        ts = self.antithetic(self.n_t, image.shape[0], self.dev)
+        return self.trainer.step(image, noise, ts)
+
+    @torch.no_grad()
+    def sampler_step(self):
+        ops, sch = self.ops, self.engine.sample_scheduler
+        t = self.ts[self.ti]
+        self.t.fill_(t)
+        eps = self.smodel.forward_nhwc(self.x, self.t)
+        a_t, a_p = sch.step_coefficients(t)
+        ops.ddim_step_raw(self.x, eps, a_t, a_p, 1.0, out=self.x)
+        self.ti += 1
+        if self.ti == len(self.ts):                                      # trajectory finished: quantise, next group
+            img = ops.to_image01_raw(self.x)
+            self.last_images = img.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)
+            self.images_done += self.x.shape[0]
+            self.group += 1
+            self.x.copy_(self.noise_pool[self.group % len(self.noise_pool)])
+            self.ti = 0
+
+    def slice(self):
+        loss = self.train_step()
+        for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):      # 8
+            self.sampler_step()
+        return loss
+
+
+def cpu_baseline(engine):
+    """The oracle (pure-PyTorch restatement = what "the reference's CPU path" can mean here: diffusers is
+    not installable) timed on the host cores on a bounded sample: 2 training steps and 3 sampler steps at
+    B=8, scaled per image to one coalition."""
+    from oracle import diffusers_ref as R
+    threads = os.cpu_count() or 1
+    torch.set_num_threads(threads)
+    torch.manual_seed(0)
+    net = R.UNet2DModel(**engine.unet_cfg)
+    opt = torch.optim.Adam(net.parameters(), lr=1e-4)
+    ema = R.EMAModel(net.parameters())
+    sch = R.DDPMScheduler(**engine.config["scheduler_config"])
+    B = 8
+    g = torch.Generator().manual_seed(0)
+    x, n = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1, torch.randn(B, 3, 32, 32, generator=g)
+    t = R.antithetic_timesteps(torch.randint(0, 1000, (B // 2 + 1,), generator=g), 1000, B)
+    R.train_step(net, opt, ema, sch, x, n, t)                          # warm-up
+    t0 = time.time()
+    for _ in range(2):
+        R.train_step(net, opt, ema, sch, x, n, t)
+    t_train_img = (time.time() - t0) / 2 / B
+    dd = R.DDIMScheduler()
+    dd.set_timesteps(DDIM_STEPS)
+    net.eval()
+    t0 = time.time()
+    with torch.no_grad():
+        xs = n.clone()
+        for ts in dd.timesteps[:3]:
+            xs = dd.step(net(xs, ts).sample, ts, xs).prev_sample
+    t_fwd_img = (time.time() - t0) / 3 / B
+    coalition_s = GD_STEPS * TRAIN_B * t_train_img + N_SAMPLES * DDIM_STEPS * t_fwd_img
+    return {"value": 3600.0 / coalition_s, "unit": "coalitions/hour", "cores": threads, "kind": "port",
+            "sample": f"oracle (PyTorch-CPU fp32 restatement) on {threads} threads: 2 train steps + 3 DDIM sampler "
+                      f"steps at B={B}, scaled per image to 1000x128 train images + 10240x100 sampler images",
+            "train_s_per_image": t_train_img, "sampler_s_per_image": t_fwd_img}
+
+
+def main():
+    a = parse()
+    world = int(os.environ.get("WORLD_SIZE", "1"))
+    rank = int(os.environ.get("RANK", "0"))
+    local = int(os.environ.get("LOCAL_RANK", "0"))
+    import torch.distributed as dist
+    if world > 1:
+        os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+        torch.cuda.set_device(local)
+        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+    dev = torch.device(f"cuda:{local}")
+    torch.cuda.set_device(dev)
+
+    import gad
+    from gad import ops
+    from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
+
+    engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
+                             sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    prof = None
+    if a.full_coalition:
+        for i in range(a.warmup):
+            engine.run_coalition(10_000 + rank)
+        barrier()
+        t0 = time.time()
+        recs = [engine.run_coalition(rank + world * i, verbose=(rank == 0)) for i in range(a.steps)]
+        barrier()
+        dt = time.time() - t0
+        units = a.steps * world                                         # coalitions
+    else:
+        run = SliceRunner(engine, removal_seed=rank)
+        for _ in range(a.warmup):
+            run.slice()
+        barrier()
+        if not a.no_kernel_timing:
+            prof = ops.GemmProfiler()
+            ops.PROFILER = prof
+        t0 = time.time()
+        for _ in range(a.steps):
+            loss = run.slice()
+        barrier()
+        dt = time.time() - t0
+        ops.PROFILER = None
+        units = a.steps * world / float(GD_STEPS)
+        recs = [CoalitionRecord(rank, len(run.loader.x), 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
+    # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
+    if world > 1:
+        packed = gather_records([r.pack(engine.n_groups) for r in recs], 8 + engine.n_groups, dev)
+        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+    value = units / (dt / 3600.0)
+
+    if rank == 0:
+        out = {
+            "metric": "shapley_coalitions_per_hour", "value": value, "unit": "coalitions/hour", "n_gpus": world,
+            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
+            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "config": {"workload": ("CIFAR-20 DDPM sFT coalition (BASELINE configs[1]): gd_steps=1000 @B=128 + 10240 samples"
+                                    " x 100 DDIM steps @B=32 (4 batches fused/launch), UNet2DModel 35.75M params fp32; "
+                                    + ("step = one complete coalition" if a.full_coalition else
+                                       "step = 1/1000 coalition = 1 train step + 8 sampler steps @B=128")),
+                       "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"},
+        }
+        # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU
+        # (empirical_verification.ipynb:128,132) -> per-GPU ratio
+        out["vs_baseline"] = value / world / 3.27
+        if not a.full_coalition:
+            train_flop = 3 * UNET_GFLOP_PER_IMG * 1e9 * TRAIN_B
+            samp_flop = UNET_GFLOP_PER_IMG * 1e9 * SAMPLE_B * FUSE * 8
+            out["unet_tflops_per_gpu"] = (train_flop + samp_flop) * a.steps / dt / 1e12
+        if prof is not None:
+            torch.cuda.synchronize(dev)
+            summ = prof.summary()
+            kern = {f"{k[0]}_t{k[1]}_sk{k[2]}_v{k[3]}": dict(launches=v["launches"], avg_us=v["ms"] / v["launches"] * 1e3,
+                                                           tflops=v["flops"] / v["ms"] / 1e9) for k, v in summ.items()}
+            dom_key = max(summ, key=lambda k: summ[k]["ms"])
+            d = summ[dom_key]
+            traffic = None
+            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
+            if os.path.exists(pmc):
+                traffic = json.load(open(pmc)).get("dominant_kernel_hbm_bytes_per_launch")
+            out["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dom_key[0]}, tile {dom_key[1]}, splitk {dom_key[2]}>",
+                               "achieved": d["flops"] / d["ms"] / 1e9, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
+                               "frac": d["flops"] / d["ms"] / 1e9 / F32_MFMA_PEAK_TF, "traffic": traffic,
+                               "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
+                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "share_of_step_time": d["ms"] / (dt * 1e3)}
+            all_ms = sum(v["ms"] for v in summ.values())
+            all_fl = sum(v["flops"] for v in summ.values())
+            out["contraction_kernels"] = {"tflops": all_fl / all_ms / 1e9, "share_of_step_time": all_ms / (dt * 1e3),
+                                          "by_instance": kern}
+        if world == 1 and not a.no_cpu_baseline:
+            out["cpu_baseline"] = cpu_baseline(engine)
+        print(json.dumps(out), flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
+if __name__ == "__main__":
+    main()

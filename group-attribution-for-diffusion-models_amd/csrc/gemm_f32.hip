@@ -78,8 +78,8 @@ struct MCSlots {
   }
 };
 
-// dense [row][k]
-template <int ROWS>
+// dense [row][k]   (VEC == 1: scalar loads, any K / leading dimension)
+template <int ROWS, int VEC>
 struct LoadKCDense : KCSlots<ROWS> {
   using S = KCSlots<ROWS>;
   const float* ptr[S::NS];
@@ -94,9 +94,20 @@ struct LoadKCDense : KCSlots<ROWS> {
   }
   __device__ void load(int k0, f32x4* v) const {
     int k = k0 + S::kq4();
-    bool kok = k < kend;
 #pragma unroll
-    for (int i = 0; i < S::NS; ++i) v[i] = (kok && ptr[i]) ? ldg4(ptr[i] + k) : zero4();
+    for (int i = 0; i < S::NS; ++i) {
+      if (VEC == 4) {
+        v[i] = (k < kend && ptr[i]) ? ldg4(ptr[i] + k) : zero4();
+      } else {
+        f32x4 t = zero4();
+        if (ptr[i]) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e)
+            if (k + e < kend) t[e] = ptr[i][k + e];
+        }
+        v[i] = t;
+      }
+    }
   }
 };
 
@@ -317,7 +328,7 @@ struct LoadConvCols : MCSlots<ROWS> {
 template <int MODE, int ROWS, int VEC>
 struct ALoader;
 template <int ROWS, int VEC>
-struct ALoader<GAD_A_KC, ROWS, VEC> : LoadKCDense<ROWS> {
+struct ALoader<GAD_A_KC, ROWS, VEC> : LoadKCDense<ROWS, VEC> {
   static constexpr bool KC = true;
   __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.lda, row0, p.M, kend); }
 };
@@ -340,7 +351,7 @@ struct ALoader<GAD_A_CONVT, ROWS, VEC> : LoadConvRows<ROWS, true, VEC> {
 template <int MODE, int ROWS, int VEC>
 struct BLoader;
 template <int ROWS, int VEC>
-struct BLoader<GAD_B_KC, ROWS, VEC> : LoadKCDense<ROWS> {
+struct BLoader<GAD_B_KC, ROWS, VEC> : LoadKCDense<ROWS, VEC> {
   static constexpr bool KC = true;
   __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
 };
@@ -549,6 +560,26 @@ static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
 
 }  // namespace
 
+static int pick_vec(const gad_gemm_args* a) {
+  int vec = 4;
+  const int am = a->a_mode, bmode = a->b_mode;
+  if (am == GAD_A_KC && (a->K % 4 != 0 || a->lda % 4 != 0)) vec = 1;
+  if (am == GAD_A_MC && (a->M % 4 != 0 || a->lda % 4 != 0)) vec = 1;
+  if (bmode == GAD_B_KC && (a->K % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
+  if (bmode == GAD_B_MC && (a->N % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
+  if ((am == GAD_A_CONV || am == GAD_A_CONVT || bmode == GAD_B_CONV) && (a->g.C % 4 != 0 || a->g.ldx % 4 != 0)) vec = 1;
+  return vec;
+}
+
+extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
+  GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
+  Plan pl = make_plan(a);
+  *tile = pl.bm;
+  *splitk = pl.splitk;
+  *vec = pick_vec(a);
+  return 0;
+}
+
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   Plan pl = make_plan(a);
   if (pl.splitk == 1) return 0;
@@ -562,16 +593,22 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   const int am = a->a_mode, bmode = a->b_mode;
   const bool convA = am == GAD_A_CONV || am == GAD_A_CONVT;
   const bool geomB = bmode == GAD_B_CONV || bmode == GAD_B_WDGRAD;
-  int vec = 4;
+  int vec = pick_vec(a);
   // --- shape / alignment contracts of the float4 paths (checked on the host so that a
   //     mismatch is an error, never an out-of-bounds access on the device) ---
   GAD_CHECK(gad_aligned16(a->A) && gad_aligned16(a->B), "gad_gemm: A/B must be 16-byte aligned");
-  if (am == GAD_A_KC) GAD_CHECK(a->K % 4 == 0 && a->lda % 4 == 0 && a->lda >= a->K, "gad_gemm: A_KC needs K%%4==0, lda%%4==0 (K=%d lda=%d)", a->K, a->lda);
+  if (am == GAD_A_KC) {
+    GAD_CHECK(a->lda >= a->K, "gad_gemm: A_KC needs lda >= K (K=%d lda=%d)", a->K, a->lda);
+    if (a->K % 4 != 0 || a->lda % 4 != 0) vec = 1;
+  }
   if (am == GAD_A_MC) {
     GAD_CHECK(a->lda >= a->M, "gad_gemm: A_MC needs lda >= M (M=%d lda=%d)", a->M, a->lda);
     if (a->M % 4 != 0 || a->lda % 4 != 0) vec = 1;
   }
-  if (bmode == GAD_B_KC) GAD_CHECK(a->K % 4 == 0 && a->ldb % 4 == 0 && a->ldb >= a->K, "gad_gemm: B_KC needs K%%4==0, ldb%%4==0 (K=%d ldb=%d)", a->K, a->ldb);
+  if (bmode == GAD_B_KC) {
+    GAD_CHECK(a->ldb >= a->K, "gad_gemm: B_KC needs ldb >= K (K=%d ldb=%d)", a->K, a->ldb);
+    if (a->K % 4 != 0 || a->ldb % 4 != 0) vec = 1;
+  }
   if (bmode == GAD_B_MC) {
     GAD_CHECK(a->ldb >= a->N, "gad_gemm: B_MC needs ldb >= N (N=%d ldb=%d)", a->N, a->ldb);
     if (a->N % 4 != 0 || a->ldb % 4 != 0) vec = 1;

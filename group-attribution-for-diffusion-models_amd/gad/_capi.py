@@ -62,6 +62,7 @@ SIGNATURES = {
     "gad_last_error": (C.c_char_p, []),
     "gad_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),

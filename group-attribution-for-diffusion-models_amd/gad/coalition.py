@@ -1,0 +1,330 @@
+"""The per-coalition sFT cycle (reference unconditional_generation/unlearn.py:267-969,
+method "gd", removal_dist "shapley") as an in-process engine, and the one-coalition-per-GPU
+scheduler that replaces the reference's SLURM job array
+(text_to_image/experiments/setup_unlearn_commands.py:160-214, unlearn.job:7-22).
+
+One process per GPU; rank r runs the coalitions whose ``removal_seed % world == r``; the
+only exchange is one ``all_gather`` (RCCL over xGMI) of fixed-size score records at the end.
+"""
+from __future__ import annotations
+
+import json
+import os
+import time
+from dataclasses import dataclass, field
+from typing import List, Optional, Sequence
+
+import numpy as np
+import torch
+
+from . import ops
+from .nn import UNet2DModel
+from .pipelines import DDPMPipeline
+from .schedulers import DDIMScheduler, DDPMScheduler
+from .training import EMAModel, FusedTrainer
+
+
+def seed_everything(seed: int):
+    """lightning.seed_everything as used at unlearn.py:359."""
+    import random
+    random.seed(seed)
+    np.random.seed(seed)
+    torch.manual_seed(seed)
+    if torch.cuda.is_available():
+        torch.cuda.manual_seed_all(seed)
+
+
+def antithetic_timesteps(n_train_timesteps: int, batch: int, device, generator=None) -> torch.Tensor:
+    """main.py:684-696 / unlearn.py:591-603: t1 ~ U{0..N-1}^(B//2+1); t = cat([t1, N - t1 - 1])[:B]."""
+    t1 = torch.randint(0, n_train_timesteps, (batch // 2 + 1,), device=device, generator=generator).long()
+    return torch.cat([t1, n_train_timesteps - t1 - 1], dim=0)[:batch]
+
+
+class DeviceLoader:
+    """DataLoader(Subset(dataset, remaining_idx), batch_size, shuffle=True) with the whole subset
+    resident in HBM (10 000 CIFAR images = 123 MB): per epoch one device randperm, batches are
+    index_select views; RandomHorizontalFlip is applied per sample on the device.  The last batch
+    of an epoch is short (drop_last=False), as in the reference (unlearn.py:373-379)."""
+
+    def __init__(self, dataset, idx: Sequence[int], batch_size: int, device, flip=True):
+        self.x = dataset.device_tensor(device, idx)             # [n,3,H,W] in [-1,1]
+        self.labels = torch.as_tensor([dataset.targets[i] for i in idx], device=device)
+        self.bs, self.flip, self.device = batch_size, flip, device
+
+    def __len__(self):
+        return (self.x.shape[0] + self.bs - 1) // self.bs
+
+    def __iter__(self):
+        n = self.x.shape[0]
+        perm = torch.randperm(n, device=self.device)
+        for s in range(0, n, self.bs):
+            sel = perm[s:s + self.bs]
+            xb = self.x.index_select(0, sel)
+            if self.flip:
+                m = torch.rand(xb.shape[0], device=self.device) < 0.5
+                xb = torch.where(m[:, None, None, None], xb.flip(-1), xb)
+            yield xb, self.labels.index_select(0, sel)
+
+
+class FusedSampler:
+    """generate_images (src/diffusion_utils.py:319-357) with several reference batches fused into
+    one U-Net launch: every reference batch b of `batch_size` images still draws its initial noise
+    from ``torch.Generator().manual_seed(b)`` on the host (bit-identical noise), but `fuse` of them
+    are stacked along N so the contraction kernels see M = fuse*batch_size*H*W rows.  The U-Net
+    has no cross-sample op (GroupNorm and attention are per sample), so results are unchanged."""
+
+    def __init__(self, unet: UNet2DModel, scheduler: DDIMScheduler, batch_size=32, fuse=4):
+        self.unet, self.sch, self.bs, self.fuse = unet, scheduler, batch_size, fuse
+        self.device = unet.device
+
+    def initial_noise(self, counters: Sequence[int], sizes: Sequence[int]) -> torch.Tensor:
+        cfg = self.unet.config
+        ss = cfg.sample_size
+        parts = [torch.randn((n, cfg.in_channels, ss, ss), generator=torch.Generator().manual_seed(c),
+                             dtype=torch.float32) for c, n in zip(counters, sizes)]
+        return ops.nchw_to_nhwc_raw(torch.cat(parts, 0).to(self.device))
+
+    @torch.no_grad()
+    def denoise(self, x: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
+        """x NHWC noise -> NHWC images in [0,1] after the full DDIM trajectory."""
+        sch = self.sch
+        sch.set_timesteps(num_inference_steps)
+        clip = float(sch.config.clip_sample_range) if sch.config.clip_sample else 0.0
+        t = torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
+        for ts in sch.timesteps.tolist():
+            t.fill_(ts)
+            eps = self.unet.forward_nhwc(x, t)
+            a_t, a_p = sch.step_coefficients(ts)
+            ops.ddim_step_raw(x, eps, a_t, a_p, clip, out=x)
+        return ops.to_image01_raw(x)
+
+    @torch.no_grad()
+    def generate(self, n_samples: int, num_inference_steps: int) -> torch.Tensor:
+        """-> float tensor [n,3,H,W] holding k/255 values (uint8 round trip of :344-355), on device."""
+        sizes = [self.bs] * (n_samples // self.bs)
+        if n_samples % self.bs:
+            sizes.append(n_samples % self.bs)
+        out = []
+        for g0 in range(0, len(sizes), self.fuse):
+            cs = list(range(g0, min(g0 + self.fuse, len(sizes))))
+            img = self.denoise(self.initial_noise(cs, [sizes[c] for c in cs]), num_inference_steps)
+            q = img.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)       # .mul(255).add_(0.5).clamp_(0,255) -> uint8
+            out.append(q.permute(0, 3, 1, 2).float().div_(255))             # ToTensor(): /255
+        return torch.cat(out, 0)
+
+
+@dataclass
+class CoalitionRecord:
+    """What one coalition contributes to the .jsonl "db" (unlearn.py:960-968) - and the payload of
+    the final all-gather."""
+    removal_seed: int
+    n_remaining: int
+    n_removed: int
+    fid_value: float
+    loss_last: float
+    total_steps_time: float
+    total_sampling_time: float
+    trained_steps: int
+    remaining_classes: List[int] = field(default_factory=list)
+
+    PACK = 8 + 32   # doubles: 8 scalars + class mask (up to 256 contributors as 32 x 8-bit... stored as doubles)
+
+    def pack(self, n_groups: int) -> torch.Tensor:
+        v = torch.zeros(8 + n_groups, dtype=torch.float64)
+        v[:8] = torch.tensor([self.removal_seed, self.n_remaining, self.n_removed, self.fid_value, self.loss_last,
+                              self.total_steps_time, self.total_sampling_time, self.trained_steps], dtype=torch.float64)
+        for c in self.remaining_classes:
+            v[8 + int(c)] = 1.0
+        return v
+
+    @classmethod
+    def unpack(cls, v: torch.Tensor):
+        s = v[:8].tolist()
+        mask = v[8:]
+        return cls(int(s[0]), int(s[1]), int(s[2]), s[3], s[4], s[5], s[6], int(s[7]),
+                   [i for i in range(mask.numel()) if mask[i] > 0.5])
+
+
+class CoalitionEngine:
+    """Everything one rank needs to run coalitions back to back on its GPU."""
+
+    def __init__(self, dataset_name="cifar100", device="cuda:0", base_state: Optional[dict] = None,
+                 gd_steps: Optional[int] = None, n_samples=10240, sample_batch=32, fuse=4,
+                 num_inference_steps=100, opt_seed=42, by_class=True, preview=True, reference_stats=None,
+                 unet_overrides: Optional[dict] = None, feature_dims=2048):
+        from src.datasets import create_dataset
+        from src.ddpm_config import DDPMConfig
+        from .scoring import FeatureNet
+
+        self.device = torch.device(device)
+        self.dataset_name = dataset_name
+        cfg_name = {"cifar100": "cifar100_config", "cifar": "cifar_config", "cifar2": "cifar2_config",
+                    "toy2": "cifar100_config"}[dataset_name]
+        self.config = {**getattr(DDPMConfig, cfg_name)}
+        self.unet_cfg = dict(self.config["unet_config"])
+        if unet_overrides:
+            self.unet_cfg.update(unet_overrides)
+        self.gd_steps = gd_steps if gd_steps is not None else self.config["training_steps"]["gd"]
+        self.n_samples, self.sample_batch, self.fuse = n_samples, sample_batch, fuse
+        self.num_inference_steps, self.opt_seed, self.by_class, self.preview = num_inference_steps, opt_seed, by_class, preview
+        self.dataset = create_dataset(dataset_name, train=True)
+        self.n_groups = len(set(self.dataset.targets))
+        self.train_scheduler = DDPMScheduler(**self.config["scheduler_config"])
+        self.sample_scheduler = DDIMScheduler()            # build_pipeline: DDPMPipeline(unet, DDIMScheduler()) :311
+        # the "pruned + fine-tuned" starting point every coalition resumes from (load_ckpt_model :111-205)
+        if base_state is None:
+            torch.manual_seed(0)
+            m = UNet2DModel(**self.unet_cfg)
+            ema = EMAModel(m.parameters())
+            ema.optimization_step = 10000                   # as after prune_fine_tune (ddpm_config.py:207-215)
+            base_state = {"unet": {k: v.clone() for k, v in m.state_dict().items()}, "unet_ema": ema.state_dict()}
+        self.base_state = base_state
+        self.feature_net = FeatureNet(feature_dims).to(self.device)
+        self.reference_stats = reference_stats
+        self.opt_kwargs = dict(self.config["optimizer_config"]["kwargs"])
+        self.adamw = self.config["optimizer_config"]["class_name"] == "AdamW"
+
+    # -- pieces ---------------------------------------------------------------------------------
+    def coalition(self, removal_seed: int):
+        from src.datasets import remove_data_by_shapley
+        return remove_data_by_shapley(self.dataset, seed=removal_seed, by_class=self.by_class)
+
+    def load_base(self):
+        model = UNet2DModel(**self.unet_cfg)
+        model.load_state_dict(self.base_state["unet"])
+        model.to(self.device)
+        ema = EMAModel(model.parameters())                  # defaults, then overridden (diffusion_utils.py:193-198)
+        ema.load_state_dict(self.base_state["unet_ema"])
+        return model, ema
+
+    def make_trainer(self, model, ema):
+        kw = self.opt_kwargs
+        return FusedTrainer(model, self.train_scheduler, ema, lr=kw.get("lr", 1e-4),
+                            weight_decay=kw.get("weight_decay", 0.0), adamw=self.adamw, max_grad_norm=1.0)
+
+    def reference_statistics(self):
+        """mu/sigma of the training set under the feature net (stats.pkl of fid_score.py:42-58)."""
+        if self.reference_stats is None:
+            from .scoring import compute_features, feature_stats
+            x = self.dataset.device_tensor(self.device).add_(1).div_(2)
+            self.reference_stats = feature_stats(compute_features(self.feature_net, x, 512, self.device))
+        return self.reference_stats
+
+    def score(self, images01: torch.Tensor) -> float:
+        from .scoring import compute_features, feature_stats, frechet_distance
+        mu, sigma = feature_stats(compute_features(self.feature_net, images01, 512, self.device))
+        mu_r, sigma_r = self.reference_statistics()
+        return frechet_distance(mu, sigma, mu_r, sigma_r)
+
+    # -- the cycle -------------------------------------------------------------------------------
+    def run_coalition(self, removal_seed: int, verbose=False) -> CoalitionRecord:
+        remaining_idx, removed_idx = self.coalition(removal_seed)
+        seed_everything(self.opt_seed)                                    # unlearn.py:359
+        model, ema = self.load_base()
+        trainer = self.make_trainer(model, ema)
+        loader = DeviceLoader(self.dataset, remaining_idx, self.config["batch_size"], self.device)
+        n_t = self.train_scheduler.config.num_train_timesteps
+        t0 = time.time()
+        steps = 0
+        loss = torch.zeros(1, device=self.device)
+        while steps < self.gd_steps:                                      # unlearn.py:558-642
+            for image, _ in loader:
+                noise = torch.randn_like(image)
+                ts = antithetic_timesteps(n_t, image.shape[0], self.device)
+                loss = trainer.step(image, noise, ts)
+                steps += 1
+                if steps == self.gd_steps:
+                    break
+        torch.cuda.synchronize(self.device)
+        total_steps_time = time.time() - t0
+        # EMA weights are used for inference (unlearn.py:751-753); the fine-tuned ones are not kept
+        model.flat[0].copy_(trainer.ema_flat)
+        model.eval()
+        t1 = time.time()
+        if self.preview:                                                  # unlearn.py:761-765 (global RNG)
+            pipe = DDPMPipeline(model, self.sample_scheduler)
+            pipe.use_graph = False                                        # one-off call: not worth a capture
+            pipe(batch_size=self.config["n_samples"], num_inference_steps=self.num_inference_steps,
+                 output_type="tensor")
+        sampler = FusedSampler(model, self.sample_scheduler, self.sample_batch, self.fuse)
+        images = sampler.generate(self.n_samples, self.num_inference_steps)
+        fid = self.score(images)
+        torch.cuda.synchronize(self.device)
+        rec = CoalitionRecord(removal_seed, len(remaining_idx), len(removed_idx), fid, float(loss.item()),
+                              total_steps_time, time.time() - t1, steps,
+                              sorted(set(int(self.dataset.targets[i]) for i in remaining_idx)))
+        if verbose:
+            print(f"[coalition {removal_seed}] |S|={rec.n_remaining} train {total_steps_time:.1f}s "
+                  f"sample+score {rec.total_sampling_time:.1f}s fid {fid:.4f}", flush=True)
+        return rec
+
+    def jsonl_row(self, rec: CoalitionRecord, extra: Optional[dict] = None) -> dict:
+        """Keys lds.py reads (lds.py:203-257): dataset, removal_dist, method, exp_name, removal_seed,
+        remaining_idx, fid_value, gd_steps, total_steps_time, total_sampling_time."""
+        remaining_idx, removed_idx = self.coalition(rec.removal_seed)
+        row = dict(dataset=self.dataset_name, method="gd", removal_dist="shapley", removal_seed=rec.removal_seed,
+                   datamodel_alpha=None, exp_name=f"gd_shapley_seed_{rec.removal_seed}", gd_steps=self.gd_steps,
+                   opt_seed=self.opt_seed, n_samples=self.n_samples, num_inference_steps=self.num_inference_steps,
+                   model_behavior="global", fid_value=rec.fid_value, total_steps_time=rec.total_steps_time,
+                   trained_steps=rec.trained_steps, remaining_idx=np.asarray(remaining_idx).tolist(),
+                   removed_idx=np.asarray(removed_idx).tolist(), device=str(self.device),
+                   total_sampling_time=rec.total_sampling_time)
+        if extra:
+            row.update(extra)
+        return row
+
+
+def shard_seeds(seeds: Sequence[int], rank: int, world: int) -> List[int]:
+    """Static partition: rank r owns the coalitions with removal_seed % world == r."""
+    return [s for s in seeds if s % world == rank]
+
+
+def gather_records(local: List[torch.Tensor], width: int, device, group=None) -> List[torch.Tensor]:
+    """The single data-path collective: all_gather of [max_local, width] float64 records
+    (padded with seed = -1).  Works for nccl(=RCCL) and gloo."""
+    import torch.distributed as dist
+
+    world = dist.get_world_size(group)
+    n_local = torch.tensor([len(local)], device=device)
+    counts = [torch.zeros_like(n_local) for _ in range(world)]
+    dist.all_gather(counts, n_local, group=group)
+    cap = max(int(c.item()) for c in counts)
+    buf = torch.full((max(cap, 1), width), -1.0, dtype=torch.float64, device=device)
+    for i, v in enumerate(local):
+        buf[i] = v.to(device)
+    bufs = [torch.empty_like(buf) for _ in range(world)]
+    dist.all_gather(bufs, buf, group=group)
+    out = []
+    for b, c in zip(bufs, counts):
+        out += [b[i].cpu() for i in range(int(c.item()))]
+    return sorted(out, key=lambda v: v[0].item())
+
+
+def run_sharded(engine: CoalitionEngine, seeds: Sequence[int], db_path: Optional[str] = None, verbose=False):
+    """Run `seeds` across the ranks of the default process group (or alone) and, on rank 0, append the
+    merged rows to the jsonl db in seed order.  Seeds already present in the db are skipped
+    (idempotent re-entry, setup_unlearn_commands.py:133-154)."""
+    import torch.distributed as dist
+
+    dist_on = dist.is_available() and dist.is_initialized()
+    rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
+    done = set()
+    if db_path and os.path.exists(db_path):
+        with open(db_path) as f:
+            for line in f:
+                try:
+                    done.add(int(json.loads(line)["removal_seed"]))
+                except (ValueError, KeyError):
+                    pass
+    mine = shard_seeds([s for s in seeds if s not in done], rank, world)
+    recs = [engine.run_coalition(s, verbose=verbose) for s in mine]
+    width = 8 + engine.n_groups
+    packed = [r.pack(engine.n_groups) for r in recs]
+    if dist_on:
+        packed = gather_records(packed, width, engine.device if dist.get_backend() == "nccl" else "cpu")
+    all_recs = [CoalitionRecord.unpack(v) for v in packed]
+    if rank == 0 and db_path:
+        with open(db_path, "a+") as f:
+            for r in all_recs:
+                f.write(json.dumps(engine.jsonl_row(r)) + "\n")
+    return all_recs

@@ -85,7 +85,43 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ldr = ldr
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
+    if PROFILER is not None:
+        PROFILER.gemm(lib, a, batch)
+        return
     check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+
+
+class GemmProfiler:
+    """Brackets every contraction launch with HIP events on the launch stream (bench.py's live
+    per-kernel timing).  Keyed by the kernel instance the C side picks (modes, tile, vec)."""
+    NAMES = {(A_CONV, B_KC): "conv_fwd", (A_CONVT, B_WDGRAD): "conv_dgrad", (A_MC, B_CONV): "conv_wgrad",
+             (A_KC, B_KC): "gemm_nt", (A_KC, B_MC): "gemm_nn", (A_MC, B_MC): "gemm_tn"}
+
+    def __init__(self):
+        self.records = []          # (key, flops, start_event, end_event)
+
+    def gemm(self, lib, a, batch):
+        tile, sk, vec = C.c_int32(), C.c_int32(), C.c_int32()
+        check(lib.gad_gemm_plan(C.byref(a), C.byref(tile), C.byref(sk), C.byref(vec)), "gad_gemm_plan")
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+        e.record()
+        key = (self.NAMES.get((a.a_mode, a.b_mode), "gemm"), tile.value, sk.value, vec.value)
+        self.records.append((key, 2.0 * a.M * a.N * a.K * max(1, batch), s, e))
+
+    def summary(self):
+        """{key: dict(launches, ms, flops)} - call after a device synchronize."""
+        out = {}
+        for key, fl, s, e in self.records:
+            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0))
+            d["launches"] += 1
+            d["ms"] += s.elapsed_time(e)
+            d["flops"] += fl
+        return out
+
+
+PROFILER = None
 
 
 def _conv_out_size(h, k, stride, pad_lo, pad_hi):

@@ -1,0 +1,74 @@
+"""Model-behaviour score tail for the CIFAR configuration (reference
+src/attributions/global_scores/fid_score.py:23-107).
+
+The reference extracts pool3 features with pytorch_fid's InceptionV3, whose weights are
+fetched from a URL (fid_score.py:28) and are unobtainable offline; the feature extractor is
+therefore a *seeded random-weight* conv stack built from the same HIP operators (the tail is
+~1 % of a coalition's FLOPs), while the score arithmetic - float64 mean / covariance and the
+Frechet distance - is restated exactly (fid_score.py:104-105 and
+pytorch_fid.calculate_frechet_distance)."""
+from __future__ import annotations
+
+import numpy as np
+import torch
+import torch.nn as nn
+
+from . import nn as gnn
+from . import ops
+
+
+class FeatureNet(nn.Module):
+    """[B,3,32,32] in [0,1] -> [B,2048] features (GroupNorm/SiLU conv pyramid + global average pool)."""
+
+    def __init__(self, dims=2048, seed=1234):
+        super().__init__()
+        rng = torch.random.get_rng_state()
+        torch.manual_seed(seed)
+        chans = [(3, 64, 1), (64, 128, 2), (128, 256, 2), (256, 512, 2)]
+        self.convs = nn.ModuleList([gnn.Conv2d(ci, co, 3, stride=s, pad=(1, 1, 1, 1)) for ci, co, s in chans])
+        self.norms = nn.ModuleList([gnn.GroupNorm(32, co, 1e-5) for _, co, _ in chans])
+        self.head = gnn.Linear(512, dims)
+        torch.random.set_rng_state(rng)
+        self.dims = dims
+
+    @torch.no_grad()
+    def forward(self, images_nchw01):
+        x = ops.nchw_to_nhwc_raw((images_nchw01.float() * 2 - 1).contiguous())
+        for conv, norm in zip(self.convs, self.norms):
+            x = norm(conv(x), silu=True)
+        b, h, w, c = x.shape
+        pooled = ops.colsum_raw(x.view(b * h * w, c), segments=b) / float(h * w)
+        return self.head(pooled)
+
+
+def feature_stats(features: np.ndarray):
+    """mu, sigma exactly as fid_score.compute_features_stats (:104-105): float64 mean and np.cov."""
+    f = np.asarray(features, dtype=np.float64)
+    return np.mean(f, axis=0), np.cov(f, rowvar=False)
+
+
+def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
+    """d^2 = |mu1-mu2|^2 + Tr(s1 + s2 - 2 sqrt(s1 s2))  (pytorch_fid.calculate_frechet_distance)."""
+    from scipy import linalg
+
+    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
+    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
+    diff = mu1 - mu2
+    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
+    if not np.isfinite(covmean).all():
+        offset = np.eye(sigma1.shape[0]) * eps
+        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
+    if np.iscomplexobj(covmean):
+        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
+            raise ValueError(f"Imaginary component {np.max(np.abs(covmean.imag))}")
+        covmean = covmean.real
+    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+
+
+def compute_features(net: FeatureNet, images: torch.Tensor, batch_size: int, device) -> np.ndarray:
+    """images [N,3,H,W] float in [0,1] (host or device) -> float64 [N, dims] (fid_score.py:74-102)."""
+    out = np.empty((len(images), net.dims))
+    for s in range(0, len(images), batch_size):
+        f = net(images[s:s + batch_size].to(device))
+        out[s:s + f.shape[0]] = f.double().cpu().numpy()
+    return out

@@ -86,6 +86,8 @@ typedef struct gad_gemm_args {
 } gad_gemm_args;
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
+/* which kernel instance gad_gemm would launch: block tile edge (128 or 64), split-K factor, vector width (4 or 1) */
+int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec);
 int gad_gemm(const gad_gemm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------

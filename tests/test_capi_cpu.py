@@ -38,11 +38,11 @@ def test_host_side_argument_validation_without_gpu():
     assert lib.gad_gemm(ctypes.byref(a), None) != 0          # null pointers are rejected on the host
     assert b"null" in lib.gad_last_error()
     a.A = a.B = a.C = 16
-    a.M, a.N, a.K = 8, 8, 6                                    # K % 4 != 0 for the float4 path
-    a.lda = a.ldb = 6
-    a.ldc = 8
+    a.M, a.N, a.K = 8, 8, 8
+    a.lda = a.ldb = 8
+    a.ldc = 4                                                  # ldc < N would write out of bounds
     assert lib.gad_gemm(ctypes.byref(a), None) != 0
-    assert b"K%4" in lib.gad_last_error()
+    assert b"ldc" in lib.gad_last_error()
 
 
 def test_product_path_has_no_cpu_fallback():

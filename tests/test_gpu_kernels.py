@@ -326,10 +326,13 @@ def test_unet_forward_backward_cifar(ops):
     got.backward(d)
     close(got, want, atol=1e-4)
     gref = dict(ref.named_parameters())
+    # to_k.bias gradients are analytically zero (softmax is shift invariant): compare every parameter's
+    # error with the typical gradient norm rather than with its own (noise-level) norm
+    typical = float(np.median([g.grad.norm().item() for g in gref.values()]))
     worst = 0.0
     for n, p in mine.named_parameters():
         a, b = p.grad.detach().cpu().double(), gref[n].grad.double()
-        worst = max(worst, ((a - b).norm() / (b.norm() + 1e-12)).item())
+        worst = max(worst, ((a - b).norm() / (b.norm() + 1e-3 * typical)).item())
     assert worst < 2e-3, worst
 
 
