@@ -35,6 +35,10 @@ UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
+def log(msg):
+    print(f"[bench {time.strftime('%H:%M:%S')}] {msg}", file=sys.stderr, flush=True)
+
+
 def parse():
     ap = argparse.ArgumentParser()
     ap.add_argument("--gpus", type=int, default=1)
@@ -119,8 +123,13 @@ def cpu_baseline(engine):
     not installable) timed on the host cores on a bounded sample: 2 training steps and 3 sampler steps at
     B=8, scaled per image to one coalition."""
     from oracle import diffusers_ref as R
-    threads = os.cpu_count() or 1
+    try:
+        threads = len(os.sched_getaffinity(0))
+    except AttributeError:
+        threads = os.cpu_count() or 1
+    threads = max(1, min(threads, int(os.environ.get("GAD_CPU_THREADS", "16"))))   # the GPU box grants a 16-CPU share
     torch.set_num_threads(threads)
+    log(f"cpu_baseline: oracle on {threads} threads")
     torch.manual_seed(0)
     net = R.UNet2DModel(**engine.unet_cfg)
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
@@ -168,6 +177,7 @@ def main():
     from gad import ops
     from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
 
+    log(f"rank {rank}/{world} on {dev}: building engine")
     engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
                              sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS)
 
@@ -188,8 +198,10 @@ def main():
         units = a.steps * world                                         # coalitions
     else:
         run = SliceRunner(engine, removal_seed=rank)
+        log("slice runner ready; warm-up")
         for _ in range(a.warmup):
             run.slice()
+        log("timed region")
         barrier()
         if not a.no_kernel_timing:
             prof = ops.GemmProfiler()
@@ -199,6 +211,7 @@ def main():
             loss = run.slice()
         barrier()
         dt = time.time() - t0
+        log(f"timed region done: {dt:.2f}s for {a.steps} steps")
         ops.PROFILER = None
         units = a.steps * world / float(GD_STEPS)
         recs = [CoalitionRecord(rank, len(run.loader.x), 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]

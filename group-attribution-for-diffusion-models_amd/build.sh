@@ -9,7 +9,7 @@ mkdir -p "$HERE/build"
 pids=()
 for f in gemm_f32 norm elementwise optim; do
   src="$HERE/csrc/$f.hip"; obj="$HERE/build/$f.o"
-  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/gad_common.h" -nt "$obj" ] || [ "$HERE/../include/gad.h" -nt "$obj" ]; then
+  if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/gad_common.h" -nt "$obj" ] || [ "$HERE/csrc/gad_reduce.h" -nt "$obj" ] || [ "$HERE/../include/gad.h" -nt "$obj" ]; then
     $HIPCC $FLAGS -c "$src" -o "$obj" &
     pids+=($!)
   fi

@@ -5,6 +5,7 @@
 #include <stdarg.h>
 
 #include "gad_common.h"
+#include "gad_reduce.h"
 
 // ------------------------------------------------------------------ error state ----
 static thread_local char g_err[512] = "";
@@ -178,27 +179,6 @@ __global__ void upsample2x_bwd_kernel(const float* __restrict__ dy, float* __res
   }
 }
 
-// ---- two-stage segmented column sum: part[seg][chunk][N] then out[seg][N] ----
-__global__ void colsum_part_kernel(const float* __restrict__ dy, float* __restrict__ part, long M, int N, int rows_per,
-                                   int nparts) {
-  int seg = blockIdx.y;
-  long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
-  const float* base = dy + (long)seg * M * N;
-  for (int n = threadIdx.x; n < N; n += blockDim.x) {
-    float s = 0.f;
-    for (long r = r0; r < r1; ++r) s += base[r * N + n];
-    part[((long)seg * nparts + blockIdx.x) * N + n] = s;
-  }
-}
-__global__ void colsum_final_kernel(const float* __restrict__ part, float* __restrict__ out, int nparts, int N) {
-  int n = blockIdx.x * blockDim.x + threadIdx.x;
-  int seg = blockIdx.y;
-  if (n >= N) return;
-  float s = 0.f;
-  for (int k = 0; k < nparts; ++k) s += part[((long)seg * nparts + k) * N + n];
-  out[(long)seg * N + n] = s;
-}
-
 // ---- block reduction helper ----
 __device__ __forceinline__ float block_sum(float v, float* sh) {
   v = wave_sum(v);
@@ -360,15 +340,9 @@ extern "C" int gad_upsample2x_bwd(const float* dy, float* dx, int32_t B, int32_t
 extern "C" int gad_colsum(const float* dy, float* out, int32_t S, int64_t M, int32_t N, void* ws, int64_t ws_bytes,
                           void* stream) {
   GAD_CHECK(dy && out && S > 0 && S < 65536 && M > 0 && N > 0, "gad_colsum: bad args");
-  int64_t want = gad_ceil_div(2048, S);
-  int rows_per = (int)gad_ceil_div(M, want > 0 ? want : 1);
-  if (rows_per < 8) rows_per = 8;
-  int nparts = (int)gad_ceil_div(M, rows_per);
-  GAD_CHECK(ws && ws_bytes >= (int64_t)S * nparts * N * 4, "gad_colsum: workspace too small");
-  hipLaunchKernelGGL(colsum_part_kernel, dim3(nparts, S), dim3(NT), 0, ST, dy, (float*)ws, (long)M, N, rows_per, nparts);
-  GAD_LAUNCH_CHECK("gad_colsum(part)");
-  hipLaunchKernelGGL(colsum_final_kernel, dim3((N + NT - 1) / NT, S), dim3(NT), 0, ST, (const float*)ws, out, nparts, N);
-  GAD_LAUNCH_CHECK("gad_colsum(final)");
+  GAD_CHECK(ws && ws_bytes >= gad_reduce::ws_bytes(S, M, N), "gad_colsum: workspace too small");
+  gad_reduce::launch(dy, out, nullptr, S, M, N, (float*)ws, ST);
+  GAD_LAUNCH_CHECK("gad_colsum");
   return 0;
 }
 extern "C" int gad_mse_fwd_bwd(const float* a, const float* b, float* loss, float* d, int64_t n, float gscale, void* ws,

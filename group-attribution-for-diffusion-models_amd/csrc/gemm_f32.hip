@@ -27,7 +27,14 @@ constexpr int BK = 32;
 constexpr int KC_LD = BK + 4;  // 36 floats: 16 distinct 16-B slots for 16 consecutive rows
 constexpr int NTHREADS = 256;
 
+// division by a launch-invariant divisor: q = (mulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31
+struct FastDiv {
+  unsigned mul, shift;
+  __device__ __forceinline__ int div(int n) const { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shift); }
+};
+
 struct DevArgs {
+  FastDiv fdC, fdKW, fdHoWo, fdWo, fdRpg;
   const float* A;
   const float* B;
   float* C;
@@ -48,10 +55,15 @@ struct DevArgs {
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
 __device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
+__device__ __forceinline__ f32x4 keep_if(f32x4 v, bool ok) { return ok ? v : zero4(); }
 
 // ------------------------------------------------------------------------------------
-// Tile loaders.  Each thread owns NS float4 slots of the tile; `load` fetches them for
-// the K step starting at k0 (global -> registers), `store` writes them into LDS.
+// Tile loaders.  Each thread owns NS float4 slots of the tile.
+//   load(k0, v, mask): issue the global loads of the K step starting at k0.  Loads are
+//     UNCONDITIONAL (an invalid slot reads the tensor's base address) so that all of a
+//     thread's loads are in flight together behind the MFMAs of the current step;
+//     `mask` bit i says whether slot i is real data.
+//   store(lds, v, mask): zero the invalid slots and write the tile into LDS.
 // KC-type: slot i = (row (tid>>3)+32 i, float4 column tid&7)
 // MC-type: slot i = (k row tid/F4 + (256/F4) i, float4 column tid%F4),  F4 = ROWS/4
 // ------------------------------------------------------------------------------------
@@ -60,9 +72,10 @@ struct KCSlots {
   static constexpr int NS = ROWS / 32;
   __device__ static int row(int i) { return (threadIdx.x >> 3) + 32 * i; }
   __device__ static int kq4() { return (threadIdx.x & 7) * 4; }
-  __device__ static void store(float* lds, const f32x4* v) {
+  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(lds + row(i) * KC_LD + kq4()) = v[i];
+    for (int i = 0; i < NS; ++i)
+      *reinterpret_cast<f32x4*>(lds + row(i) * KC_LD + kq4()) = keep_if(v[i], (mask >> i) & 1u);
   }
 };
 template <int ROWS>
@@ -72,9 +85,10 @@ struct MCSlots {
   static constexpr int KSTEP = NTHREADS / F4;
   __device__ static int krow(int i) { return threadIdx.x / F4 + KSTEP * i; }
   __device__ static int rq4() { return (threadIdx.x % F4) * 4; }
-  __device__ static void store(float* lds, const f32x4* v) {
+  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {
 #pragma unroll
-    for (int i = 0; i < NS; ++i) *reinterpret_cast<f32x4*>(lds + krow(i) * ROWS + rq4()) = v[i];
+    for (int i = 0; i < NS; ++i)
+      *reinterpret_cast<f32x4*>(lds + krow(i) * ROWS + rq4()) = keep_if(v[i], (mask >> i) & 1u);
   }
 };
 
@@ -82,28 +96,40 @@ struct MCSlots {
 template <int ROWS, int VEC>
 struct LoadKCDense : KCSlots<ROWS> {
   using S = KCSlots<ROWS>;
-  const float* ptr[S::NS];
+  const float* base;
+  long roff[S::NS];
+  unsigned rowmask;
   int kend;
-  __device__ void init(const float* base, int ld, int row0, int nrows, int kend_) {
+  __device__ void init(const float* b, int ld, int row0, int nrows, int kend_) {
+    base = b;
     kend = kend_;
+    rowmask = 0;
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) {
       int r = row0 + S::row(i);
-      ptr[i] = r < nrows ? base + (long)r * ld : nullptr;
+      bool ok = r < nrows;
+      roff[i] = ok ? (long)r * ld : 0;
+      rowmask |= (unsigned)ok << i;
     }
   }
-  __device__ void load(int k0, f32x4* v) const {
+  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
     int k = k0 + S::kq4();
+    if (VEC == 4) {
+      bool kok = k < kend;
+      mask = kok ? rowmask : 0u;
+      int kk = kok ? k : 0;
 #pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-      if (VEC == 4) {
-        v[i] = (k < kend && ptr[i]) ? ldg4(ptr[i] + k) : zero4();
-      } else {
+      for (int i = 0; i < S::NS; ++i) v[i] = ldg4(base + roff[i] + kk);
+    } else {
+      mask = rowmask;
+#pragma unroll
+      for (int i = 0; i < S::NS; ++i) {
         f32x4 t = zero4();
-        if (ptr[i]) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (k + e < kend) t[e] = ptr[i][k + e];
+        for (int e = 0; e < 4; ++e) {
+          bool ok = k + e < kend;
+          float x = base[roff[i] + (ok ? k + e : 0)];
+          t[e] = ok ? x : 0.f;
         }
         v[i] = t;
       }
@@ -118,26 +144,33 @@ struct LoadMCDense : MCSlots<ROWS> {
   const float* base;
   int ld, kend, c0, nrows;
   __device__ void init(const float* b, int ld_, int row0, int nrows_, int kend_) {
+    base = b;
     ld = ld_;
     kend = kend_;
     nrows = nrows_;
     c0 = row0 + S::rq4();
-    base = b + c0;
   }
-  __device__ void load(int k0, f32x4* v) const {
+  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+    mask = 0;
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) {
       int k = k0 + S::krow(i);
+      bool kok = k < kend;
+      long off = kok ? (long)k * ld : 0;
       if (VEC == 4) {
-        v[i] = (c0 < nrows && k < kend) ? ldg4(base + (long)k * ld) : zero4();
+        bool ok = kok && c0 < nrows;
+        v[i] = ldg4(base + off + (ok ? c0 : 0));
+        mask |= (unsigned)ok << i;
       } else {
         f32x4 t = zero4();
-        if (k < kend) {
 #pragma unroll
-          for (int e = 0; e < 4; ++e)
-            if (c0 + e < nrows) t[e] = base[(long)k * ld + e];
+        for (int e = 0; e < 4; ++e) {
+          bool ok = kok && c0 + e < nrows;
+          float x = base[off + (ok ? c0 + e : 0)];
+          t[e] = ok ? x : 0.f;
         }
         v[i] = t;
+        mask |= 1u << i;
       }
     }
   }
@@ -150,47 +183,49 @@ struct LoadConvRows : KCSlots<ROWS> {
   using S = KCSlots<ROWS>;
   const float* x;
   gad_conv_geom g;
-  int bh[S::NS], bw[S::NS], boff[S::NS];  // per row: base h, base w, image pixel offset (or -1)
+  FastDiv fdC, fdKW;
+  int bh[S::NS], bw[S::NS], boff[S::NS];  // per row: base h, base w, image pixel offset
+  unsigned rowmask;
   int kend, hlim, wlim;
-  __device__ void init(const float* x_, const gad_conv_geom& g_, int row0, int nrows, int kend_) {
+  __device__ void init(const float* x_, const DevArgs& p, int row0, int nrows, int kend_) {
     x = x_;
-    g = g_;
+    g = p.g;
+    fdC = p.fdC;
+    fdKW = p.fdKW;
     kend = kend_;
     hlim = g.upsample ? 2 * g.H : g.H;
     wlim = g.upsample ? 2 * g.W : g.W;
-    int hw = g.Ho * g.Wo;
+    rowmask = 0;
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) {
       int m = row0 + S::row(i);
-      if (m < nrows) {
-        int img = m / hw, rem = m - img * hw;
-        int oh = rem / g.Wo, ow = rem - oh * g.Wo;
-        boff[i] = img * g.H * g.W;
-        if (TRANSPOSED) {
-          bh[i] = oh + g.pad_t;
-          bw[i] = ow + g.pad_l;
-        } else {
-          bh[i] = oh * g.stride - g.pad_t;
-          bw[i] = ow * g.stride - g.pad_l;
-        }
+      bool ok = m < nrows;
+      int mm = ok ? m : 0;
+      int img = p.fdHoWo.div(mm), rem = mm - img * (g.Ho * g.Wo);
+      int oh = p.fdWo.div(rem), ow = rem - oh * g.Wo;
+      boff[i] = img * g.H * g.W;
+      rowmask |= (unsigned)ok << i;
+      if (TRANSPOSED) {
+        bh[i] = oh + g.pad_t;
+        bw[i] = ow + g.pad_l;
       } else {
-        boff[i] = -1;
-        bh[i] = bw[i] = 0;
+        bh[i] = oh * g.stride - g.pad_t;
+        bw[i] = ow * g.stride - g.pad_l;
       }
     }
   }
-  __device__ __forceinline__ const float* addr(int i, int r, int s, int c) const {
-    if (boff[i] < 0) return nullptr;
+  // pixel offset (in floats, without the channel) of slot i for tap (r,s); ok=false if out of range
+  __device__ __forceinline__ long pix(int i, int r, int s, bool& ok) const {
     int ih, iw;
     if (TRANSPOSED) {
       int nh = bh[i] - r, nw = bw[i] - s;
-      if (nh < 0 || nw < 0) return nullptr;
+      ok = (nh | nw) >= 0;
       if (g.stride == 2) {
-        if ((nh | nw) & 1) return nullptr;
+        ok = ok && !((nh | nw) & 1);
         nh >>= 1;
         nw >>= 1;
       } else if (g.stride != 1) {
-        if (nh % g.stride || nw % g.stride) return nullptr;
+        ok = ok && (nh % g.stride == 0) && (nw % g.stride == 0);
         nh /= g.stride;
         nw /= g.stride;
       }
@@ -199,39 +234,48 @@ struct LoadConvRows : KCSlots<ROWS> {
     } else {
       ih = bh[i] + r;
       iw = bw[i] + s;
-      if (ih < 0 || iw < 0) return nullptr;
+      ok = (ih | iw) >= 0;
     }
-    if (ih >= hlim || iw >= wlim) return nullptr;
+    ok = ok && ih < hlim && iw < wlim;
     if (g.upsample) {
       ih >>= 1;
       iw >>= 1;
     }
-    return x + (long)(boff[i] + ih * g.W + iw) * g.ldx + c;
+    return ok ? (long)(boff[i] + ih * g.W + iw) * g.ldx : 0;
   }
-  __device__ void load(int k0, f32x4* v) const {
+  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
     int k = k0 + S::kq4();
     if (VEC == 4) {
-      int tap = k / g.C, c = k - tap * g.C;
-      int r = tap / g.KW, s = tap - r * g.KW;
       bool kok = k < kend;
+      int kk = kok ? k : 0;
+      int tap = fdC.div(kk), c = kk - tap * g.C;
+      int r = fdKW.div(tap), s = tap - r * g.KW;
+      mask = 0;
 #pragma unroll
       for (int i = 0; i < S::NS; ++i) {
-        const float* p = kok ? addr(i, r, s, c) : nullptr;
-        v[i] = p ? ldg4(p) : zero4();
+        bool ok;
+        long off = pix(i, r, s, ok);
+        ok = ok && kok && ((rowmask >> i) & 1u);
+        v[i] = ldg4(x + (ok ? off + c : 0));
+        mask |= (unsigned)ok << i;
       }
     } else {
+      mask = rowmask;
 #pragma unroll
       for (int i = 0; i < S::NS; ++i) {
         f32x4 t = zero4();
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
           int ke = k + e;
-          if (ke < kend) {
-            int tap = ke / g.C, c = ke - tap * g.C;
-            int r = tap / g.KW, s = tap - r * g.KW;
-            const float* p = addr(i, r, s, c);
-            if (p) t[e] = *p;
-          }
+          bool kok = ke < kend;
+          int kk = kok ? ke : 0;
+          int tap = fdC.div(kk), c = kk - tap * g.C;
+          int r = fdKW.div(tap), s = tap - r * g.KW;
+          bool ok;
+          long off = pix(i, r, s, ok);
+          ok = ok && kok;
+          float val = x[ok ? off + c : 0];
+          t[e] = ok ? val : 0.f;
         }
         v[i] = t;
       }
@@ -244,27 +288,27 @@ template <int ROWS>
 struct LoadWDgrad : MCSlots<ROWS> {
   using S = MCSlots<ROWS>;
   const float* base;
-  int Cout, taps, ncols, kend;
-  bool cok;
-  __device__ void init(const float* w, const gad_conv_geom& g, int col0, int ncols_, int kend_) {
-    Cout = g.C;
-    taps = g.KH * g.KW;
+  FastDiv fdC;
+  int Cout, taps, ncols, kend, c0;
+  __device__ void init(const float* w, const DevArgs& p, int col0, int ncols_, int kend_) {
+    base = w;
+    fdC = p.fdC;
+    Cout = p.g.C;
+    taps = p.g.KH * p.g.KW;
     ncols = ncols_;
     kend = kend_;
-    int c = col0 + S::rq4();
-    cok = c < ncols;
-    base = w + c;
+    c0 = col0 + S::rq4();
   }
-  __device__ void load(int k0, f32x4* v) const {
+  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+    mask = 0;
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) {
       int k = k0 + S::krow(i);
-      if (cok && k < kend) {
-        int tap = k / Cout, co = k - tap * Cout;
-        v[i] = ldg4(base + ((long)co * taps + tap) * ncols);
-      } else {
-        v[i] = zero4();
-      }
+      bool ok = k < kend && c0 < ncols;
+      int kk = ok ? k : 0;
+      int tap = fdC.div(kk), co = kk - tap * Cout;
+      v[i] = ldg4(base + (ok ? ((long)co * taps + tap) * ncols + c0 : 0));
+      mask |= (unsigned)ok << i;
     }
   }
 };
@@ -273,51 +317,60 @@ struct LoadWDgrad : MCSlots<ROWS> {
 template <int ROWS, int VEC>
 struct LoadConvCols : MCSlots<ROWS> {
   using S = MCSlots<ROWS>;
+  static constexpr int NE = VEC == 4 ? 1 : 4;
   const float* x;
   gad_conv_geom g;
-  int r[VEC == 4 ? 1 : 4], s[VEC == 4 ? 1 : 4], c[VEC == 4 ? 1 : 4];
-  bool nok[VEC == 4 ? 1 : 4];
+  FastDiv fdHoWo, fdWo;
+  int r[NE], s[NE], c[NE];
+  bool nok[NE];
   int kend, hlim, wlim;
-  __device__ void init(const float* x_, const gad_conv_geom& g_, int col0, int ncols, int kend_) {
+  __device__ void init(const float* x_, const DevArgs& p, int col0, int ncols, int kend_) {
     x = x_;
-    g = g_;
+    g = p.g;
+    fdHoWo = p.fdHoWo;
+    fdWo = p.fdWo;
     kend = kend_;
     hlim = g.upsample ? 2 * g.H : g.H;
     wlim = g.upsample ? 2 * g.W : g.W;
     int n = col0 + S::rq4();
 #pragma unroll
-    for (int e = 0; e < (VEC == 4 ? 1 : 4); ++e) {
+    for (int e = 0; e < NE; ++e) {
       int ne = n + e;
       nok[e] = ne < ncols;
-      int tap = ne / g.C;
-      c[e] = ne - tap * g.C;
-      r[e] = tap / g.KW;
+      int nn = nok[e] ? ne : 0;
+      int tap = p.fdC.div(nn);
+      c[e] = nn - tap * g.C;
+      r[e] = p.fdKW.div(tap);
       s[e] = tap - r[e] * g.KW;
     }
   }
-  __device__ void load(int k0, f32x4* v) const {
+  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+    mask = 0;
     int hw = g.Ho * g.Wo;
 #pragma unroll
     for (int i = 0; i < S::NS; ++i) {
       int m = k0 + S::krow(i);
+      bool mok = m < kend;
+      int mm = mok ? m : 0;
+      int img = fdHoWo.div(mm), rem = mm - img * hw;
+      int oh = fdWo.div(rem), ow = rem - oh * g.Wo;
       f32x4 t = zero4();
-      if (m < kend) {
-        int img = m / hw, rem = m - img * hw;
-        int oh = rem / g.Wo, ow = rem - oh * g.Wo;
 #pragma unroll
-        for (int e = 0; e < (VEC == 4 ? 1 : 4); ++e) {
-          int ih = oh * g.stride - g.pad_t + r[e], iw = ow * g.stride - g.pad_l + s[e];
-          if (nok[e] && ih >= 0 && iw >= 0 && ih < hlim && iw < wlim) {
-            if (g.upsample) {
-              ih >>= 1;
-              iw >>= 1;
-            }
-            const float* p = x + (long)(img * g.H * g.W + ih * g.W + iw) * g.ldx + c[e];
-            if (VEC == 4)
-              t = ldg4(p);
-            else
-              t[e] = *p;
-          }
+      for (int e = 0; e < NE; ++e) {
+        int ih = oh * g.stride - g.pad_t + r[e], iw = ow * g.stride - g.pad_l + s[e];
+        bool ok = mok && nok[e] && (ih | iw) >= 0 && ih < hlim && iw < wlim;
+        if (g.upsample) {
+          ih >>= 1;
+          iw >>= 1;
+        }
+        long off = ok ? (long)(img * g.H * g.W + ih * g.W + iw) * g.ldx + c[e] : 0;
+        if (VEC == 4) {
+          t = ldg4(x + off);
+          mask |= (unsigned)ok << i;
+        } else {
+          float val = x[off];
+          t[e] = ok ? val : 0.f;
+          mask |= 1u << i;
         }
       }
       v[i] = t;
@@ -340,12 +393,12 @@ struct ALoader<GAD_A_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
 template <int ROWS, int VEC>
 struct ALoader<GAD_A_CONV, ROWS, VEC> : LoadConvRows<ROWS, false, VEC> {
   static constexpr bool KC = true;
-  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.g, row0, p.M, kend); }
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p, row0, p.M, kend); }
 };
 template <int ROWS, int VEC>
 struct ALoader<GAD_A_CONVT, ROWS, VEC> : LoadConvRows<ROWS, true, VEC> {
   static constexpr bool KC = true;
-  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.g, row0, p.M, kend); }
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p, row0, p.M, kend); }
 };
 
 template <int MODE, int ROWS, int VEC>
@@ -363,12 +416,12 @@ struct BLoader<GAD_B_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
 template <int ROWS, int VEC>
 struct BLoader<GAD_B_WDGRAD, ROWS, VEC> : LoadWDgrad<ROWS> {
   static constexpr bool KC = false;
-  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.g, col0, p.N, kend); }
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p, col0, p.N, kend); }
 };
 template <int ROWS, int VEC>
 struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
   static constexpr bool KC = false;
-  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.g, col0, p.N, kend); }
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p, col0, p.N, kend); }
 };
 
 // ------------------------------------------------------------------------------------
@@ -428,11 +481,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
   f32x4 ra[AL::NS], rb[BL::NS];
+  unsigned ma = 0, mb = 0;
   if (nkt > 0) {
-    al.load(kbeg, ra);
-    bl.load(kbeg, rb);
-    AL::store(lds, ra);
-    BL::store(lds + A_TILE, rb);
+    al.load(kbeg, ra, ma);
+    bl.load(kbeg, rb, mb);
+    AL::store(lds, ra, ma);
+    BL::store(lds + A_TILE, rb, mb);
   }
   __syncthreads();
 
@@ -441,8 +495,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
     const float* lb = la + A_TILE;
     const bool more = kt + 1 < nkt;
     if (more) {
-      al.load(kbeg + (kt + 1) * BK, ra);
-      bl.load(kbeg + (kt + 1) * BK, rb);
+      al.load(kbeg + (kt + 1) * BK, ra, ma);
+      bl.load(kbeg + (kt + 1) * BK, rb, mb);
     }
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
@@ -461,8 +515,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
     }
     if (more) {
       float* na = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
-      AL::store(na, ra);
-      BL::store(na + A_TILE, rb);
+      AL::store(na, ra, ma);
+      BL::store(na + A_TILE, rb, mb);
     }
     __syncthreads();
   }
@@ -486,7 +540,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
         float v = acc[i][j][e];
         if (direct) {
           v = v * p.alpha + bias;
-          if (p.rowadd) v += p.rowadd[(long)(m / p.rows_per_group) * p.ld_rowadd + n];
+          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
           if (R) v += R[(long)m * p.ldr + n];
         }
         C[(long)m * ldc + n] = v;
@@ -514,6 +568,17 @@ __global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
     if (p.residual) v += p.residual[coff + (long)m * p.ldr + n];
     p.C[coff + (long)m * p.ldc + n] = v;
   }
+}
+
+static FastDiv make_fastdiv(unsigned d) {
+  FastDiv f;
+  if (d == 0) d = 1;
+  unsigned l = 0;
+  while ((1ull << l) < d) ++l;
+  f.shift = l;
+  f.mul = (unsigned)((((1ull << l) - d) << 32) / d + 1);
+  if (d == 1) f.mul = 0;
+  return f;
 }
 
 struct Plan {
@@ -655,6 +720,11 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   d.sA0 = a->strideA0; d.sA1 = a->strideA1; d.sB0 = a->strideB0; d.sB1 = a->strideB1;
   d.sC0 = a->strideC0; d.sC1 = a->strideC1;
   d.g = a->g;
+  d.fdC = make_fastdiv(a->g.C);
+  d.fdKW = make_fastdiv(a->g.KW);
+  d.fdHoWo = make_fastdiv((unsigned)a->g.Ho * a->g.Wo);
+  d.fdWo = make_fastdiv(a->g.Wo);
+  d.fdRpg = make_fastdiv(a->rows_per_group > 0 ? a->rows_per_group : 1);
   d.alpha = a->alpha;
   d.bias = a->bias; d.rowadd = a->rowadd; d.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
   d.ld_rowadd = a->ld_rowadd; d.residual = a->residual; d.ldr = a->ldr;

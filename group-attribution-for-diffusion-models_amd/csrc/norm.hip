@@ -10,6 +10,7 @@
 // The second read of x hits the 256 MiB Infinity Cache for the tensors on this path
 // (<= 67 MB at B=128), so HBM traffic stays near the 8 B/elem algorithmic figure.
 #include "gad_common.h"
+#include "gad_reduce.h"
 
 namespace {
 
@@ -248,20 +249,6 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
   }
 }
 
-__global__ void gn_bwd_param_kernel(const float* __restrict__ part, float* __restrict__ dgamma, float* __restrict__ dbeta,
-                                    int nparts, int C) {
-  int c = blockIdx.x * blockDim.x + threadIdx.x;
-  if (c >= C) return;
-  float A = 0.f, Bx = 0.f;
-  for (int k = 0; k < nparts; ++k) {
-    const float* o = part + ((long)k * C + c) * 2;
-    A += o[0];
-    Bx += o[1];
-  }
-  dbeta[c] = A;
-  dgamma[c] = Bx;
-}
-
 static int check(const gad_groupnorm_args* a, const char* who) {
   GAD_CHECK(a && a->x && a->y && a->gamma && a->beta && a->mean && a->rstd, "%s: null pointer", who);
   GAD_CHECK(a->B > 0 && a->HW > 0 && a->C > 0 && a->G > 0 && a->C % a->G == 0, "%s: bad shape", who);
@@ -276,7 +263,8 @@ static int check(const gad_groupnorm_args* a, const char* who) {
 
 extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
   Geo g = make_geo(a);
-  return (int64_t)a->B * g.nch * a->C * 2 * (int64_t)sizeof(float);  // covers fwd (G<=C) and bwd
+  int64_t parts = (int64_t)a->B * g.nch * a->C * 2 * (int64_t)sizeof(float);  // covers fwd (G<=C) and bwd
+  return parts + gad_reduce::ws_bytes(1, (long)a->B * g.nch, 2 * a->C);       // + dgamma/dbeta reduction
 }
 
 extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream) {
@@ -301,7 +289,9 @@ extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream)
   GAD_LAUNCH_CHECK("gn_bwd_stats");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a->x, a->dy, a->y, a->gamma, a->beta, a->mean, a->rstd, (const float*)a->ws, g, a->silu);
   GAD_LAUNCH_CHECK("gn_bwd_apply");
-  hipLaunchKernelGGL(gn_bwd_param_kernel, dim3((a->C + 255) / 256), dim3(256), 0, st, (const float*)a->ws, a->dgamma, a->dbeta, a->B * g.nch, a->C);
+  // dbeta[c] = sum parts[.][c][0], dgamma[c] = sum parts[.][c][1]: a column sum of the [B*nch][2C] partials
+  float* ws2 = (float*)a->ws + (long)a->B * g.nch * a->C * 2;
+  gad_reduce::launch((const float*)a->ws, a->dbeta, a->dgamma, 1, (long)a->B * g.nch, 2 * a->C, ws2, st);
   GAD_LAUNCH_CHECK("gn_bwd_param");
   return 0;
 }
