@@ -19,6 +19,8 @@
 //     operands so any A/B layout pair composes;
 //   * 1-D grid with an XCD-aware bijective remap so that tiles sharing an A panel sit
 //     on one XCD's L2; split-K through a caller-owned workspace + deterministic reduce.
+#include <stdlib.h>
+
 #include "gad_common.h"
 
 namespace {
@@ -243,22 +245,32 @@ struct LoadConvRows : KCSlots<ROWS> {
     }
     return ok ? (long)(boff[i] + ih * g.W + iw) * g.ldx : 0;
   }
-  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+  // per-tap cache: the pixel offsets of this thread's rows only change when the K step moves to
+  // the next filter tap (every C/32 steps), so the bounds logic runs once per tap, not per step
+  int cur_tap = -1;
+  unsigned tapmask = 0;
+  long toff[S::NS];
+  __device__ void load(int k0, f32x4* v, unsigned& mask) {
     int k = k0 + S::kq4();
     if (VEC == 4) {
       bool kok = k < kend;
       int kk = kok ? k : 0;
       int tap = fdC.div(kk), c = kk - tap * g.C;
-      int r = fdKW.div(tap), s = tap - r * g.KW;
-      mask = 0;
+      if (tap != cur_tap) {
+        cur_tap = tap;
+        int r = fdKW.div(tap), s = tap - r * g.KW;
+        tapmask = 0;
 #pragma unroll
-      for (int i = 0; i < S::NS; ++i) {
-        bool ok;
-        long off = pix(i, r, s, ok);
-        ok = ok && kok && ((rowmask >> i) & 1u);
-        v[i] = ldg4(x + (ok ? off + c : 0));
-        mask |= (unsigned)ok << i;
+        for (int i = 0; i < S::NS; ++i) {
+          bool ok;
+          toff[i] = pix(i, r, s, ok);
+          tapmask |= (unsigned)ok << i;
+        }
+        tapmask &= rowmask;
       }
+      mask = kok ? tapmask : 0u;
+#pragma unroll
+      for (int i = 0; i < S::NS; ++i) v[i] = ldg4(x + (((mask >> i) & 1u) ? toff[i] + c : 0));
     } else {
       mask = rowmask;
 #pragma unroll
@@ -586,31 +598,48 @@ struct Plan {
   long nblocks;
 };
 
+// Tile / split-K choice by a small analytic cost model (cycles at ~2 GHz), calibrated on the MI355X
+// sweep in tools/sweep_conv.py: a CU holds 2 (128x128) or 4 (64x64) workgroups whose waves share each
+// SIMD's matrix pipe; one K step costs conc*mfma + X cycles (X = load/barrier time that is not hidden);
+// split-K adds a reduction pass over (sk+1)*M*N floats.
 static Plan make_plan(const gad_gemm_args* a) {
-  Plan pl;
-  long batch = a->batch > 0 ? a->batch : 1;
-  long t128 = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, 128) * batch;
-  int bm = (t128 >= 512) ? 128 : 64;
-  if (a->tile_hint == 1) bm = 128;
-  if (a->tile_hint == 2) bm = 64;
-  pl.bm = bm;
-  pl.tiles_m = (int)gad_ceil_div(a->M, bm);
-  pl.tiles_n = (int)gad_ceil_div(a->N, bm);
-  long tiles = (long)pl.tiles_m * pl.tiles_n * batch;
-  int kt = (int)gad_ceil_div(a->K, BK);
-  int sk = 1;
-  if (tiles < 384 && kt >= 16) {
-    sk = (int)gad_ceil_div(768, tiles);
-    int maxsk = kt / 8;
-    if (sk > maxsk) sk = maxsk;
-    if (sk > 32) sk = 32;
-    if (sk < 1) sk = 1;
+  const long batch = a->batch > 0 ? a->batch : 1;
+  const int kt = (int)gad_ceil_div(a->K, BK) > 0 ? (int)gad_ceil_div(a->K, BK) : 1;
+  static const int sks[] = {1, 2, 3, 4, 6, 8, 12, 16, 24, 32, 48, 64, 96, 128};
+  double best = 1e30;
+  Plan pl{};
+  for (int bm = 128; bm >= 64; bm -= 64) {
+    if (a->tile_hint == 1 && bm != 128) continue;
+    if (a->tile_hint == 2 && bm != 64) continue;
+    const int cap = bm == 128 ? 2 : 4;
+    const double mfma = bm == 128 ? 4096.0 : 1100.0, X = bm == 128 ? 1200.0 : 600.0, fixed = bm == 128 ? 6000.0 : 3000.0;
+    const long tiles = gad_ceil_div(a->M, bm) * gad_ceil_div(a->N, bm) * batch;
+    for (int sk : sks) {
+      if (a->splitk_hint > 0) sk = a->splitk_hint < kt ? a->splitk_hint : kt;
+      else if (sk > 1 && sk > kt / 4) break;
+      const int per = (int)gad_ceil_div(kt, sk);
+      const int sk_eff = (int)gad_ceil_div(kt, per);
+      const long blocks = tiles * sk_eff;
+      const long slots = 256L * cap;
+      const long rounds = gad_ceil_div(blocks, slots);
+      double occ = (double)(blocks - (rounds - 1) * slots) / 256.0;
+      double conc = occ < 1.0 ? 1.0 : (occ > cap ? cap : occ);
+      conc = (double)(long)(conc + 0.999);
+      double cyc = per * ((rounds - 1) * (cap * mfma + X) + (conc * mfma + X)) + rounds * fixed;
+      double us = cyc / 2000.0;
+      if (sk_eff > 1) us += 4.0 + (double)batch * a->M * a->N * 4.0 * (sk_eff + 1) / 3.0e6;
+      if (us < best) {
+        best = us;
+        pl.bm = bm;
+        pl.tiles_m = (int)gad_ceil_div(a->M, bm);
+        pl.tiles_n = (int)gad_ceil_div(a->N, bm);
+        pl.splitk = sk_eff;
+        pl.ktiles_per_split = per;
+        pl.nblocks = blocks;
+      }
+      if (a->splitk_hint > 0) break;
+    }
   }
-  if (a->splitk_hint > 0) sk = a->splitk_hint;
-  if (sk > kt) sk = kt > 0 ? kt : 1;
-  pl.ktiles_per_split = (int)gad_ceil_div(kt > 0 ? kt : 1, sk);
-  pl.splitk = (int)gad_ceil_div(kt > 0 ? kt : 1, pl.ktiles_per_split);
-  pl.nblocks = tiles * pl.splitk;
   return pl;
 }
 

@@ -148,7 +148,7 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     return y
 
 
-def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False):
+def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0):
     """dy [B,Ho,Wo,Cout] -> dx [B,H,W,Cin] (sums the 2x2 replicas if the conv was upsample-fused)."""
     _req(dy, "conv dy")
     Bn, H, W, Cin = x_shape
@@ -158,7 +158,8 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False)
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     dxe = torch.empty((Bn, He, We, Cin), device=dy.device, dtype=torch.float32)
     g = ConvGeom(Ho, Wo, Cout, Cout, He, We, KH, KW, stride, pad[0], pad[2], 0)
-    gemm_raw(dy, wk, dxe, A_CONVT, B_WDGRAD, Bn * He * We, Cin, KH * KW * Cout, 0, 0, Cin, geom=g)
+    gemm_raw(dy, wk, dxe, A_CONVT, B_WDGRAD, Bn * He * We, Cin, KH * KW * Cout, 0, 0, Cin, geom=g,
+             tile_hint=tile_hint, splitk_hint=splitk_hint)
     if not upsample:
         return dxe
     dx = torch.empty((Bn, H, W, Cin), device=dy.device, dtype=torch.float32)
@@ -166,7 +167,7 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False)
     return dx
 
 
-def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False):
+def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0):
     """dW with the parameter's logical shape [Cout,Cin,KH,KW] and channels_last storage."""
     _req(dy, "conv dy")
     _req(x, "conv x")
@@ -175,7 +176,8 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False):
     _, Ho, Wo, _ = dy.shape
     dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
     g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
-    gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g)
+    gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
+             tile_hint=tile_hint, splitk_hint=splitk_hint)
     return dwk.permute(0, 3, 1, 2)
 
 
