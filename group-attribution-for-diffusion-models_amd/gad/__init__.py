@@ -8,5 +8,8 @@ from .nn import LoRALinearLayer, UNet2DModel  # noqa: F401
 from .pipelines import DDIMPipeline, DDPMPipeline  # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
 from .training import EMAModel, FusedTrainer  # noqa: F401
+from . import coalition  # noqa: F401,E402
+from .coalition import DeviceLoader, antithetic_timesteps, seed_everything  # noqa: F401,E402
 
 __version__ = "0.1.0"
+from .scoring import fid_against_dataset  # noqa: F401,E402

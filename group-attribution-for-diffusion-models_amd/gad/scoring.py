@@ -72,3 +72,21 @@ def compute_features(net: FeatureNet, images: torch.Tensor, batch_size: int, dev
         f = net(images[s:s + batch_size].to(device))
         out[s:s + f.shape[0]] = f.double().cpu().numpy()
     return out
+
+
+_REF_STATS = {}
+
+
+def fid_against_dataset(images01, dataset, device, batch_size=512, feature_dims=2048):
+    """calculate_fid (fid_score.py:23-71) with the training set as the reference distribution (its
+    mu/sigma play the role of the precomputed stats.pkl, :42-58; cached per dataset object)."""
+    net = _REF_STATS.get("net")
+    if net is None:
+        net = FeatureNet(feature_dims).to(device)
+        _REF_STATS["net"] = net
+    key = id(dataset)
+    if key not in _REF_STATS:
+        ref = dataset.device_tensor(device).add_(1).div_(2)
+        _REF_STATS[key] = feature_stats(compute_features(net, ref, max(batch_size, 256), device))
+    mu, sigma = feature_stats(compute_features(net, images01, max(batch_size, 256), device))
+    return frechet_distance(mu, sigma, *_REF_STATS[key])

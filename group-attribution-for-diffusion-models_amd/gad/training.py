@@ -152,3 +152,13 @@ class FusedTrainer:
 
     def grad_norm(self):
         return self._sumsq.sqrt()
+
+    def state_dict(self):
+        """Optimizer state in the flat layout (the `optimizer` entry of ckpt_steps_*.pt, main.py:827-840)."""
+        return {"step": self.step_count, "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu(),
+                "hyper": dict(self.hp)}
+
+    def load_state_dict(self, sd):
+        self.step_count = int(sd["step"])
+        self.m.copy_(sd["exp_avg"].to(self.m.device))
+        self.v.copy_(sd["exp_avg_sq"].to(self.v.device))

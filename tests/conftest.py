@@ -5,7 +5,7 @@ import pytest
 
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 PKG = os.path.join(ROOT, "group-attribution-for-diffusion-models_amd")
-for p in (PKG, ROOT):
+for p in (PKG, ROOT, os.path.join(ROOT, "tests")):
     if p not in sys.path:
         sys.path.insert(0, p)
 os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")   # the value the config fixture was dumped with

@@ -1,0 +1,95 @@
+"""BASELINE config 1 on CPU: CIFAR-20-style DDPM, 2 contributor groups, 4 coalitions, 50 inference
+timesteps through the kept entry points unconditional_generation/main.py and unlearn.py
+(plumbing: directory grammar, checkpoint keys, resume, jsonl schema, aggregation).  The model classes
+are the CPU oracle injected as `backend` - the shipped default backend is the HIP engine."""
+import json
+import os
+import shutil
+
+import numpy as np
+import pytest
+import torch
+
+import oracle_backend as OB
+from src.attributions.methods.datashapley import data_shapley
+from unconditional_generation import main as train_main
+from unconditional_generation import unlearn as unlearn_main
+
+TINY = dict(block_out_channels=[32, 32, 64, 64], norm_num_groups=8)
+
+
+@pytest.fixture()
+def tiny_registry(monkeypatch):
+    from src.ddpm_config import DDPMConfig
+    cfg = {**DDPMConfig.cifar100_config}
+    cfg["unet_config"] = dict(cfg["unet_config"], **TINY)
+    cfg["n_samples"] = 4
+    cfg["training_steps"] = dict(cfg["training_steps"], retrain=2)
+    cfg["sample_freq"] = dict(cfg["sample_freq"], retrain=2)
+    cfg["ckpt_freq"] = dict(cfg["ckpt_freq"], retrain=1)
+    monkeypatch.setattr(DDPMConfig, "cifar100_config", cfg)
+    return cfg
+
+
+@pytest.mark.timeout(600)
+def test_config1_cpu_plumbing(tmp_path, tiny_registry):
+    out = str(tmp_path / "results")
+    db_train, db = str(tmp_path / "train.jsonl"), str(tmp_path / "db.jsonl")
+    # ---- 1. "pre-train" the full model for 2 steps on the 2-group toy set ----
+    a = train_main.parse_args(["--dataset", "toy2", "--method", "retrain", "--outdir", out, "--db", db_train,
+                               "--batch_size", "8", "--num_inference_steps", "50", "--device", "cpu",
+                               "--keep_all_ckpts", "--log_freq", "1"])
+    assert train_main.main(a, backend=OB)
+    mdir = os.path.join(out, "toy2", "retrain", "models", "full")
+    assert sorted(f for f in os.listdir(mdir) if f.startswith("ckpt")) == ["ckpt_steps_00000001.pt", "ckpt_steps_00000002.pt"]
+    ck = torch.load(os.path.join(mdir, "ckpt_steps_00000002.pt"), weights_only=False)
+    assert {"unet", "unet_ema", "optimizer", "lr_scheduler", "remaining_idx", "removed_idx", "total_steps_time"} <= set(ck)
+    assert ck["unet_ema"]["optimization_step"] == 2 and len(ck["remaining_idx"]) == 128
+    assert os.path.exists(os.path.join(out, "toy2", "retrain", "samples", "full", "steps_00000002.png"))
+    assert np.load(os.path.join(mdir, "remaining_idx.npy")).shape == (128,)
+    # resume: nothing left to do, newest checkpoint is picked up by file name
+    assert train_main.main(a, backend=OB)
+    # ---- 2. the "pruned" starting point of sFT (architecture + weights in one file) ----
+    pdir = os.path.join(out, "toy2", "pruned", "models", "pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
+    os.makedirs(pdir)
+    torch.save({"unet": ck["unet"], "unet_config": ck["unet_config"]}, os.path.join(pdir, "ckpt_steps_00000000.pt"))
+    # ---- 3. four Shapley coalitions through unlearn.py ----
+    for seed in range(4):
+        u = unlearn_main.parse_args(["--dataset", "toy2", "--method", "gd", "--removal_dist", "shapley",
+                                     "--removal_seed", str(seed), "--load", mdir, "--outdir", out, "--db", db,
+                                     "--gd_steps", "2", "--n_samples", "8", "--batch_size", "4",
+                                     "--num_inference_steps", "50", "--model_behavior", "global",
+                                     "--exp_name", f"gd_shapley_seed_{seed}", "--device", "cpu"])
+        assert unlearn_main.main(u, backend=OB)
+    rows = [json.loads(l) for l in open(db)]
+    assert len(rows) == 4
+    need = {"dataset", "method", "removal_dist", "removal_seed", "exp_name", "gd_steps", "remaining_idx", "removed_idx",
+            "fid_value", "total_steps_time", "total_sampling_time", "trained_steps", "device", "opt_seed"}
+    for r in rows:
+        assert need <= set(r)
+        assert r["method"] == "gd" and r["gd_steps"] == 2 and np.isfinite(r["fid_value"])
+        assert len(r["remaining_idx"]) == 64 and len(r["removed_idx"]) == 64       # one of the two groups
+    # ---- 4. aggregation exactly as lds.py:203-257,423-430 does it: class masks + data_shapley ----
+    labels = [i // 64 for i in range(128)]
+    X = np.array([[float(c in {labels[i] for i in r["remaining_idx"]}) for c in (0, 1)] for r in rows])
+    y = np.array([r["fid_value"] for r in rows])
+    coef = data_shapley(2, X, y, v1=float(y.mean()) - 1.0, v0=float(y.mean()) + 1.0)
+    assert coef.shape == (2, 1) and np.isfinite(coef).all()
+    assert abs(coef.sum() - (-2.0)) < 1e-8                                           # efficiency: v1 - v0
+
+
+def test_uniform_removal_reproduces_reference_typeerror(tmp_path, tiny_registry):
+    a = train_main.parse_args(["--dataset", "toy2", "--method", "retrain", "--outdir", str(tmp_path), "--removal_dist",
+                               "uniform", "--device", "cpu"])
+    with pytest.raises(TypeError):
+        train_main.main(a, backend=OB)
+
+
+def test_removal_directory_grammar():
+    a = train_main.parse_args(["--dataset", "cifar100", "--method", "retrain"])
+    assert train_main.removal_directory(a) == "full"
+    a = train_main.parse_args(["--dataset", "cifar100", "--method", "retrain", "--removal_dist", "datamodel",
+                               "--datamodel_alpha", "0.25", "--removal_seed", "7"])
+    assert train_main.removal_directory(a) == "datamodel/datamodel_alpha=0.25_seed=7"
+    a = train_main.parse_args(["--dataset", "cifar100", "--method", "retrain", "--removal_dist", "shapley", "--removal_seed", "3"])
+    assert train_main.removal_directory(a) == "shapley/shapley_seed=3"

@@ -1,0 +1,110 @@
+"""GPU tests of the engine around the kernels: fused trainer vs the oracle training step, fused-batch sampler vs
+per-batch pipeline calls, entry points and the sharded coalition runner on the HIP backend."""
+import json
+import os
+
+import numpy as np
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+TINY = dict(block_out_channels=[32, 32, 64, 64], norm_num_groups=8)
+
+
+def _cfg():
+    from src.ddpm_config import DDPMConfig
+    return dict(DDPMConfig.cifar100_config["unet_config"], **TINY), DDPMConfig.cifar100_config["scheduler_config"]
+
+
+def test_fused_trainer_matches_oracle_training_steps():
+    import gad
+    from oracle import diffusers_ref as R
+    ucfg, scfg = _cfg()
+    torch.manual_seed(0)
+    ref = R.UNet2DModel(**ucfg)
+    net = gad.UNet2DModel(**ucfg)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    ema_r = R.EMAModel(ref.parameters())
+    ema_g = gad.EMAModel(net.parameters())
+    for e in (ema_r, ema_g):
+        e.optimization_step = 5000
+    tr = gad.FusedTrainer(net, gad.DDPMScheduler(**scfg), ema_g, lr=1e-4)
+    sch = R.DDPMScheduler(**scfg)
+    g = torch.Generator().manual_seed(1)
+    for i in range(3):
+        x, n = torch.rand(8, 3, 32, 32, generator=g) * 2 - 1, torch.randn(8, 3, 32, 32, generator=g)
+        t = R.antithetic_timesteps(torch.randint(0, 1000, (5,), generator=g), 1000, 8)
+        lr_, gn = R.train_step(ref, opt, ema_r, sch, x, n, t)
+        lg = tr.step(x.to(dev), n.to(dev), t.to(dev))
+        assert abs(lg.item() - lr_.item()) < 1e-4 * max(1.0, abs(lr_.item()))
+        assert abs(tr.grad_norm().item() - gn.item()) < 2e-3 * gn.item()
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        assert torch.allclose(a.cpu(), b, atol=2e-5), k
+    for a, b in zip(ema_g.shadow_params, ema_r.shadow_params):
+        assert torch.allclose(a.cpu(), b, atol=2e-6)
+    assert ema_g.optimization_step == ema_r.optimization_step == 5003
+
+
+def test_fused_sampler_equals_per_batch_pipeline_calls():
+    import gad
+    from gad.coalition import FusedSampler
+    ucfg, _ = _cfg()
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**ucfg).to(dev).eval()
+    sch = gad.DDIMScheduler()
+    fused = FusedSampler(net, sch, batch_size=4, fuse=3).generate(10, 5)          # batches 4,4,2 -> one launch group
+    pipe = gad.DDPMPipeline(net, gad.DDIMScheduler())
+    parts = []
+    for counter, bs in enumerate([4, 4, 2]):
+        im = pipe(batch_size=bs, generator=torch.Generator().manual_seed(counter), num_inference_steps=5,
+                  output_type="numpy").images
+        x = torch.from_numpy(im).permute(0, 3, 1, 2)
+        parts.append(x.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8).float().div_(255))
+    want = torch.cat(parts)
+    got = fused.cpu()
+    assert got.shape == want.shape == (10, 3, 32, 32)
+    # identical per-sample arithmetic; allow one 8-bit level where a value sits on a rounding boundary
+    assert (got - want).abs().max().item() <= 1 / 255 + 1e-6
+    assert ((got - want).abs() > 1e-6).float().mean().item() < 1e-3
+
+
+def test_entry_points_and_sharded_runner_on_gpu(tmp_path, monkeypatch):
+    from src.ddpm_config import DDPMConfig
+    cfg = {**DDPMConfig.cifar100_config}
+    cfg["unet_config"] = dict(cfg["unet_config"], **TINY)
+    cfg["n_samples"] = 4
+    cfg["training_steps"] = dict(cfg["training_steps"], retrain=3)
+    cfg["ckpt_freq"] = dict(cfg["ckpt_freq"], retrain=3)
+    cfg["sample_freq"] = dict(cfg["sample_freq"], retrain=3)
+    monkeypatch.setattr(DDPMConfig, "cifar100_config", cfg)
+    from unconditional_generation import main as train_main
+    from unconditional_generation import unlearn as unlearn_main
+    out, db = str(tmp_path / "res"), str(tmp_path / "db.jsonl")
+    a = train_main.parse_args(["--dataset", "toy2", "--method", "retrain", "--outdir", out, "--batch_size", "16",
+                               "--num_inference_steps", "10", "--log_freq", "1"])
+    assert train_main.main(a)
+    mdir = os.path.join(out, "toy2", "retrain", "models", "full")
+    ck = torch.load(os.path.join(mdir, "ckpt_steps_00000003.pt"), weights_only=False)
+    assert ck["unet"]["conv_in.weight"].shape == (32, 3, 3, 3) and ck["unet_ema"]["optimization_step"] == 3
+    pdir = os.path.join(out, "toy2", "pruned", "models", "pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
+    os.makedirs(pdir)
+    torch.save({"unet": ck["unet"], "unet_config": ck["unet_config"]}, os.path.join(pdir, "ckpt_steps_00000000.pt"))
+    u = unlearn_main.parse_args(["--dataset", "toy2", "--method", "gd", "--removal_dist", "shapley", "--removal_seed", "1",
+                                 "--load", mdir, "--outdir", out, "--db", db, "--gd_steps", "3", "--n_samples", "16",
+                                 "--batch_size", "8", "--num_inference_steps", "10", "--model_behavior", "global"])
+    assert unlearn_main.main(u)
+    row = json.loads(open(db).readline())
+    assert np.isfinite(row["fid_value"]) and len(row["remaining_idx"]) == 64 and row["trained_steps"] == 3
+    # in-process scheduler on the same toy problem
+    from gad.coalition import CoalitionEngine, run_sharded
+    eng = CoalitionEngine("toy2", device=dev, gd_steps=2, n_samples=16, sample_batch=8, fuse=2, num_inference_steps=5,
+                          unet_overrides=TINY, feature_dims=64)
+    db2 = str(tmp_path / "db2.jsonl")
+    recs = run_sharded(eng, [0, 1, 2], db_path=db2)
+    assert [r.removal_seed for r in recs] == [0, 1, 2] and all(np.isfinite(r.fid_value) for r in recs)
+    rows = [json.loads(l) for l in open(db2)]
+    assert [r["removal_seed"] for r in rows] == [0, 1, 2]
+    assert run_sharded(eng, [0, 1, 2], db_path=db2) == []            # idempotent: everything is already in the db
