@@ -9,14 +9,18 @@
 // chip peak), so the result matches a CPU fp32 reference to summation-order noise.
 //
 // Structure (per 256-thread workgroup = 4 waves in a 2x2 arrangement):
-//   * block tile BMxBN (128x128 or 64x64), K step 32, two LDS buffers;
-//   * global -> registers (float4, coalesced along the contiguous dim) for tile t+1 is
-//     issued before the MFMAs of tile t and written to the other LDS buffer after them
-//     (one barrier per K step);
-//   * "KC" tiles ([row][k], k contiguous, row stride 36 floats -> conflict-free
-//     ds_read_b128 of 4 consecutive k) and "MC" tiles ([k][row], ds_read_b32);
-//     the k -> (MFMA step, lane half) assignment is the same permutation for both
-//     operands so any A/B layout pair composes;
+//   * block tile BMxBN (128x128 or 64x64), K step 32, two LDS buffers (64 KB at 128x128 -> 2 blocks/CU);
+//   * staging is LDS-DMA (global_load_lds_dwordx4, 1 KiB per wave-instruction, no VGPR round trip, no
+//     ds_write): each wave-instruction fills 8 tile rows (KC tiles, [row][32 floats]) or 2-4 k-rows (MC
+//     tiles, [k][row]); the DMA of step t+1 is issued slot by slot between the MFMA groups of step t so
+//     its address arithmetic runs in the shadow of the 64-cycle MFMAs; padding / out-of-range lanes read
+//     a 64-byte zero block, so there is no masking and no branch in the K step;
+//   * KC tiles are XOR-swizzled on the SOURCE side (16-B chunk q of row r lives at chunk q^((r>>1)&7)):
+//     the LDS image stays lane-linear for the DMA and ds_read_b128 of 4 consecutive k is conflict-free;
+//     MC tiles are read with ds_read_b32; the k -> (MFMA step, lane half) assignment is the same
+//     permutation for both operands so any A/B layout pair composes;
+//   * operands that cannot be read as aligned float4 (Cin = 3, Cout = 3, odd K) take a register-staged
+//     scalar path (VEC = 1) into the same LDS image;
 //   * 1-D grid with an XCD-aware bijective remap so that tiles sharing an A panel sit
 //     on one XCD's L2; split-K through a caller-owned workspace + deterministic reduce.
 #include <stdlib.h>
@@ -26,8 +30,19 @@
 namespace {
 
 constexpr int BK = 32;
-constexpr int KC_LD = BK + 4;  // 36 floats: 16 distinct 16-B slots for 16 consecutive rows
 constexpr int NTHREADS = 256;
+
+// 64 bytes of zeros in device memory: the DMA source of padding / out-of-range tile slots
+__device__ __attribute__((aligned(64))) float g_zero_block[16];
+
+// physical float offset of logical 16-B chunk q (0..7) of KC-tile row r
+__device__ __forceinline__ int kc_off(int r, int q) { return r * BK + ((q ^ ((r >> 1) & 7)) << 2); }
+
+// LDS-DMA: 64 lanes x 16 B -> LDS [dst, dst + 1 KiB), lane-linear; src is per lane
+__device__ __forceinline__ void glds16(const float* src, float* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, 0);
+}
 
 // division by a launch-invariant divisor: q = (mulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31
 struct FastDiv {
@@ -73,11 +88,15 @@ template <int ROWS>
 struct KCSlots {
   static constexpr int NS = ROWS / 32;
   __device__ static int row(int i) { return (threadIdx.x >> 3) + 32 * i; }
-  __device__ static int kq4() { return (threadIdx.x & 7) * 4; }
-  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {
+  // logical float4 column (k chunk) this lane supplies for its row: the lane's LDS position is fixed by
+  // the DMA (physical chunk = lane & 7), so the swizzle is applied to what it loads
+  // (row(i) >> 1) & 7 == (tid >> 4) & 7 for every slot i, so the column is slot independent
+  __device__ static int kq4() { return ((threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7)) * 4; }
+  __device__ static float* dma_dst(float* tile, int i) { return tile + ((threadIdx.x >> 6) * 8 + 32 * i) * BK; }
+  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
-      *reinterpret_cast<f32x4*>(lds + row(i) * KC_LD + kq4()) = keep_if(v[i], (mask >> i) & 1u);
+      *reinterpret_cast<f32x4*>(lds + row(i) * BK + (threadIdx.x & 7) * 4) = keep_if(v[i], (mask >> i) & 1u);
   }
 };
 template <int ROWS>
@@ -87,21 +106,34 @@ struct MCSlots {
   static constexpr int KSTEP = NTHREADS / F4;
   __device__ static int krow(int i) { return threadIdx.x / F4 + KSTEP * i; }
   __device__ static int rq4() { return (threadIdx.x % F4) * 4; }
-  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {
+  __device__ static float* dma_dst(float* tile, int i) { return tile + ((threadIdx.x >> 6) * (KSTEP / 4) + KSTEP * i) * ROWS; }
+  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
       *reinterpret_cast<f32x4*>(lds + krow(i) * ROWS + rq4()) = keep_if(v[i], (mask >> i) & 1u);
   }
 };
 
-// dense [row][k]   (VEC == 1: scalar loads, any K / leading dimension)
+// Loader protocol: prep(k0) once per K step (shared decode), then per slot i either
+//   src(i)            -> per-lane source address of the float4 (or the zero block)   [VEC == 4, LDS-DMA]
+//   slot(i, v, mask)  -> register-staged scalar gather of the 4 floats               [VEC == 1]
+// both called from between MFMA groups so the address arithmetic sits in the MFMA shadow.
+// branch-free source select: offsets are always computed (possibly from out-of-range coordinates), masked
+// to 0 when invalid and added to either the tensor base or the zero block
+__device__ __forceinline__ const float* sel_src(const float* base, long off, bool ok) {
+  const float* b = ok ? base : (const float*)g_zero_block;
+  return b + (off & -(long)ok);
+}
+
+// dense [row][k]
 template <int ROWS, int VEC>
 struct LoadKCDense : KCSlots<ROWS> {
   using S = KCSlots<ROWS>;
   const float* base;
   long roff[S::NS];
   unsigned rowmask;
-  int kend;
+  int kend, k;
+  bool kok;
   __device__ void init(const float* b, int ld, int row0, int nrows, int kend_) {
     base = b;
     kend = kend_;
@@ -114,37 +146,33 @@ struct LoadKCDense : KCSlots<ROWS> {
       rowmask |= (unsigned)ok << i;
     }
   }
-  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
-    int k = k0 + S::kq4();
-    if (VEC == 4) {
-      bool kok = k < kend;
-      mask = kok ? rowmask : 0u;
-      int kk = kok ? k : 0;
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) {
+    k = k0 + S::kq4();
+    kok = k < kend;
+    mask = rowmask;
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    bool ok = kok && ((rowmask >> i) & 1u);
+    return sel_src(base, roff[i] + k, ok);
+  }
+  __device__ __forceinline__ void slot(int i, f32x4* v, unsigned& mask) const {
+    f32x4 t = zero4();
 #pragma unroll
-      for (int i = 0; i < S::NS; ++i) v[i] = ldg4(base + roff[i] + kk);
-    } else {
-      mask = rowmask;
-#pragma unroll
-      for (int i = 0; i < S::NS; ++i) {
-        f32x4 t = zero4();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bool ok = k + e < kend;
-          float x = base[roff[i] + (ok ? k + e : 0)];
-          t[e] = ok ? x : 0.f;
-        }
-        v[i] = t;
-      }
+    for (int e = 0; e < 4; ++e) {
+      bool ok = k + e < kend;
+      float x = base[roff[i] + (ok ? k + e : 0)];
+      t[e] = ok ? x : 0.f;
     }
+    v[i] = t;
   }
 };
 
-// dense [k][row]   (VEC == 1: scalar loads, any row count / leading dimension)
+// dense [k][row]
 template <int ROWS, int VEC>
 struct LoadMCDense : MCSlots<ROWS> {
   using S = MCSlots<ROWS>;
   const float* base;
-  int ld, kend, c0, nrows;
+  int ld, kend, c0, nrows, k0;
   __device__ void init(const float* b, int ld_, int row0, int nrows_, int kend_) {
     base = b;
     ld = ld_;
@@ -152,29 +180,28 @@ struct LoadMCDense : MCSlots<ROWS> {
     nrows = nrows_;
     c0 = row0 + S::rq4();
   }
-  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+  __device__ __forceinline__ void prep(int k0_, unsigned& mask) {
+    k0 = k0_;
     mask = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    int k = k0 + S::krow(i);
+    bool ok = k < kend && c0 < nrows;
+    return sel_src(base, (long)k * ld + c0, ok);
+  }
+  __device__ __forceinline__ void slot(int i, f32x4* v, unsigned& mask) const {
+    int k = k0 + S::krow(i);
+    bool kok = k < kend;
+    long off = kok ? (long)k * ld : 0;
+    f32x4 t = zero4();
 #pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-      int k = k0 + S::krow(i);
-      bool kok = k < kend;
-      long off = kok ? (long)k * ld : 0;
-      if (VEC == 4) {
-        bool ok = kok && c0 < nrows;
-        v[i] = ldg4(base + off + (ok ? c0 : 0));
-        mask |= (unsigned)ok << i;
-      } else {
-        f32x4 t = zero4();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          bool ok = kok && c0 + e < nrows;
-          float x = base[off + (ok ? c0 + e : 0)];
-          t[e] = ok ? x : 0.f;
-        }
-        v[i] = t;
-        mask |= 1u << i;
-      }
+    for (int e = 0; e < 4; ++e) {
+      bool ok = kok && c0 + e < nrows;
+      float x = base[off + (ok ? c0 + e : 0)];
+      t[e] = ok ? x : 0.f;
     }
+    v[i] = t;
+    mask |= 1u << i;
   }
 };
 
@@ -189,6 +216,8 @@ struct LoadConvRows : KCSlots<ROWS> {
   int bh[S::NS], bw[S::NS], boff[S::NS];  // per row: base h, base w, image pixel offset
   unsigned rowmask;
   int kend, hlim, wlim;
+  int k, c, r, s;   // decode of the current K step (prep)
+  bool kok;
   __device__ void init(const float* x_, const DevArgs& p, int row0, int nrows, int kend_) {
     x = x_;
     g = p.g;
@@ -216,11 +245,11 @@ struct LoadConvRows : KCSlots<ROWS> {
       }
     }
   }
-  // pixel offset (in floats, without the channel) of slot i for tap (r,s); ok=false if out of range
-  __device__ __forceinline__ long pix(int i, int r, int s, bool& ok) const {
+  // element offset of slot i's pixel for tap (rr,ss); computed unconditionally, `ok` says if it is real
+  __device__ __forceinline__ long pix(int i, int rr, int ss, bool& ok) const {
     int ih, iw;
     if (TRANSPOSED) {
-      int nh = bh[i] - r, nw = bw[i] - s;
+      int nh = bh[i] - rr, nw = bw[i] - ss;
       ok = (nh | nw) >= 0;
       if (g.stride == 2) {
         ok = ok && !((nh | nw) & 1);
@@ -234,8 +263,8 @@ struct LoadConvRows : KCSlots<ROWS> {
       ih = nh;
       iw = nw;
     } else {
-      ih = bh[i] + r;
-      iw = bw[i] + s;
+      ih = bh[i] + rr;
+      iw = bw[i] + ss;
       ok = (ih | iw) >= 0;
     }
     ok = ok && ih < hlim && iw < wlim;
@@ -243,65 +272,50 @@ struct LoadConvRows : KCSlots<ROWS> {
       ih >>= 1;
       iw >>= 1;
     }
-    return ok ? (long)(boff[i] + ih * g.W + iw) * g.ldx : 0;
+    return (long)(boff[i] + ih * g.W + iw) * g.ldx;
   }
-  // per-tap cache: the pixel offsets of this thread's rows only change when the K step moves to
-  // the next filter tap (every C/32 steps), so the bounds logic runs once per tap, not per step
-  int cur_tap = -1;
-  unsigned tapmask = 0;
-  long toff[S::NS];
-  __device__ void load(int k0, f32x4* v, unsigned& mask) {
-    int k = k0 + S::kq4();
-    if (VEC == 4) {
-      bool kok = k < kend;
-      int kk = kok ? k : 0;
-      int tap = fdC.div(kk), c = kk - tap * g.C;
-      if (tap != cur_tap) {
-        cur_tap = tap;
-        int r = fdKW.div(tap), s = tap - r * g.KW;
-        tapmask = 0;
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) {
+    k = k0 + S::kq4();
+    kok = k < kend;
+    int kk = kok ? k : 0;
+    int tap = fdC.div(kk);
+    c = kk - tap * g.C;
+    r = fdKW.div(tap);
+    s = tap - r * g.KW;
+    mask = rowmask;
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    bool ok;
+    long off = pix(i, r, s, ok) + c;
+    ok = ok && kok && ((rowmask >> i) & 1u);
+    return sel_src(x, off, ok);
+  }
+  __device__ __forceinline__ void slot(int i, f32x4* v, unsigned& mask) const {
+    f32x4 t = zero4();
 #pragma unroll
-        for (int i = 0; i < S::NS; ++i) {
-          bool ok;
-          toff[i] = pix(i, r, s, ok);
-          tapmask |= (unsigned)ok << i;
-        }
-        tapmask &= rowmask;
-      }
-      mask = kok ? tapmask : 0u;
-#pragma unroll
-      for (int i = 0; i < S::NS; ++i) v[i] = ldg4(x + (((mask >> i) & 1u) ? toff[i] + c : 0));
-    } else {
-      mask = rowmask;
-#pragma unroll
-      for (int i = 0; i < S::NS; ++i) {
-        f32x4 t = zero4();
-#pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          int ke = k + e;
-          bool kok = ke < kend;
-          int kk = kok ? ke : 0;
-          int tap = fdC.div(kk), c = kk - tap * g.C;
-          int r = fdKW.div(tap), s = tap - r * g.KW;
-          bool ok;
-          long off = pix(i, r, s, ok);
-          ok = ok && kok;
-          float val = x[ok ? off + c : 0];
-          t[e] = ok ? val : 0.f;
-        }
-        v[i] = t;
-      }
+    for (int e = 0; e < 4; ++e) {
+      int ke = k + e;
+      bool ko = ke < kend;
+      int kk = ko ? ke : 0;
+      int tap = fdC.div(kk), cc = kk - tap * g.C;
+      int rr = fdKW.div(tap), ss = tap - rr * g.KW;
+      bool ok;
+      long off = pix(i, rr, ss, ok) + cc;
+      ok = ok && ko;
+      float val = x[off & -(long)ok];
+      t[e] = ok ? val : 0.f;
     }
+    v[i] = t;
   }
 };
 
 // conv weight W[co][tap][ci] read as B[k = tap*Cout + co][n = ci]   (MC-type)
-template <int ROWS>
+template <int ROWS, int VEC>
 struct LoadWDgrad : MCSlots<ROWS> {
   using S = MCSlots<ROWS>;
   const float* base;
   FastDiv fdC;
-  int Cout, taps, ncols, kend, c0;
+  int Cout, taps, ncols, kend, c0, k0;
   __device__ void init(const float* w, const DevArgs& p, int col0, int ncols_, int kend_) {
     base = w;
     fdC = p.fdC;
@@ -311,17 +325,20 @@ struct LoadWDgrad : MCSlots<ROWS> {
     kend = kend_;
     c0 = col0 + S::rq4();
   }
-  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+  __device__ __forceinline__ void prep(int k0_, unsigned& mask) {
+    k0 = k0_;
     mask = 0;
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-      int k = k0 + S::krow(i);
-      bool ok = k < kend && c0 < ncols;
-      int kk = ok ? k : 0;
-      int tap = fdC.div(kk), co = kk - tap * Cout;
-      v[i] = ldg4(base + (ok ? ((long)co * taps + tap) * ncols + c0 : 0));
-      mask |= (unsigned)ok << i;
-    }
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    int k = k0 + S::krow(i);
+    bool ok = k < kend && c0 < ncols;
+    int kk = ok ? k : 0;
+    int tap = fdC.div(kk), co = kk - tap * Cout;
+    return sel_src(base, ((long)co * taps + tap) * ncols + c0, ok);
+  }
+  __device__ __forceinline__ void slot(int i, f32x4* v, unsigned& mask) const {   // N % 4 == 0 is required
+    v[i] = ldg4(src(i));
+    mask |= 1u << i;
   }
 };
 
@@ -335,7 +352,7 @@ struct LoadConvCols : MCSlots<ROWS> {
   FastDiv fdHoWo, fdWo;
   int r[NE], s[NE], c[NE];
   bool nok[NE];
-  int kend, hlim, wlim;
+  int kend, hlim, wlim, k0;
   __device__ void init(const float* x_, const DevArgs& p, int col0, int ncols, int kend_) {
     x = x_;
     g = p.g;
@@ -356,37 +373,40 @@ struct LoadConvCols : MCSlots<ROWS> {
       s[e] = tap - r[e] * g.KW;
     }
   }
-  __device__ void load(int k0, f32x4* v, unsigned& mask) const {
+  __device__ __forceinline__ void prep(int k0_, unsigned& mask) {
+    k0 = k0_;
     mask = 0;
-    int hw = g.Ho * g.Wo;
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-      int m = k0 + S::krow(i);
-      bool mok = m < kend;
-      int mm = mok ? m : 0;
-      int img = fdHoWo.div(mm), rem = mm - img * hw;
-      int oh = fdWo.div(rem), ow = rem - oh * g.Wo;
-      f32x4 t = zero4();
-#pragma unroll
-      for (int e = 0; e < NE; ++e) {
-        int ih = oh * g.stride - g.pad_t + r[e], iw = ow * g.stride - g.pad_l + s[e];
-        bool ok = mok && nok[e] && (ih | iw) >= 0 && ih < hlim && iw < wlim;
-        if (g.upsample) {
-          ih >>= 1;
-          iw >>= 1;
-        }
-        long off = ok ? (long)(img * g.H * g.W + ih * g.W + iw) * g.ldx + c[e] : 0;
-        if (VEC == 4) {
-          t = ldg4(x + off);
-          mask |= (unsigned)ok << i;
-        } else {
-          float val = x[off];
-          t[e] = ok ? val : 0.f;
-          mask |= 1u << i;
-        }
-      }
-      v[i] = t;
+  }
+  __device__ __forceinline__ long off_of(int i, int e, bool& ok) const {
+    int m = k0 + S::krow(i);
+    bool mok = m < kend;
+    int mm = mok ? m : 0;
+    int img = fdHoWo.div(mm), rem = mm - img * (g.Ho * g.Wo);
+    int oh = fdWo.div(rem), ow = rem - oh * g.Wo;
+    int ih = oh * g.stride - g.pad_t + r[e], iw = ow * g.stride - g.pad_l + s[e];
+    ok = mok && nok[e] && (ih | iw) >= 0 && ih < hlim && iw < wlim;
+    if (g.upsample) {
+      ih >>= 1;
+      iw >>= 1;
     }
+    return (long)(img * g.H * g.W + ih * g.W + iw) * g.ldx + c[e];
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    bool ok;
+    long off = off_of(i, 0, ok);
+    return sel_src(x, off, ok);
+  }
+  __device__ __forceinline__ void slot(int i, f32x4* v, unsigned& mask) const {
+    f32x4 t = zero4();
+#pragma unroll
+    for (int e = 0; e < NE; ++e) {
+      bool ok;
+      long off = off_of(i, e, ok);
+      float val = x[off & -(long)ok];
+      t[e] = ok ? val : 0.f;
+    }
+    v[i] = t;
+    mask |= 1u << i;
   }
 };
 
@@ -426,7 +446,7 @@ struct BLoader<GAD_B_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
   __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
 };
 template <int ROWS, int VEC>
-struct BLoader<GAD_B_WDGRAD, ROWS, VEC> : LoadWDgrad<ROWS> {
+struct BLoader<GAD_B_WDGRAD, ROWS, VEC> : LoadWDgrad<ROWS, VEC> {
   static constexpr bool KC = false;
   __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p, col0, p.N, kend); }
 };
@@ -443,7 +463,7 @@ struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
 template <bool KC, int ROWS>
 __device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int g, int h) {
   if (KC) {
-    return *reinterpret_cast<const f32x4*>(lds + row * KC_LD + 8 * g + 4 * h);
+    return *reinterpret_cast<const f32x4*>(lds + kc_off(row, 2 * g + h));
   } else {
     const float* p = lds + (8 * g + 4 * h) * ROWS + row;
     return f32x4{p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]};
@@ -455,8 +475,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   using AL = ALoader<AM, BM, VEC>;
   using BL = BLoader<BMODE, BN, VEC>;
-  constexpr int A_TILE = AL::KC ? BM * KC_LD : BK * BM;
-  constexpr int B_TILE = BL::KC ? BN * KC_LD : BK * BN;
+  constexpr int A_TILE = BK * BM;
+  constexpr int B_TILE = BK * BN;
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
 
   // ---- block -> (batch z, split, tile_m, tile_n), XCD-aware (bijective) ----
@@ -475,7 +495,6 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   int kbeg = split * p.ktiles_per_split * BK;
   int kend = min(p.K, kbeg + p.ktiles_per_split * BK);
   int nkt = (kend - kbeg + BK - 1) / BK;
-
   AL al;
   BL bl;
   al.setup(p, A, row0, kend);
@@ -492,45 +511,81 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
 
-  f32x4 ra[AL::NS], rb[BL::NS];
+  // stage(tile buffers, k0): bring the K step starting at k0 into LDS.  VEC==4: one DMA per slot;
+  // VEC==1: scalar gathers into registers (ra/rb), written to LDS by stage_commit().
+  f32x4 ra[VEC == 4 ? 1 : AL::NS], rb[VEC == 4 ? 1 : BL::NS];
   unsigned ma = 0, mb = 0;
-  if (nkt > 0) {
-    al.load(kbeg, ra, ma);
-    bl.load(kbeg, rb, mb);
-    AL::store(lds, ra, ma);
-    BL::store(lds + A_TILE, rb, mb);
-  }
-  __syncthreads();
-
-  for (int kt = 0; kt < nkt; ++kt) {
-    const float* la = lds + (kt & 1) * (A_TILE + B_TILE);
-    const float* lb = la + A_TILE;
-    const bool more = kt + 1 < nkt;
-    if (more) {
-      al.load(kbeg + (kt + 1) * BK, ra, ma);
-      bl.load(kbeg + (kt + 1) * BK, rb, mb);
+  auto stage_slot = [&](int piece, float* ta, float* tb) {
+    constexpr int NSA = AL::NS, NSB = BL::NS;
+    if (piece < NSA) {
+      if (VEC == 4) glds16(al.src(piece), AL::dma_dst(ta, piece));
+      else al.slot(piece, ra, ma);
+    } else if (piece < NSA + NSB) {
+      if (VEC == 4) glds16(bl.src(piece - NSA), BL::dma_dst(tb, piece - NSA));
+      else bl.slot(piece - NSA, rb, mb);
     }
+  };
+  auto stage_commit = [&](float* ta, float* tb) {
+    if (VEC != 4) {
+      AL::store(ta, ra, ma);
+      BL::store(tb, rb, mb);
+    }
+  };
+  if (nkt > 0) {
+    al.prep(kbeg, ma);
+    bl.prep(kbeg, mb);
+#pragma unroll
+    for (int q = 0; q < AL::NS + BL::NS; ++q) stage_slot(q, lds, lds + A_TILE);
+    stage_commit(lds, lds + A_TILE);
+  }
+  __syncthreads();   // (with DMA in flight hipcc's barrier also waits vmcnt(0))
+
+  // One K step = 16 "pieces" of TM*TN MFMAs (4 fragment groups x 4 MFMA steps).  The staging of step
+  // kt+1 (into the other buffer, last read before the previous barrier) is issued one slot per piece
+  // from the first pieces on - unconditional: past the end it fetches the zero block - pinned there by
+  // sched_barrier so its address VALU runs in the shadow of the 64-cycle MFMAs; the fragments of
+  // group g+1 are read during group g.
+  for (int kt = 0; kt < nkt; ++kt) {
+    float* cur = lds + (kt & 1) * (A_TILE + B_TILE);
+    float* nxt = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
+    const float* la = cur;
+    const float* lb = cur + A_TILE;
+    const int knext = kbeg + (kt + 1) * BK;   // past the end: k >= kend, every slot reads zeros
+    al.prep(knext, ma);
+    bl.prep(knext, mb);
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<AL::KC, BM>(la, wm * (BM / 2) + i * 32 + l31, 0, h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
-      f32x4 fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i) fa[i] = read_frag<AL::KC, BM>(la, wm * (BM / 2) + i * 32 + l31, g, h);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, g, h);
-#pragma unroll
-      for (int s = 0; s < 4; ++s)
+      for (int s = 0; s < 4; ++s) {
 #pragma unroll
         for (int i = 0; i < TM; ++i)
 #pragma unroll
           for (int j = 0; j < TN; ++j)
-            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[i][s], fb[j][s], acc[i][j], 0, 0, 0);
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
+        stage_slot(g * 4 + s, nxt, nxt + A_TILE);
+        if (s == 1 && g < 3) {   // prefetch the next group's fragments into the other register set
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = read_frag<AL::KC, BM>(la, wm * (BM / 2) + i * 32 + l31, g + 1, h);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+        }
+        // within the piece: alternate 1 MFMA with <= 7 VALU so the staging arithmetic never holds back
+        // the next MFMA by more than its 64-cycle shadow
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
     }
-    if (more) {
-      float* na = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
-      AL::store(na, ra, ma);
-      BL::store(na + A_TILE, rb, mb);
-    }
-    __syncthreads();
+    stage_commit(nxt, nxt + A_TILE);
+    __syncthreads();   // all DMA of step kt+1 landed (vmcnt(0)) and every wave is done reading `cur`
   }
 
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
