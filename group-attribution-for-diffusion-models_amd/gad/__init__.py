@@ -13,3 +13,4 @@ from .coalition import DeviceLoader, antithetic_timesteps, seed_everything  # no
 
 __version__ = "0.1.0"
 from .scoring import fid_against_dataset  # noqa: F401,E402
+from .sd import UNet2DConditionModel  # noqa: F401,E402

@@ -68,6 +68,11 @@ SIGNATURES = {
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_softmax_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "gad_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gad_layernorm_workspace_bytes": (_i64, [_i64, _i32]),
+    "gad_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "gad_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "gad_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "gad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
     "gad_silu_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gad_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

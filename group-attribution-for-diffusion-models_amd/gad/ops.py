@@ -534,3 +534,66 @@ def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weigh
 
 def ema_update_raw(ema, p, decay: float):
     check(_capi.load().gad_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), decay, _stream()), "gad_ema_update")
+
+
+# ----------------------------------------------------------------------------------
+# transformer-block operators (UNet2DConditionModel)
+# ----------------------------------------------------------------------------------
+class LayerNormFn(torch.autograd.Function):
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        _req(x, "layernorm x")
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        y = torch.empty_like(x)
+        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        check(_capi.load().gad_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
+                                             mean.data_ptr(), rstd.data_ptr(), rows, C_, eps, _stream()), "gad_layernorm_fwd")
+        ctx.save_for_backward(x, gamma, mean, rstd)
+        return y
+
+    @staticmethod
+    def backward(ctx, dy):
+        x, gamma, mean, rstd = ctx.saved_tensors
+        dy = dy.contiguous()
+        C_ = x.shape[-1]
+        rows = x.numel() // C_
+        dx = torch.empty_like(x)
+        dgb = torch.empty(2 * C_, device=x.device, dtype=torch.float32)
+        ws = workspace(x.device)
+        check(_capi.load().gad_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
+                                             rstd.data_ptr(), dgb.data_ptr(), rows, C_, ws.data_ptr(), ws.numel(),
+                                             _stream()), "gad_layernorm_bwd")
+        return dx, dgb[:C_], dgb[C_:], None
+
+
+def layer_norm(x, gamma, beta, eps=1e-5):
+    return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+class GegluFn(torch.autograd.Function):
+    """out = h[..., :F] * gelu(h[..., F:])  (diffusers GEGLU after its projection)."""
+
+    @staticmethod
+    def forward(ctx, h):
+        _req(h, "geglu h")
+        F2 = h.shape[-1]
+        out = torch.empty((*h.shape[:-1], F2 // 2), device=h.device, dtype=torch.float32)
+        check(_capi.load().gad_geglu_fwd(h.data_ptr(), out.data_ptr(), h.numel() // F2, F2 // 2, _stream()), "gad_geglu_fwd")
+        ctx.save_for_backward(h)
+        return out
+
+    @staticmethod
+    def backward(ctx, dout):
+        (h,) = ctx.saved_tensors
+        dout = dout.contiguous()
+        F2 = h.shape[-1]
+        dh = torch.empty_like(h)
+        check(_capi.load().gad_geglu_bwd(h.data_ptr(), dout.data_ptr(), dh.data_ptr(), h.numel() // F2, F2 // 2, _stream()),
+              "gad_geglu_bwd")
+        return dh
+
+
+def geglu(h):
+    return GegluFn.apply(h)

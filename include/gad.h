@@ -131,6 +131,20 @@ int gad_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, in
                     void* stream);
 
 /* ------------------------------------------------------------------------------
+ * Transformer-block pieces of UNet2DConditionModel (Stable Diffusion; BasicTransformerBlock in diffusers,
+ * reached from text_to_image/train_text_to_image_lora.py:1268-1270): LayerNorm over the last dim and GEGLU
+ * (out = h[:, :F] * gelu(h[:, F:]), exact erf GELU).  dgamma_dbeta is [2C]: dgamma then dbeta.
+ * ---------------------------------------------------------------------------- */
+int64_t gad_layernorm_workspace_bytes(int64_t rows, int32_t C);
+int gad_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
+                      int64_t rows, int32_t C, float eps, void* stream);
+int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* mean,
+                      const float* rstd, float* dgamma_dbeta, int64_t rows, int32_t C, void* ws, int64_t ws_bytes,
+                      void* stream);
+int gad_geglu_fwd(const float* h, float* out, int64_t M, int32_t F, void* stream);
+int gad_geglu_bwd(const float* h, const float* dout, float* dh, int64_t M, int32_t F, void* stream);
+
+/* ------------------------------------------------------------------------------
  * Elementwise / small kernels (HBM-bound)
  * ---------------------------------------------------------------------------- */
 /* diffusers get_timestep_embedding: out[b][dim] fp32; t int64 [B] */

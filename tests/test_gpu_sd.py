@@ -1,0 +1,148 @@
+"""GPU parity of the Stable-Diffusion pieces: LayerNorm, GEGLU, cross-attention with Tk=77,
+UNet2DConditionModel forward and LoRA-only backward vs the CPU oracle (fp64/fp32 torch)."""
+import math
+
+import pytest
+import torch
+import torch.nn.functional as F
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def close(got, want, rtol=2e-4, atol=2e-4):
+    got, want = got.detach().cpu().double(), want.detach().cpu().double()
+    assert got.shape == want.shape
+    assert torch.allclose(got, want, rtol=rtol, atol=atol * max(1.0, want.abs().max().item())), \
+        f"max err {(got - want).abs().max().item():.3e}"
+
+
+@pytest.mark.parametrize("rows,C", [(7, 320), (300, 640), (77 * 3, 1280), (5, 96)])
+def test_layernorm_fwd_bwd(rows, C):
+    from gad import ops
+    x = (rnd(rows, C, seed=1) * 1.7 + 0.4).double().requires_grad_(True)
+    g, b = (rnd(C, seed=2) * 0.2 + 1).double().requires_grad_(True), (rnd(C, seed=3) * 0.1).double().requires_grad_(True)
+    y = F.layer_norm(x, (C,), g, b, 1e-5)
+    dy = rnd(rows, C, seed=4)
+    y.backward(dy.double())
+    gx, gg, gb = (t.detach().float().to(dev).requires_grad_(True) for t in (x, g, b))
+    out = ops.layer_norm(gx, gg, gb, 1e-5)
+    out.backward(dy.to(dev))
+    close(out, y, atol=2e-5)
+    close(gx.grad, x.grad, atol=5e-5)
+    close(gg.grad, g.grad, atol=2e-5 * math.sqrt(rows))
+    close(gb.grad, b.grad, atol=2e-5 * math.sqrt(rows))
+
+
+def test_geglu_fwd_bwd():
+    from gad import ops
+    h = rnd(50, 2 * 128, seed=1).double().requires_grad_(True)
+    a, gate = h.chunk(2, dim=-1)
+    y = a * F.gelu(gate)
+    dy = rnd(50, 128, seed=2)
+    y.backward(dy.double())
+    gh = h.detach().float().to(dev).requires_grad_(True)
+    out = ops.geglu(gh)
+    out.backward(dy.to(dev))
+    close(out, y, atol=1e-6)
+    close(gh.grad, h.grad, atol=1e-6)
+
+
+def test_cross_attention_ragged_context_length():
+    from gad import ops
+    B, Tq, Tk, heads, d = 2, 64, 77, 4, 40
+    C = heads * d
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.5), rnd(B, Tk, C, seed=2, scale=0.5), rnd(B, Tk, C, seed=3)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+
+    def split(t, T):
+        return t.view(B, T, heads, d).transpose(1, 2)
+    o = F.scaled_dot_product_attention(split(qd, Tq), split(kd, Tk), split(vd, Tk)).transpose(1, 2).reshape(B, Tq, C)
+    do = rnd(B, Tq, C, seed=4)
+    o.backward(do.double())
+    gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_core(gq, gk, gv, heads)
+    out.backward(do.to(dev))
+    close(out, o, atol=3e-5)
+    close(gq.grad, qd.grad, atol=5e-5)
+    close(gk.grad, kd.grad, atol=5e-5)
+    close(gv.grad, vd.grad, atol=5e-5)
+
+
+SMALL = dict(block_out_channels=(64, 128, 128, 128), attention_head_dim=4, cross_attention_dim=96, sample_size=16)
+
+
+def _pair(lora_rank=None):
+    import gad
+    from oracle.diffusers_ref import LoRALinearLayer as RL
+    from oracle.sd_unet_ref import CrossAttention as RCA
+    from oracle.sd_unet_ref import UNet2DConditionModel as R
+    torch.manual_seed(0)
+    ref = R(**SMALL)
+    net = gad.UNet2DConditionModel(**SMALL)
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    if lora_rank:
+        ranks = {}
+        i = 0
+        for name, m in ref.named_modules():
+            if isinstance(m, RCA):
+                for proj, lin in (("to_q", m.to_q), ("to_k", m.to_k), ("to_v", m.to_v), ("to_out", m.to_out[0])):
+                    r = lora_rank - (i % 3) * 2          # ragged ranks as after prune_lora.py
+                    i += 1
+                    layer = RL(lin.in_features, lin.out_features, rank=r)
+                    with torch.no_grad():
+                        layer.up.weight.copy_(rnd(lin.out_features, r, seed=100 + i, scale=0.05))
+                    lin.set_lora_layer(layer)
+                    ranks[f"{name}.{proj}"] = (r, layer)
+        for p in ref.parameters():
+            p.requires_grad_(False)
+        net.inject_lora(rank=lora_rank, ranks={k: v[0] for k, v in ranks.items()})
+        for name, attn in net.attention_modules().items():
+            base = name[: -len(".processor")]
+            for proj, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0])):
+                src = ranks[f"{base}.{proj}"][1]
+                with torch.no_grad():
+                    lin.lora_layer.down.weight.copy_(src.down.weight)
+                    lin.lora_layer.up.weight.copy_(src.up.weight)
+                for p in src.parameters():
+                    p.requires_grad_(True)
+    return ref, net
+
+
+def test_sd_unet_forward_matches_oracle():
+    ref, net = _pair()
+    x, ctx, t = rnd(2, 4, 16, 16, seed=1), rnd(2, 77, 96, seed=2), torch.tensor([5, 800])
+    close(net(x.to(dev), t.to(dev), ctx.to(dev)).sample, ref(x, t, ctx).sample, atol=1e-4)
+
+
+def test_sd_lora_training_step_grads(tmp_path):
+    from gad import ops
+    ref, net = _pair(lora_rank=8)
+    x, ctx, t = rnd(2, 4, 16, 16, seed=1), rnd(2, 77, 96, seed=2), torch.tensor([5, 800])
+    noise = rnd(2, 4, 16, 16, seed=3)
+    want = ref(x, t, ctx).sample
+    F.mse_loss(want, noise).backward()
+    got = net(x.to(dev), t.to(dev), ctx.to(dev)).sample
+    loss, d = ops.mse_fwd_bwd_raw(got.contiguous(), noise.to(dev))
+    got.backward(d)
+    close(got, want, atol=1e-4)
+    rg = {n: p.grad for n, p in ref.named_parameters() if p.grad is not None}
+    gg = {n: p.grad for n, p in net.named_parameters() if p.grad is not None}
+    assert len(rg) == len(gg) == 32 * 4 * 2 and set(rg) == set(gg)          # only LoRA down/up get gradients
+    typical = sorted(v.norm().item() for v in rg.values())[len(rg) // 2]
+    for n in rg:
+        err = (gg[n].cpu().double() - rg[n].double()).norm().item() / (rg[n].norm().item() + 1e-3 * typical)
+        assert err < 3e-3, (n, err)
+    # safetensors round trip with ragged ranks
+    net.save_attn_procs(str(tmp_path))
+    import gad
+    net2 = gad.UNet2DConditionModel(**SMALL)
+    net2.load_state_dict({k: v for k, v in ref.state_dict().items() if "lora" not in k})
+    net2.to(dev)
+    net2.load_attn_procs(str(tmp_path))
+    close(net2(x.to(dev), t.to(dev), ctx.to(dev)).sample, got, atol=1e-6)

@@ -1,0 +1,65 @@
+"""Score-tail arithmetic against independent recomputations with the same
+libraries the reference calls (scipy.stats.entropy, scipy sqrtm, scipy ward/fcluster, brute-force torch)."""
+import numpy as np
+import torch
+from scipy.stats import entropy
+
+from src.attributions.global_scores.diversity_score import diversity_from_embeddings
+from src.attributions.global_scores.fid_score import (calculate_fid_from_features, calculate_frechet_distance,
+                                                      compute_features_stats)
+from src.attributions.global_scores.inception_score import inception_score_from_probs
+from src.attributions.global_scores.precision_recall import calc_pr, make_manifold
+
+
+def test_frechet_distance_closed_forms():
+    rng = np.random.RandomState(0)
+    a = rng.randn(500, 16)
+    mu, sig = compute_features_stats(a)
+    assert abs(calculate_frechet_distance(mu, sig, mu, sig)) < 1e-6
+    # commuting covariances: d^2 = |dmu|^2 + sum (sqrt(l1) - sqrt(l2))^2
+    l1, l2 = rng.rand(8) + 0.5, rng.rand(8) + 0.5
+    d = calculate_frechet_distance(np.zeros(8), np.diag(l1), np.ones(8), np.diag(l2))
+    assert abs(d - (8 + np.sum((np.sqrt(l1) - np.sqrt(l2)) ** 2))) < 1e-8
+    assert calculate_fid_from_features(a * 1.5 + 0.3, mu, sig) > 0
+
+
+def test_inception_score_matches_scipy_entropy_loop():
+    rng = np.random.RandomState(1)
+    logits = rng.randn(200, 10) * 2
+    p = np.exp(logits) / np.exp(logits).sum(1, keepdims=True)
+    for splits in (1, 4):
+        want = []
+        for k in range(splits):
+            part = p[k * (200 // splits):(k + 1) * (200 // splits)]
+            py = part.mean(0)
+            want.append(np.exp(np.mean([entropy(part[i], py) for i in range(len(part))])))
+        assert abs(inception_score_from_probs(p, splits) - np.mean(want)) < 1e-10
+    assert abs(inception_score_from_probs(np.full((50, 10), 0.1)) - 1.0) < 1e-12
+
+
+def test_precision_recall_bruteforce():
+    g = torch.Generator().manual_seed(0)
+    real, fake = torch.randn(300, 8, generator=g), torch.randn(200, 8, generator=g) * 0.7 + 0.2
+    m_fake, m_real = make_manifold(fake, 3, 128, 100), make_manifold(real, 3, 128, 100)
+    p, r = calc_pr(m_fake, m_real, 64, 90, "cpu")
+
+    def brute(probe, target):
+        ft, fp = target.features, probe.features
+        kth = torch.cdist(ft, ft).float().kthvalue(4, dim=1).values.half()
+        return (torch.cdist(fp, ft) <= kth.unsqueeze(0)).any(1).float().mean().item()
+    assert abs(p - brute(m_fake, m_real)) < 1e-6 and abs(r - brute(m_real, m_fake)) < 1e-6
+    assert 0 < p <= 1 and 0 < r <= 1
+    assert calc_pr(m_real, m_real, 64, 90, "cpu") == (1.0, 1.0)
+
+
+def test_diversity_entropy():
+    rng = np.random.RandomState(2)
+    centers = rng.randn(4, 16) * 4
+    ref = np.concatenate([c + 0.1 * rng.randn(25, 16) for c in centers])
+    ref /= np.linalg.norm(ref, axis=1, keepdims=True)
+    gen_uniform = np.concatenate([c + 0.1 * rng.randn(10, 16) for c in centers])
+    gen_uniform /= np.linalg.norm(gen_uniform, axis=1, keepdims=True)
+    ent, count, prop, labels, assigned = diversity_from_embeddings(ref, gen_uniform, 4)
+    assert sorted(count) == [10, 10, 10, 10] and abs(ent - 2.0) < 1e-9 and len(set(labels)) == 4
+    ent1, count1, *_ = diversity_from_embeddings(ref, gen_uniform[:10], 4)
+    assert abs(ent1) < 1e-9 and sorted(count1) == [0, 0, 0, 10]
