@@ -15,9 +15,10 @@
 namespace {
 
 constexpr int NT = 256;
+constexpr int MAXC = 3072;   // SD up-blocks concatenate to 2560 channels
 
 struct Geo {
-  int B, HW, C, G, cpg, C4, rows_par, nch, ppc;  // ppc = pixels per chunk
+  int B, HW, C, G, cpg, C4, tpr, rows_par, nch, ppc;  // ppc = pixels per chunk
 };
 
 static Geo make_geo(const gad_groupnorm_args* a) {
@@ -25,7 +26,8 @@ static Geo make_geo(const gad_groupnorm_args* a) {
   g.B = a->B; g.HW = a->HW; g.C = a->C; g.G = a->G;
   g.cpg = a->C / a->G;
   g.C4 = a->C / 4;
-  g.rows_par = NT / g.C4;
+  g.tpr = g.C4 < NT ? g.C4 : NT;       // threads per pixel row; wider rows loop over channel quads
+  g.rows_par = NT / g.tpr;
   int nch = 2048 / (a->B > 0 ? a->B : 1);
   int maxch = a->HW / 8;
   if (nch > maxch) nch = maxch;
@@ -39,23 +41,25 @@ __device__ __forceinline__ float silu_f(float z) { return z / (1.f + expf(-z)); 
 
 // ---------------------------------------------------------------- forward ----
 __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, Geo g) {
-  __shared__ float red[2 * 1024];  // [rows_par][C] sums then sumsqs; rows_par*C <= 1024
+  __shared__ float red[2 * MAXC];  // [rows_par][C] sums then sumsqs; rows_par*C <= max(1024, C)
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
   int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
   int tid = threadIdx.x;
-  int prow = tid / g.C4, cq = tid - prow * g.C4;
-  f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+  int prow = tid / g.tpr, cfirst = tid - prow * g.tpr;
   if (prow < g.rows_par) {
-    const float* xb = x + ((long)b * g.HW) * g.C + cq * 4;
-    for (int p = p0 + prow; p < p1; p += g.rows_par) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
-      s += v;
-      ss += v * v;
-    }
-    float* r0 = red + prow * g.C + cq * 4;
-    float* r1 = red + g.rows_par * g.C + prow * g.C + cq * 4;
+    for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
+      f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
+      const float* xb = x + ((long)b * g.HW) * g.C + cq * 4;
+      for (int p = p0 + prow; p < p1; p += g.rows_par) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
+        s += v;
+        ss += v * v;
+      }
+      float* r0 = red + prow * g.C + cq * 4;
+      float* r1 = red + g.rows_par * g.C + prow * g.C + cq * 4;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { r0[e] = s[e]; r1[e] = ss[e]; }
+      for (int e = 0; e < 4; ++e) { r0[e] = s[e]; r1[e] = ss[e]; }
+    }
   }
   __syncthreads();
   for (int grp = tid; grp < g.G; grp += NT) {
@@ -106,28 +110,30 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
       mean_out[b * g.G + grp] = s_mean[grp];
       rstd_out[b * g.G + grp] = s_rstd[grp];
     }
-  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  int prow = tid / g.tpr, cfirst = tid - prow * g.tpr;
   if (prow >= g.rows_par) return;
-  int c0 = cq * 4;
-  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
-  f32x4 mu, rs;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    int grp = (c0 + e) / g.cpg;
-    mu[e] = s_mean[grp];
-    rs[e] = s_rstd[grp];
-  }
-  f32x4 scale = rs * ga, shift = be - mu * scale;
   int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
-  long base = ((long)b * g.HW) * g.C + c0;
-  for (int p = p0 + prow; p < p1; p += g.rows_par) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
-    f32x4 z = v * scale + shift;
-    if (silu) {
+  for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
+    int c0 = cq * 4;
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 mu, rs;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+    for (int e = 0; e < 4; ++e) {
+      int grp = (c0 + e) / g.cpg;
+      mu[e] = s_mean[grp];
+      rs[e] = s_rstd[grp];
     }
-    *reinterpret_cast<f32x4*>(y + base + (long)p * g.C) = z;
+    f32x4 scale = rs * ga, shift = be - mu * scale;
+    long base = ((long)b * g.HW) * g.C + c0;
+    for (int p = p0 + prow; p < p1; p += g.rows_par) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+      f32x4 z = v * scale + shift;
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+      }
+      *reinterpret_cast<f32x4*>(y + base + (long)p * g.C) = z;
+    }
   }
 }
 
@@ -143,38 +149,40 @@ __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const float* __restric
                                                           const float* __restrict__ gamma, const float* __restrict__ beta,
                                                           const float* __restrict__ mean, const float* __restrict__ rstd,
                                                           float* __restrict__ part, Geo g, int silu) {
-  __shared__ float red[2 * 1024];
+  __shared__ float red[2 * MAXC];
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
   int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
   int tid = threadIdx.x;
-  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  int prow = tid / g.tpr, cfirst = tid - prow * g.tpr;
   if (prow < g.rows_par) {
-    int c0 = cq * 4;
-    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
-    f32x4 mu, rs;
-#pragma unroll
-    for (int e = 0; e < 4; ++e) {
-      int grp = (c0 + e) / g.cpg;
-      mu[e] = mean[b * g.G + grp];
-      rs[e] = rstd[b * g.G + grp];
-    }
-    f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
-    long base = ((long)b * g.HW) * g.C + c0;
-    for (int p = p0 + prow; p < p1; p += g.rows_par) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
-      f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
-      f32x4 xh = (v - mu) * rs;
+    for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
+      int c0 = cq * 4;
+      f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+      f32x4 mu, rs;
 #pragma unroll
       for (int e = 0; e < 4; ++e) {
-        float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
-        sa[e] += ge;
-        sb[e] += ge * xh[e];
+        int grp = (c0 + e) / g.cpg;
+        mu[e] = mean[b * g.G + grp];
+        rs[e] = rstd[b * g.G + grp];
       }
-    }
-    float* r0 = red + prow * g.C + c0;
-    float* r1 = red + g.rows_par * g.C + prow * g.C + c0;
+      f32x4 sa = {0, 0, 0, 0}, sb = {0, 0, 0, 0};
+      long base = ((long)b * g.HW) * g.C + c0;
+      for (int p = p0 + prow; p < p1; p += g.rows_par) {
+        f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+        f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
+        f32x4 xh = (v - mu) * rs;
 #pragma unroll
-    for (int e = 0; e < 4; ++e) { r0[e] = sa[e]; r1[e] = sb[e]; }
+        for (int e = 0; e < 4; ++e) {
+          float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
+          sa[e] += ge;
+          sb[e] += ge * xh[e];
+        }
+      }
+      float* r0 = red + prow * g.C + c0;
+      float* r1 = red + g.rows_par * g.C + prow * g.C + c0;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { r0[e] = sa[e]; r1[e] = sb[e]; }
+    }
   }
   __syncthreads();
   for (int c = tid; c < g.C; c += NT) {
@@ -194,7 +202,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
                                                           const float* __restrict__ beta, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ part,
                                                           Geo g, int silu) {
-  __shared__ float s_a[1024], s_b[1024];     // per channel sums (gamma-weighted)
+  __shared__ float s_a[MAXC], s_b[MAXC];     // per channel sums (gamma-weighted)
   __shared__ float s_s1[256], s_s2[256];     // per group
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
   int tid = threadIdx.x;
@@ -221,38 +229,40 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
     s_s2[grp] = s2 * inv_n;
   }
   __syncthreads();
-  int prow = tid / g.C4, cq = tid - prow * g.C4;
+  int prow = tid / g.tpr, cfirst = tid - prow * g.tpr;
   if (prow >= g.rows_par) return;
-  int c0 = cq * 4;
-  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
-  f32x4 mu, rs, m1, m2;
-#pragma unroll
-  for (int e = 0; e < 4; ++e) {
-    int grp = (c0 + e) / g.cpg;
-    mu[e] = mean[b * g.G + grp];
-    rs[e] = rstd[b * g.G + grp];
-    m1[e] = s_s1[grp];
-    m2[e] = s_s2[grp];
-  }
   int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
-  long base = ((long)b * g.HW) * g.C + c0;
-  for (int p = p0 + prow; p < p1; p += g.rows_par) {
-    f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
-    f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
-    f32x4 xh = (v - mu) * rs, o;
+  for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
+    int c0 = cq * 4;
+    f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    f32x4 mu, rs, m1, m2;
 #pragma unroll
     for (int e = 0; e < 4; ++e) {
-      float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
-      o[e] = rs[e] * (ge * ga[e] - m1[e] - xh[e] * m2[e]);
+      int grp = (c0 + e) / g.cpg;
+      mu[e] = mean[b * g.G + grp];
+      rs[e] = rstd[b * g.G + grp];
+      m1[e] = s_s1[grp];
+      m2[e] = s_s2[grp];
     }
-    *reinterpret_cast<f32x4*>(dx + base + (long)p * g.C) = o;
+    long base = ((long)b * g.HW) * g.C + c0;
+    for (int p = p0 + prow; p < p1; p += g.rows_par) {
+      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+      f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * g.C);
+      f32x4 xh = (v - mu) * rs, o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
+        o[e] = rs[e] * (ge * ga[e] - m1[e] - xh[e] * m2[e]);
+      }
+      *reinterpret_cast<f32x4*>(dx + base + (long)p * g.C) = o;
+    }
   }
 }
 
 static int check(const gad_groupnorm_args* a, const char* who) {
   GAD_CHECK(a && a->x && a->y && a->gamma && a->beta && a->mean && a->rstd, "%s: null pointer", who);
   GAD_CHECK(a->B > 0 && a->HW > 0 && a->C > 0 && a->G > 0 && a->C % a->G == 0, "%s: bad shape", who);
-  GAD_CHECK(a->C % 4 == 0 && a->C <= 1024 && a->G <= 256, "%s: needs C%%4==0, C<=1024, G<=256 (C=%d G=%d)", who, a->C, a->G);
+  GAD_CHECK(a->C % 4 == 0 && a->C <= MAXC && a->G <= 256, "%s: needs C%%4==0, C<=3072, G<=256 (C=%d G=%d)", who, a->C, a->G);
   GAD_CHECK(gad_aligned16(a->x) && gad_aligned16(a->y) && gad_aligned16(a->gamma) && gad_aligned16(a->beta), "%s: pointers must be 16-byte aligned", who);
   int64_t need = gad_groupnorm_workspace_bytes(a);
   GAD_CHECK(a->ws && a->ws_bytes >= need, "%s: workspace too small (%lld < %lld)", who, (long long)a->ws_bytes, (long long)need);

@@ -152,7 +152,7 @@ def test_conv_autograd_function(ops):
 # -------------------------------------------------------------------------- groupnorm ----
 @pytest.mark.parametrize("B,C,H,G,silu", [(2, 128, 32, 32, True), (3, 256, 16, 32, True), (2, 384, 16, 32, True),
                                           (2, 512, 4, 32, True), (2, 224, 8, 32, False), (1, 896, 8, 32, True),
-                                          (32, 128, 32, 32, True)])
+                                          (32, 128, 32, 32, True), (2, 1280, 8, 32, True), (1, 2560, 4, 32, True)])
 def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
     x = (rnd(B, C, H, H, seed=1) * 2 + 0.7).double().requires_grad_(True)   # non-zero mean stresses the variance
     ga, be = (rnd(C, seed=2) * 0.3 + 1).double().requires_grad_(True), (rnd(C, seed=3) * 0.2).double().requires_grad_(True)
