@@ -7,7 +7,7 @@ from . import _capi, ops  # noqa: F401
 from .nn import LoRALinearLayer, UNet2DModel  # noqa: F401
 from .pipelines import DDIMPipeline, DDPMPipeline  # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
-from .training import EMAModel, FusedTrainer  # noqa: F401
+from .training import EMAModel, FusedTrainer, flatten_params, lr_lambda  # noqa: F401
 from . import coalition  # noqa: F401,E402
 from .coalition import DeviceLoader, antithetic_timesteps, seed_everything  # noqa: F401,E402
 

@@ -337,28 +337,8 @@ class UNet2DModel(nn.Module):
     def flatten_parameters(self):
         """Re-home every parameter (and its .grad) in one contiguous fp32 buffer; conv weights keep
         their [Cout,KH,KW,Cin] storage.  Returns (flat_params, flat_grads)."""
-        params = list(self.parameters())
-        dev = params[0].device
-        sizes = [(p.numel() + 3) // 4 * 4 for p in params]           # keep every slice 16-B aligned
-        total = sum(sizes)
-        flat = torch.zeros(total, device=dev, dtype=torch.float32)
-        gflat = torch.zeros(total, device=dev, dtype=torch.float32)
-        off = 0
-        with torch.no_grad():
-            for p, sz in zip(params, sizes):
-                n = p.numel()
-
-                def view_like(buf, p=p, off=off, n=n):
-                    if p.ndim == 4:
-                        o, i, kh, kw = p.shape
-                        return buf[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
-                    return buf[off:off + n].view(p.shape)
-
-                v = view_like(flat)
-                v.copy_(p)
-                p.data = v
-                p.grad = view_like(gflat)
-                off += sz
+        from .training import flatten_params
+        flat, gflat = flatten_params(self.parameters())
         self._flat = (flat, gflat)
         return flat, gflat
 

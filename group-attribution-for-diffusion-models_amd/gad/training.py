@@ -8,6 +8,49 @@ import torch
 from . import ops
 
 
+def flatten_params(params):
+    """Re-home the given parameters (and their .grad) in one contiguous fp32 buffer each, keeping conv weights'
+    [Cout,KH,KW,Cin] storage.  Every slice starts 16-B aligned.  Returns (flat, flat_grad)."""
+    params = list(params)
+    dev = params[0].device
+    sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+    flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
+    gflat = torch.zeros_like(flat)
+    off = 0
+    with torch.no_grad():
+        for p, sz in zip(params, sizes):
+            n = p.numel()
+
+            def view_like(buf, p=p, off=off, n=n):
+                if p.ndim == 4:
+                    o, i, kh, kw = p.shape
+                    return buf[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+                return buf[off:off + n].view(p.shape)
+
+            v = view_like(flat)
+            v.copy_(p)
+            p.data = v
+            p.grad = view_like(gflat)
+            off += sz
+    return flat, gflat
+
+
+def lr_lambda(name, num_training_steps, num_warmup_steps=0):
+    """diffusers.optimization.get_scheduler multipliers used by the reference: "constant" (main.py) and
+    "cosine" (text_to_image LoRA trainer, ddpm_config.py:637); SURVEY A.12."""
+    import math
+    if name == "constant":
+        return lambda step: 1.0
+    if name == "cosine":
+        def f(step):
+            if step < num_warmup_steps:
+                return step / max(1, num_warmup_steps)
+            prog = (step - num_warmup_steps) / max(1, num_training_steps - num_warmup_steps)
+            return max(0.0, 0.5 * (1.0 + math.cos(math.pi * prog)))
+        return f
+    raise NotImplementedError(f"lr_scheduler={name}")
+
+
 class EMAModel:
     def __init__(self, parameters, decay=0.9999, min_decay=0.0, update_after_step=0, use_ema_warmup=False,
                  inv_gamma=1.0, power=2 / 3, model_cls=None, model_config=None, **unused):
@@ -118,9 +161,15 @@ class FusedTrainer:
     the caller (so the RNG policy stays in the entry point)."""
 
     def __init__(self, model, scheduler, ema: EMAModel | None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, adamw=False, max_grad_norm=1.0, loss_sign=1.0):
+                 weight_decay=0.0, adamw=False, max_grad_norm=1.0, loss_sign=1.0, params=None, lr_schedule=None):
         self.model, self.scheduler, self.ema = model, scheduler, ema
-        self.flat, self.gflat = model.flatten_parameters() if model._flat is None else model.flat
+        if params is None:                      # train everything (DDPM); else only `params` (LoRA: base frozen)
+            self.flat, self.gflat = model.flatten_parameters() if model._flat is None else model.flat
+        else:
+            if ema is not None:
+                raise ValueError("EMA over a parameter subset is not used by the reference's LoRA trainer")
+            self.flat, self.gflat = flatten_params(params)
+        self.base_lr, self.lr_schedule = lr, lr_schedule
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.ema_flat = ema.bind_flat(model) if ema is not None else None
@@ -130,11 +179,11 @@ class FusedTrainer:
         self._sumsq = torch.zeros(1, device=self.flat.device)
         self.last_loss = None
 
-    def step(self, image_nchw, noise_nchw, timesteps):
+    def step(self, image_nchw, noise_nchw, timesteps, *model_args):
         model = self.model
         self.gflat.zero_()
         noisy = self.scheduler.add_noise(image_nchw, noise_nchw, timesteps)
-        eps = model(noisy, timesteps).sample
+        eps = model(noisy, timesteps, *model_args).sample
         loss, d = ops.mse_fwd_bwd_raw(eps.contiguous(), noise_nchw.contiguous(), grad_scale=self.loss_sign)
         eps.backward(d)
         self.optimizer_step()
@@ -147,6 +196,8 @@ class FusedTrainer:
         if self.max_grad_norm is not None:
             sumsq = ops.sumsq_raw(self.gflat, out=self._sumsq)
         decay = self.ema.next_decay() if self.ema is not None else 0.0
+        if self.lr_schedule is not None:        # LambdaLR semantics: step k (0-based) runs at base_lr * f(k)
+            self.hp["lr"] = self.base_lr * self.lr_schedule(self.step_count - 1)
         ops.clip_adam_ema_raw(self.flat, self.gflat, self.m, self.v, self.ema_flat, sumsq,
                               max_norm=self.max_grad_norm or 0.0, step=self.step_count, ema_decay=decay, **self.hp)
 

@@ -93,3 +93,30 @@ def test_removal_directory_grammar():
     assert train_main.removal_directory(a) == "datamodel/datamodel_alpha=0.25_seed=7"
     a = train_main.parse_args(["--dataset", "cifar100", "--method", "retrain", "--removal_dist", "shapley", "--removal_seed", "3"])
     assert train_main.removal_directory(a) == "shapley/shapley_seed=3"
+
+
+def test_sd_entry_point_bookkeeping(tmp_path):
+    """Directory grammar, removal-unit table, removal_idx.csv and the cosine schedule of the SD LoRA trainer (CPU)."""
+    import pandas as pd
+    from text_to_image import train_text_to_image_lora as T
+    import gad
+    a = T.parse_args(["--train_data_dir", str(tmp_path / "artbench"), "--removal_dist", "shapley", "--removal_unit", "artist",
+                      "--removal_seed", "3"])
+    assert T.removal_directory(a) == "artist_shapley/shapley_seed=3"
+    a2 = T.parse_args(["--train_data_dir", "x", "--removal_dist", "datamodel", "--datamodel_alpha", "0.5", "--removal_unit",
+                       "artist", "--removal_seed", "1"])
+    assert T.removal_directory(a2) == "artist_datamodel_alpha=0.5/datamodel_alpha=0.5_seed=1"
+    a3 = T.parse_args(["--train_data_dir", "x", "--removal_dist", "loo", "--removal_unit", "filename", "--loo_idx", "7"])
+    assert T.removal_directory(a3) == "filename_loo/loo_idx=7"
+    cache = T.synthetic_cache(str(tmp_path / "artbench" / "latent_cache.pt"), n=600, n_artists=258, res=64)
+    units = pd.read_csv(tmp_path / "artbench" / "post_impressionism_artists.csv")
+    assert len(units) == 258 and cache["latents"].shape == (600, 4, 8, 8)
+    os.makedirs(tmp_path / "m")
+    rem, rmv = T.coalition_rows(a, str(tmp_path / "m"), units)
+    from src.datasets import remove_data_by_shapley
+    r2, x2 = remove_data_by_shapley(units, 3)
+    assert rem.tolist() == r2.tolist() and rmv.tolist() == x2.tolist() and len(rem) + len(rmv) == 258
+    rem_again, _ = T.coalition_rows(a, str(tmp_path / "m"), units)       # second call reads removal_idx.csv
+    assert sorted(rem_again.tolist()) == sorted(rem.tolist())
+    f = gad.lr_lambda("cosine", 200)
+    assert f(0) == 1.0 and abs(f(100) - 0.5) < 1e-12 and f(200) == 0.0 and gad.lr_lambda("constant", 10)(7) == 1.0

@@ -146,3 +146,30 @@ def test_sd_lora_training_step_grads(tmp_path):
     net2.to(dev)
     net2.load_attn_procs(str(tmp_path))
     close(net2(x.to(dev), t.to(dev), ctx.to(dev)).sample, got, atol=1e-6)
+
+
+def test_sd_lora_entry_point(tmp_path):
+    import json
+    import pandas as pd
+    from safetensors.torch import load_file
+    from text_to_image import train_text_to_image_lora as T
+    data = tmp_path / "artbench"
+    T.synthetic_cache(str(data / "latent_cache.pt"), n=300, n_artists=20, res=128, ctx_dim=96)
+    pd.DataFrame({"artist": sorted({f"artist_{i:03d}" for i in range(20)})}).to_csv(data / "post_impressionism_artists.csv", index=False)
+    over = json.dumps(dict(block_out_channels=(64, 128, 128, 128), attention_head_dim=4, cross_attention_dim=96, sample_size=16))
+    common = ["--train_data_dir", str(data), "--output_dir", str(tmp_path / "out"), "--cls_key", "style", "--cls",
+              "post_impressionism", "--train_batch_size", "8", "--unet_overrides", over, "--seed", "42",
+              "--lr_scheduler", "cosine", "--learning_rate", "3e-4", "--adam_weight_decay", "1e-6"]
+    a = T.parse_args(common + ["--method", "retrain", "--rank", "8", "--max_train_steps", "4", "--removal_dist", "shapley",
+                               "--removal_unit", "artist", "--removal_seed", "0"])
+    assert T.main(a)
+    mdir = tmp_path / "out" / "artbench_post_impressionism" / "retrain" / "models" / "artist_shapley" / "shapley_seed=0"
+    sd = load_file(str(mdir / "pytorch_lora_weights.safetensors"))
+    assert len(sd) == 32 * 4 * 2
+    k = "unet.mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_k_lora.down.weight"
+    assert sd[k].shape == (8, 96) and sd[k.replace("down", "up")].abs().sum() > 0        # up started at 0: it trained
+    t = pd.read_csv(mdir / "time.csv")
+    assert list(t.columns) == ["step", "time", "gpu"] and len(t) == 4
+    ridx = pd.read_csv(mdir / "removal_idx.csv")
+    assert set(ridx.columns) == {"idx", "remaining"} and len(ridx) == 20
+    assert T.main(a) is False                                                          # skip-if-done
