@@ -79,6 +79,27 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
+__global__ void cfg_ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eu, const float* __restrict__ ec,
+                                     float* __restrict__ xp, long n, float gd, float sa, float sb, float spa, float spb, float clip) {
+  EW_LOOP_VEC(n) {
+    f32x4 v = reinterpret_cast<const f32x4*>(x)[i], u = reinterpret_cast<const f32x4*>(eu)[i], c = reinterpret_cast<const f32x4*>(ec)[i], o;
+#pragma unroll
+    for (int e = 0; e < 4; ++e) {
+      float eps = u[e] + gd * (c[e] - u[e]);
+      float x0 = (v[e] - sb * eps) / sa;
+      if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+      o[e] = spa * x0 + spb * eps;
+    }
+    reinterpret_cast<f32x4*>(xp)[i] = o;
+  }
+  EW_LOOP_TAIL(n) {
+    float eps = eu[i] + gd * (ec[i] - eu[i]);
+    float x0 = (x[i] - sb * eps) / sa;
+    if (clip > 0.f) x0 = fminf(fmaxf(x0, -clip), clip);
+    xp[i] = spa * x0 + spb * eps;
+  }
+}
+
 __global__ void to_image01_kernel(const float* __restrict__ x, float* __restrict__ y, long n) {
   EW_LOOP_VEC(n) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i];
@@ -279,6 +300,16 @@ extern "C" int gad_ddim_step(const float* x, const float* eps, float* x_prev, in
   float sa = sqrtf(alpha_t), sb = sqrtf(1.f - alpha_t), spa = sqrtf(alpha_prev), spb = sqrtf(1.f - alpha_prev);
   hipLaunchKernelGGL(ddim_step_kernel, ew_grid(n / 4), dim3(NT), 0, ST, x, eps, x_prev, (long)n, sa, sb, spa, spb, clip);
   GAD_LAUNCH_CHECK("gad_ddim_step");
+  return 0;
+}
+extern "C" int gad_cfg_ddim_step(const float* x, const float* eps_uc, float* x_prev, int64_t n, float guidance, float alpha_t,
+                                 float alpha_prev, float clip, void* stream) {
+  GAD_CHECK(x && eps_uc && x_prev && n > 0 && n % 4 == 0 && gad_aligned16(x) && gad_aligned16(eps_uc) && gad_aligned16(x_prev),
+            "gad_cfg_ddim_step: bad args (n must be a multiple of 4)");
+  GAD_CHECK(alpha_t > 0.f && alpha_t <= 1.f && alpha_prev > 0.f && alpha_prev <= 1.f, "gad_cfg_ddim_step: alphas out of (0,1]");
+  hipLaunchKernelGGL(cfg_ddim_step_kernel, ew_grid(n / 4), dim3(NT), 0, ST, x, eps_uc, eps_uc + n, x_prev, (long)n, guidance,
+                     sqrtf(alpha_t), sqrtf(1.f - alpha_t), sqrtf(alpha_prev), sqrtf(1.f - alpha_prev), clip);
+  GAD_LAUNCH_CHECK("gad_cfg_ddim_step");
   return 0;
 }
 extern "C" int gad_to_image01(const float* x, float* y, int64_t n, void* stream) {

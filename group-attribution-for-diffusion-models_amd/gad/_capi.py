@@ -84,6 +84,7 @@ SIGNATURES = {
     "gad_colsum": (C.c_int, [_vp, _vp, _i32, _i64, _i32, _vp, _i64, _vp]),
     "gad_add_noise": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _i32, _i64, _vp]),
     "gad_ddim_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _vp]),
+    "gad_cfg_ddim_step": (C.c_int, [_vp, _vp, _vp, _i64, _f32, _f32, _f32, _f32, _vp]),
     "gad_to_image01": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gad_mse_fwd_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _i64, _f32, _vp, _i64, _vp]),
     "gad_sumsq": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),

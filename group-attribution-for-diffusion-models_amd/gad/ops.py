@@ -597,3 +597,15 @@ class GegluFn(torch.autograd.Function):
 
 def geglu(h):
     return GegluFn.apply(h)
+
+
+def cfg_ddim_step_raw(x, eps_uc, guidance: float, alpha_t: float, alpha_prev: float, clip: float, out=None):
+    """x [n...], eps_uc = U-Net output of the doubled batch [uncond ; cond] -> guided DDIM update of x."""
+    _req(x, "cfg x")
+    _req(eps_uc, "cfg eps")
+    if eps_uc.numel() != 2 * x.numel():
+        raise _capi.GadError("cfg_ddim_step: eps must hold the doubled batch")
+    out = torch.empty_like(x) if out is None else out
+    check(_capi.load().gad_cfg_ddim_step(x.data_ptr(), eps_uc.data_ptr(), out.data_ptr(), x.numel(), guidance, alpha_t,
+                                         alpha_prev, clip, _stream()), "gad_cfg_ddim_step")
+    return out

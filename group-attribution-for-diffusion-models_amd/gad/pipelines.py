@@ -97,3 +97,61 @@ class DDIMPipeline(DDPMPipeline):
 
     def __init__(self, unet, scheduler):
         super().__init__(unet, DDIMScheduler.from_config(scheduler.config))
+
+
+class StableDiffusionLatentPipeline:
+    """The U-Net half of StableDiffusionPipeline.__call__ as driven by the reference's behaviour script
+    (text_to_image/compute_model_behaviors.py:311-326): classifier-free guidance on a doubled batch and the
+    scheduler update, returning LATENTS.  The VAE decoder and the CLIP text encoder (hub-fetched, frozen,
+    off the hot path) stay outside: the caller passes prompt / negative-prompt embeddings and decodes.
+    Scheduler: DDIM over the SD beta schedule (the sampler class shipped with miniSD is unknown offline,
+    SURVEY A.13, so it is a parameter)."""
+
+    def __init__(self, unet, scheduler=None):
+        from .schedulers import DDIMScheduler
+        self.unet = unet
+        self.scheduler = scheduler or DDIMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear",
+                                                    clip_sample=False, set_alpha_to_one=False, steps_offset=1)
+        self.device = unet.device
+
+    @torch.no_grad()
+    def __call__(self, prompt_embeds, negative_prompt_embeds, num_inference_steps=100, guidance_scale=7.5,
+                 generator=None, height=None, width=None):
+        cfg = self.unet.config
+        B = prompt_embeds.shape[0]
+        hw = (height or cfg.sample_size * 8) // 8, (width or cfg.sample_size * 8) // 8
+        shape = (B, cfg.in_channels, *hw)
+        if generator is not None and generator.device.type == "cpu":
+            lat = torch.randn(shape, generator=generator, dtype=torch.float32).to(self.device)
+        else:
+            lat = torch.randn(shape, generator=generator, dtype=torch.float32, device=self.device)
+        sch = self.scheduler
+        sch.set_timesteps(num_inference_steps)
+        x = ops.nchw_to_nhwc_raw((lat * sch.init_noise_sigma).contiguous())
+        ctx = torch.cat([negative_prompt_embeds, prompt_embeds], 0).to(self.device, torch.float32).contiguous()
+        t2 = torch.empty(2 * B, device=self.device, dtype=torch.int64)
+        clip = float(sch.config.clip_sample_range) if sch.config.clip_sample else 0.0
+        for t in sch.timesteps.tolist():
+            t2.fill_(t)
+            eps = self.unet.forward_nhwc(torch.cat([x, x], 0), t2, ctx)
+            a_t, a_p = sch.step_coefficients(t)
+            ops.cfg_ddim_step_raw(x, eps, guidance_scale, a_t, a_p, clip, out=x)
+        return SimpleNamespace(latents=ops.nhwc_to_nchw_raw(x))
+
+
+def sd_simple_loss(unet, scheduler, latents0, prompt_embeds, timesteps, n_noises=3, generator=None):
+    """compute_model_behaviors.py:391-417: mean over `n_noises` of MSE(unet(add_noise(z0, eps, t_list), t_list), eps)
+    with the batch being the scheduler's whole timestep list."""
+    dev = unet.device
+    T = timesteps.shape[0]
+    z = latents0.to(dev).expand(T, -1, -1, -1).contiguous()
+    ctx = prompt_embeds.to(dev).expand(T, -1, -1).contiguous()
+    total = 0.0
+    with torch.no_grad():
+        for _ in range(n_noises):
+            eps = torch.randn(z.shape, generator=generator, device=dev, dtype=torch.float32)
+            noisy = scheduler.add_noise(z, eps, timesteps.to(dev))
+            pred = unet(noisy, timesteps.to(dev), ctx).sample
+            loss, _ = ops.mse_fwd_bwd_raw(pred.contiguous(), eps)
+            total += float(loss)
+    return total / n_noises

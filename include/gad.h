@@ -176,6 +176,11 @@ int gad_add_noise(const float* x0, const float* eps, const int64_t* t, const flo
  *   x0 = (x - sqrt(1-a_t) e)/sqrt(a_t); clamp(+-clip) if clip>0; x' = sqrt(a_p) x0 + sqrt(1-a_p) e      */
 int gad_ddim_step(const float* x, const float* eps, float* x_prev, int64_t n, float alpha_t,
                   float alpha_prev, float clip, void* stream);
+/* classifier-free-guidance DDIM step (StableDiffusionPipeline loop driven at
+ * text_to_image/compute_model_behaviors.py:311-326): eps = eps_u + guidance*(eps_c - eps_u), then the DDIM update.
+ * eps_uc holds the U-Net output of the doubled batch: [uncond ; cond], each n floats. */
+int gad_cfg_ddim_step(const float* x, const float* eps_uc, float* x_prev, int64_t n, float guidance, float alpha_t,
+                      float alpha_prev, float clip, void* stream);
 /* final pipeline post-processing: y = clamp(x/2 + 0.5, 0, 1) */
 int gad_to_image01(const float* x, float* y, int64_t n, void* stream);
 /* MSE loss and its gradient in one pass: loss[0] = mean((a-b)^2) ; d = 2 (a-b) * gscale / n */

@@ -120,3 +120,40 @@ def test_sd_entry_point_bookkeeping(tmp_path):
     assert sorted(rem_again.tolist()) == sorted(rem.tolist())
     f = gad.lr_lambda("cosine", 200)
     assert f(0) == 1.0 and abs(f(100) - 0.5) < 1e-12 and f(200) == 0.0 and gad.lr_lambda("constant", 10)(7) == 1.0
+
+
+def test_prune_lora_ranks(tmp_path):
+    """LoRA rank pruning: stops at the target, removes the smallest-magnitude ranks, leaves ragged ranks."""
+    import pandas as pd
+    from safetensors.torch import load_file, save_file
+    from text_to_image import prune_lora as P
+    g = torch.Generator().manual_seed(0)
+    sd = {}
+    dims = [(320, 320), (768, 320), (640, 640), (1280, 1280)]
+    for m, (cin, cout) in enumerate(dims):
+        scale = torch.linspace(0.1, 2.0, 16)[torch.randperm(16, generator=g)]
+        sd[f"unet.blk{m}.attn.processor.to_q_lora.down.weight"] = torch.randn(16, cin, generator=g) * scale[:, None]
+        sd[f"unet.blk{m}.attn.processor.to_q_lora.up.weight"] = torch.randn(cout, 16, generator=g) * scale[None, :]
+    src = tmp_path / "artbench_post_impressionism" / "retrain" / "models" / "full"
+    os.makedirs(src)
+    save_file(sd, str(src / "pytorch_lora_weights.safetensors"))
+    outdir = P.main(P.parse_args(["--lora_dir", str(src), "--pruning_ratio", "0.5"]))
+    assert outdir.endswith("artbench_post_impressionism/pruned_ratio=0.5/models/full")
+    out = load_file(os.path.join(outdir, "pytorch_lora_weights.safetensors"))
+    total = sum(t.numel() for t in sd.values())
+    kept = sum(t.numel() for t in out.values())
+    # the reference charges a removed pair 2x the size of the node that was met first (down: in_features, up:
+    # out_features), so for non-square projections the realised ratio only approximates the target (info.csv
+    # records it as actual_pruning_ratio)
+    assert abs(kept / total - 0.5) < 0.05
+    ranks = [out[f"unet.blk{m}.attn.processor.to_q_lora.down.weight"].shape[0] for m in range(4)]
+    assert all(out[f"unet.blk{m}.attn.processor.to_q_lora.up.weight"].shape[1] == r for m, r in enumerate(ranks))
+    assert 0 < min(ranks) and max(ranks) < 16
+    # kept ranks of a module are its highest-scoring ones
+    d0, u0 = sd["unet.blk0.attn.processor.to_q_lora.down.weight"], sd["unet.blk0.attn.processor.to_q_lora.up.weight"]
+    sc = P.rank_scores(d0, u0)
+    kept_rows = out["unet.blk0.attn.processor.to_q_lora.down.weight"]
+    kept_idx = [i for i in range(16) if any(torch.equal(d0[i], r) for r in kept_rows)]
+    assert sorted(kept_idx) == sorted(np.argsort(sc)[16 - len(kept_idx):].tolist())
+    info = pd.read_csv(os.path.join(outdir, "info.csv")).set_index("metric")["value"]
+    assert int(info["pruned_lora_params"]) == kept and abs(info["actual_pruning_ratio"] - kept / total) < 1e-4

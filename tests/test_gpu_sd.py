@@ -173,3 +173,29 @@ def test_sd_lora_entry_point(tmp_path):
     ridx = pd.read_csv(mdir / "removal_idx.csv")
     assert set(ridx.columns) == {"idx", "remaining"} and len(ridx) == 20
     assert T.main(a) is False                                                          # skip-if-done
+
+
+def test_guided_latent_sampling_matches_oracle_loop():
+    import gad
+    from oracle import diffusers_ref as R
+    ref, net = _pair()
+    cond, uncond = rnd(2, 77, 96, seed=5), rnd(1, 77, 96, seed=6).expand(2, -1, -1).contiguous()
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", clip_sample=False, set_alpha_to_one=False,
+              steps_offset=1)
+    pipe = gad.StableDiffusionLatentPipeline(net, gad.DDIMScheduler(**kw))
+    got = pipe(cond.to(dev), uncond.to(dev), num_inference_steps=4, guidance_scale=7.5,
+               generator=torch.Generator().manual_seed(11), height=128, width=128).latents
+    sch = R.DDIMScheduler(**kw)
+    sch.set_timesteps(4)
+    assert sch.timesteps.tolist() == [751, 501, 251, 1]
+    x = torch.randn((2, 4, 16, 16), generator=torch.Generator().manual_seed(11))
+    with torch.no_grad():
+        for t in sch.timesteps:
+            e = ref(torch.cat([x, x]), t, torch.cat([uncond, cond])).sample
+            eu, ec = e.chunk(2)
+            x = sch.step(eu + 7.5 * (ec - eu), t, x).prev_sample
+    close(got, x, atol=2e-4)
+    loss = gad.sd_simple_loss(net, gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear"),
+                              got[:1], cond[:1].to(dev), torch.tensor([751, 501, 251, 1]), n_noises=2,
+                              generator=torch.Generator(device=dev).manual_seed(0))
+    assert loss > 0 and loss == loss
