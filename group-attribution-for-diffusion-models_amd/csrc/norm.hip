@@ -29,7 +29,7 @@ static Geo make_geo(const gad_groupnorm_args* a) {
   g.tpr = g.C4 < NT ? g.C4 : NT;       // threads per pixel row; wider rows loop over channel quads
   g.rows_par = NT / g.tpr;
   int nch = 2048 / (a->B > 0 ? a->B : 1);
-  int maxch = a->HW / 8;
+  int maxch = a->HW / (8 * g.rows_par > 32 ? 8 * g.rows_par : 32);   // >= 8 pixels per thread row, >= 32 px per chunk
   if (nch > maxch) nch = maxch;
   if (nch < 1) nch = 1;
   g.ppc = (a->HW + nch - 1) / nch;
@@ -50,7 +50,17 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
     for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
       f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
       const float* xb = x + ((long)b * g.HW) * g.C + cq * 4;
-      for (int p = p0 + prow; p < p1; p += g.rows_par) {
+      int p = p0 + prow;
+      const int R = g.rows_par;
+      for (; p + 3 * R < p1; p += 4 * R) {      // 4 independent 16-B loads in flight per thread
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + R) * g.C);
+        f32x4 v2 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 2 * R) * g.C);
+        f32x4 v3 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 3 * R) * g.C);
+        s += (v0 + v1) + (v2 + v3);
+        ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
+      }
+      for (; p < p1; p += R) {
         f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
         s += v;
         ss += v * v;
@@ -125,7 +135,23 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
     }
     f32x4 scale = rs * ga, shift = be - mu * scale;
     long base = ((long)b * g.HW) * g.C + c0;
-    for (int p = p0 + prow; p < p1; p += g.rows_par) {
+    int p = p0 + prow;
+    const int R = g.rows_par;
+    for (; p + 3 * R < p1; p += 4 * R) {        // 4 independent 16-B loads in flight per thread
+      f32x4 v[4];
+#pragma unroll
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + base + (long)(p + u * R) * g.C);
+#pragma unroll
+      for (int u = 0; u < 4; ++u) {
+        f32x4 z = v[u] * scale + shift;
+        if (silu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+        }
+        *reinterpret_cast<f32x4*>(y + base + (long)(p + u * R) * g.C) = z;
+      }
+    }
+    for (; p < p1; p += R) {
       f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
       f32x4 z = v * scale + shift;
       if (silu) {
