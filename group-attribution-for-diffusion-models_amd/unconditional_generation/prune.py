@@ -1,0 +1,252 @@
+"""Structural magnitude pruning of a trained UNet2DModel (reference unconditional_generation/prune.py:318-421),
+torch_pruning-free.
+
+The reference hands the model to torch_pruning 1.3.2 (`MagnitudePruner(ch_sparsity=ratio, iterative_steps=1,
+ignored_layers=[conv_out])`, :344-352) and pickles the resulting nn.Module (:416-421).  torch_pruning is not
+installable offline, so the dependency analysis is restated here for the UNet2DModel topology:
+
+  * a *channel space* is a set of tensor dimensions that must keep the same channels: the residual stream of a
+    stage (conv_in / conv2 / conv_shortcut / to_out outputs joined by identity shortcuts and attention
+    residuals), each ResnetBlock2D's internal width (conv1 out + time_emb_proj out + norm2 + conv2 in), the
+    attention q/k width, the attention v width, the two time-embedding widths; consumers (norm1, conv1 in,
+    shortcut in, q/k/v in, down/upsampler in, the slices of the skip concatenation) follow their producer;
+  * importance of a channel = mean over the space's conv / linear weights of the squared L2 norm of the
+    channel's slice, normalised by the space's mean (MagnitudeImportance p=2, group_reduction="mean",
+    normalizer="mean");
+  * spaces that pass through a GroupNorm lose the same number of channels from every norm group, so the
+    widths stay multiples of the group count (128 -> 96, 256 -> 192 at ratio 0.3).
+Deviation kept on purpose: spaces without a GroupNorm (time embedding, attention q/k and v) are cut to the width
+the model constructor derives from `block_out_channels` (4 x width0, stage width) rather than to
+int(w * (1 - ratio)), so the pruned network is described by a plain `unet_config` and its state_dict - the
+checkpoint stores those two instead of a pickled module.  Parity-unpinned."""
+import argparse
+import os
+import sys
+
+import numpy as np
+import torch
+
+_HERE = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+if _HERE not in sys.path:
+    sys.path.insert(0, _HERE)
+
+import src.constants as constants  # noqa: E402
+
+
+def parse_args(argv=None):
+    p = argparse.ArgumentParser(description="Pruning diffusion models")
+    p.add_argument("--load", type=str, default=None, help="directory of the pre-trained model checkpoints")
+    p.add_argument("--dataset", type=str, default=None, choices=constants.DATASET + ["toy2"])
+    p.add_argument("--outdir", type=str, default=constants.OUTDIR)
+    p.add_argument("--opt_seed", type=int, default=42)
+    p.add_argument("--pruning_ratio", type=float, default=0.3)
+    p.add_argument("--pruner", type=str, default="magnitude", choices=["magnitude", "random", "reinit"])
+    p.add_argument("--thr", type=float, default=0.05)
+    p.add_argument("--trained_steps", type=int, default=None)
+    return p.parse_args(argv)
+
+
+def pruned_width(w, ratio, groups):
+    """Channels kept by MagnitudePruner for a space that passes through GroupNorm(groups)."""
+    n_pruned = w - int(w * (1 - ratio))
+    return w - (n_pruned // groups) * groups
+
+
+class Space:
+    """One tied channel dimension: `members` = (param name, dim, offset) with `width` channels each."""
+
+    def __init__(self, name, width, gn_groups=None, target=None):
+        self.name, self.width, self.gn, self.target = name, width, gn_groups, target
+        self.members = []          # every tensor dim that is sliced with this space's kept indices
+        self.scored = []           # subset of members that are conv / linear weights (importance)
+        self.keep = None
+
+    def add(self, param, dim, offset=0, score=False):
+        self.members.append((param, dim, offset))
+        if score:
+            self.scored.append((param, dim, offset))
+
+
+def build_spaces(cfg, ratio=0.0):
+    """Walk the UNet2DModel topology and return the list of channel spaces, each with the width
+    it keeps at `ratio`."""
+    boc = list(cfg["block_out_channels"])
+    G = cfg.get("norm_num_groups", 32)
+    lpb = cfg.get("layers_per_block", 2)
+    spaces = []
+
+    def new(name, width, gn=True, target=None):
+        s = Space(name, width, G if gn else None, target if target is not None else pruned_width(width, ratio, G))
+        spaces.append(s)
+        return s
+
+    temb_target = 4 * pruned_width(boc[0], ratio, G)          # time_embed_dim = 4 * block_out_channels[0]
+    t1 = new("temb_hidden", boc[0] * 4, gn=False, target=temb_target)
+    t2 = new("temb_out", boc[0] * 4, gn=False, target=temb_target)
+    for suffix in ("weight", "bias"):
+        t1.add(f"time_embedding.linear_1.{suffix}", 0, score=suffix == "weight")
+        t2.add(f"time_embedding.linear_2.{suffix}", 0, score=suffix == "weight")
+    t1.add("time_embedding.linear_2.weight", 1, score=True)
+    # the sinusoidal projection has block_out_channels[0] features: linear_1's input follows the new width
+    # (the constructor re-derives the frequencies for the narrower embedding)
+    t0 = new("temb_in", boc[0], gn=False, target=pruned_width(boc[0], ratio, G))
+    t0.add("time_embedding.linear_1.weight", 1, score=True)
+
+    def produce(space, prefix):                      # conv / linear output channels + bias
+        space.add(prefix + ".weight", 0, score=True)
+        space.add(prefix + ".bias", 0)
+
+    def consume(parts, prefix, norm=False):          # parts: [(space, offset)] along the input-channel dim
+        for sp, off in parts:
+            if norm:
+                sp.add(prefix + ".weight", 0, off)
+                sp.add(prefix + ".bias", 0, off)
+            else:
+                sp.add(prefix + ".weight", 1, off, score=True)
+
+    def resnet(prefix, parts, cin, cout):
+        consume(parts, prefix + ".norm1", norm=True)
+        consume(parts, prefix + ".conv1")
+        inner = new(prefix + ".inner", cout)
+        produce(inner, prefix + ".conv1")
+        produce(inner, prefix + ".time_emb_proj")
+        t2.add(prefix + ".time_emb_proj.weight", 1, score=True)
+        consume([(inner, 0)], prefix + ".norm2", norm=True)
+        consume([(inner, 0)], prefix + ".conv2")
+        if cin != cout:
+            out = new(prefix + ".out", cout)
+            consume(parts, prefix + ".conv_shortcut")
+            produce(out, prefix + ".conv_shortcut")
+        else:
+            assert len(parts) == 1
+            out = parts[0][0]
+        produce(out, prefix + ".conv2")
+        return out
+
+    def attention(prefix, stream, c):
+        consume([(stream, 0)], prefix + ".group_norm", norm=True)
+        qk, v = new(prefix + ".qk", c, gn=False), new(prefix + ".v", c, gn=False)
+        for proj, sp in (("to_q", qk), ("to_k", qk), ("to_v", v)):
+            consume([(stream, 0)], f"{prefix}.{proj}")
+            produce(sp, f"{prefix}.{proj}")
+        consume([(v, 0)], prefix + ".to_out.0")
+        produce(stream, prefix + ".to_out.0")
+
+    cur = new("conv_in", boc[0])
+    produce(cur, "conv_in")
+    skips = [(cur, boc[0])]
+    width = boc[0]
+    for i, typ in enumerate(cfg["down_block_types"]):
+        cin, cout = width, boc[i]
+        for j in range(lpb):
+            cur = resnet(f"down_blocks.{i}.resnets.{j}", [(cur, 0)], cin if j == 0 else cout, cout)
+            if typ == "AttnDownBlock2D":
+                attention(f"down_blocks.{i}.attentions.{j}", cur, cout)
+            skips.append((cur, cout))
+        width = cout
+        if i != len(boc) - 1:
+            consume([(cur, 0)], f"down_blocks.{i}.downsamplers.0.conv")
+            cur = new(f"down_blocks.{i}.down", cout)
+            produce(cur, f"down_blocks.{i}.downsamplers.0.conv")
+            skips.append((cur, cout))
+    cur = resnet("mid_block.resnets.0", [(cur, 0)], width, width)
+    if cfg.get("add_attention", True):
+        attention("mid_block.attentions.0", cur, width)
+    cur = resnet("mid_block.resnets.1", [(cur, 0)], width, width)
+    rev = list(reversed(boc))
+    for i, typ in enumerate(cfg["up_block_types"]):
+        cout = rev[i]
+        for j in range(lpb + 1):
+            sk, wk = skips.pop()
+            cur = resnet(f"up_blocks.{i}.resnets.{j}", [(cur, 0), (sk, width)], width + wk, cout)
+            width = cout
+            if typ == "AttnUpBlock2D":
+                attention(f"up_blocks.{i}.attentions.{j}", cur, cout)
+        if i != len(boc) - 1:
+            consume([(cur, 0)], f"up_blocks.{i}.upsamplers.0.conv")
+            cur = new(f"up_blocks.{i}.up", cout)
+            produce(cur, f"up_blocks.{i}.upsamplers.0.conv")
+    consume([(cur, 0)], "conv_norm_out", norm=True)
+    consume([(cur, 0)], "conv_out")                  # conv_out's own output channels are never pruned
+    assert not skips
+    return spaces
+
+
+def channel_scores(space, sd):
+    acc = []
+    for name, dim, off in space.scored:
+        w = sd[name].double()
+        w = w.transpose(0, dim).reshape(w.shape[dim], -1)[off:off + space.width]
+        acc.append(w.pow(2).sum(dim=1))
+    s = torch.stack(acc).mean(dim=0)
+    return (s / s.mean()).numpy()
+
+
+def select_channels(space, sd, target, mode="magnitude", rng=None):
+    score = channel_scores(space, sd) if mode == "magnitude" else rng.rand(space.width)
+    if space.gn:
+        cpg = space.width // space.gn
+        keep_per = target // space.gn
+        keep = []
+        for g in range(space.gn):
+            idx = np.arange(g * cpg, (g + 1) * cpg)
+            order = idx[np.argsort(-score[idx], kind="stable")]
+            keep += sorted(order[:keep_per].tolist())
+        return np.array(keep)
+    return np.sort(np.argsort(-score, kind="stable")[:target])
+
+
+def prune_state_dict(cfg, sd, ratio, mode="magnitude", seed=42):
+    """-> (new unet_config, new state_dict).  Widths of the new config: pruned_width(w, ratio, groups) per stage."""
+    G = cfg.get("norm_num_groups", 32)
+    boc = list(cfg["block_out_channels"])
+    new_boc = [pruned_width(w, ratio, G) for w in boc]
+    rng = np.random.RandomState(seed)
+    spaces = build_spaces(cfg, ratio)
+    plan = {}                                   # param -> {dim: [(offset, width, keep idx)]}
+    for sp in spaces:
+        sp.keep = select_channels(sp, sd, sp.target, mode, rng)
+        for name, dim, off in sp.members:
+            plan.setdefault(name, {}).setdefault(dim, []).append((off, sp.width, sp.keep))
+    out = {}
+    for name, t in sd.items():
+        for dim, parts in plan.get(name, {}).items():
+            parts = sorted(parts, key=lambda p: p[0])
+            assert sum(p[1] for p in parts) == t.shape[dim], (name, dim, t.shape, [(p[0], p[1]) for p in parts])
+            idx = torch.as_tensor(np.concatenate([off + keep for off, _, keep in parts]))
+            t = t.index_select(dim, idx)
+        out[name] = t.contiguous()
+    if cfg.get("attention_head_dim") is not None:
+        raise NotImplementedError("head-grouped q/k/v pruning (CelebA, prune.py:337-342) is not restated yet")
+    return dict(cfg, block_out_channels=new_boc), out
+
+
+def main(args, backend=None):
+    if backend is None:
+        import gad as backend
+    from src.utils import get_max_steps
+    steps = args.trained_steps if args.trained_steps is not None else get_max_steps(args.load)
+    if steps is None:
+        raise ValueError(f"No trained checkpoints found at {args.load}")
+    ck = torch.load(os.path.join(args.load, f"ckpt_steps_{steps:0>8}.pt"), map_location="cpu", weights_only=False)
+    from src.diffusion_utils import dataset_config
+    cfg = dict(ck.get("unet_config") or dataset_config(args.dataset)["unet_config"])
+    sd = {k: v.detach().cpu().contiguous() for k, v in ck["unet"].items()}
+    base = sum(v.numel() for v in sd.values())
+    mode = "magnitude" if args.pruner == "magnitude" else "random"
+    new_cfg, new_sd = prune_state_dict(cfg, sd, args.pruning_ratio, mode, args.opt_seed)
+    model = getattr(backend, new_cfg["_class_name"])(**new_cfg)
+    if args.pruner == "reinit":
+        new_sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}
+    model.load_state_dict(new_sd)                                   # strict: every shape must agree
+    print("#Params: {:.4f} M => {:.4f} M".format(base / 1e6, sum(v.numel() for v in new_sd.values()) / 1e6))
+    tag = f"pruner={args.pruner}_pruning_ratio={args.pruning_ratio}_threshold={args.thr}"
+    outdir = os.path.join(args.outdir, args.dataset, "pruned", "models", tag)
+    os.makedirs(outdir, exist_ok=True)
+    torch.save({"unet": new_sd, "unet_config": new_cfg}, os.path.join(outdir, f"ckpt_steps_{0:0>8}.pt"))
+    print(f"Checkpoint saved at {outdir}")
+    return outdir
+
+
+if __name__ == "__main__":
+    main(parse_args())

@@ -157,3 +157,44 @@ def test_prune_lora_ranks(tmp_path):
     assert sorted(kept_idx) == sorted(np.argsort(sc)[16 - len(kept_idx):].tolist())
     info = pd.read_csv(os.path.join(outdir, "info.csv")).set_index("metric")["value"]
     assert int(info["pruned_lora_params"]) == kept and abs(info["actual_pruning_ratio"] - kept / total) < 1e-4
+
+
+def test_structural_magnitude_pruning(tmp_path):
+    """prune.py restatement: dependency spaces cover every prunable dimension exactly once, widths 128->96 /
+    256->192 at ratio 0.3, the sliced state_dict loads strictly, kept channels are the high-magnitude ones."""
+    from src.ddpm_config import DDPMConfig
+    from unconditional_generation import prune as P
+    cfg = dict(DDPMConfig.cifar100_config["unet_config"])
+    assert P.pruned_width(128, 0.3, 32) == 96 and P.pruned_width(256, 0.3, 32) == 192
+    torch.manual_seed(0)
+    net = OB.UNet2DModel(**cfg)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # make channel 5 of down_blocks.0.resnets.0's internal width tiny and channel 6 huge
+    for name in ("down_blocks.0.resnets.0.conv1.weight", "down_blocks.0.resnets.0.time_emb_proj.weight"):
+        sd[name][5] *= 1e-3
+        sd[name][6] *= 30
+    sd["down_blocks.0.resnets.0.conv2.weight"][:, 5] *= 1e-3
+    sd["down_blocks.0.resnets.0.conv2.weight"][:, 6] *= 30
+    new_cfg, new_sd = P.prune_state_dict(cfg, sd, 0.3)
+    assert new_cfg["block_out_channels"] == [96, 192, 192, 192]
+    small = OB.UNet2DModel(**new_cfg)
+    small.load_state_dict(new_sd)                                        # strict
+    assert sum(v.numel() for v in new_sd.values()) == sum(p.numel() for p in small.parameters())
+    assert new_sd["time_embedding.linear_2.weight"].shape == (384, 384)
+    assert new_sd["up_blocks.2.resnets.2.conv1.weight"].shape == (192, 192 + 96, 3, 3)
+    spaces = {s.name: s for s in P.build_spaces(cfg, 0.3)}
+    inner = spaces["down_blocks.0.resnets.0.inner"]
+    keep = P.select_channels(inner, sd, inner.target)
+    assert 6 in keep and 5 not in keep and len(keep) == 96
+    per_group = np.bincount(keep // 4, minlength=32)                     # 3 of every 4-channel norm group survive
+    assert (per_group == 3).all()
+    y = small(torch.randn(1, 3, 32, 32), torch.tensor([10])).sample
+    assert y.shape == (1, 3, 32, 32) and torch.isfinite(y).all()
+    # end to end through the entry point + the sFT loader
+    mdir = tmp_path / "toy2" / "retrain" / "models" / "full"
+    os.makedirs(mdir)
+    torch.save({"unet": sd, "unet_config": cfg}, mdir / "ckpt_steps_00000010.pt")
+    out = P.main(P.parse_args(["--load", str(mdir), "--dataset", "toy2", "--outdir", str(tmp_path)]), backend=OB)
+    ck = torch.load(os.path.join(out, "ckpt_steps_00000000.pt"), weights_only=False)
+    assert ck["unet_config"]["block_out_channels"] == [96, 192, 192, 192]
+    assert out.endswith("toy2/pruned/models/pruner=magnitude_pruning_ratio=0.3_threshold=0.05")

@@ -353,3 +353,10 @@ def test_ddim_sampling_matches_oracle(ops):
     b = pm(batch_size=2, generator=torch.Generator().manual_seed(3), num_inference_steps=4, output_type="numpy").images
     assert a.shape == b.shape == (2, 32, 32, 3)
     np.testing.assert_allclose(b, a, atol=2e-4)
+
+
+def test_unet_forward_pruned_widths(ops):
+    # widths produced by unconditional_generation/prune.py at ratio 0.3
+    ref, mine, cfg = _models(shrink=dict(block_out_channels=[96, 192, 192, 192]))
+    x, t = rnd(2, 3, 32, 32, seed=1), torch.tensor([3, 700])
+    close(mine(x.to(dev), t.to(dev)).sample, ref(x, t).sample, atol=1e-4)
