@@ -60,6 +60,41 @@ def weight_krsc(w: torch.Tensor) -> torch.Tensor:
 
 
 # ----------------------------------------------------------------------------------
+# gradient sinks: when a parameter lives in a flat gradient buffer (training.flatten_params) its gradient
+# kernels write straight into that slot and autograd receives the slot itself, so there is no per-parameter
+# accumulate kernel and no memset of the flat buffer.  A second gradient for the same parameter within one
+# step is added on top.
+# ----------------------------------------------------------------------------------
+_SINK_EPOCH = [0]        # sinks live on the parameter object: p._gad_sink (view), p._gad_sink_epoch (last write)
+
+
+def begin_backward_step():
+    """Call once per training step before backward(): marks every sink as not yet written."""
+    _SINK_EPOCH[0] += 1
+
+
+def _sink(param):
+    """(destination view or None, first_write flag)"""
+    v = getattr(param, "_gad_sink", None) if param is not None else None
+    if v is None:
+        return None, True
+    first = getattr(param, "_gad_sink_epoch", -1) != _SINK_EPOCH[0]
+    param._gad_sink_epoch = _SINK_EPOCH[0]
+    return v, first
+
+
+def _deliver(param, grad):
+    """Route a freshly computed gradient tensor to the parameter's sink if it has one.  First gradient of the
+    step: copied into the slot and the slot is returned (autograd then adopts it as .grad).  Later gradients
+    are returned as they are - autograd adds them into .grad, which is the slot."""
+    v, first = _sink(param)
+    if v is None or not first:
+        return grad
+    v.copy_(grad)
+    return v
+
+
+# ----------------------------------------------------------------------------------
 # raw contraction launches
 # ----------------------------------------------------------------------------------
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
@@ -167,26 +202,28 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False,
     return dx
 
 
-def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0):
-    """dW with the parameter's logical shape [Cout,Cin,KH,KW] and channels_last storage."""
+def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0, out=None):
+    """dW with the parameter's logical shape [Cout,Cin,KH,KW] and channels_last storage; `out` = a
+    [Cout,Cin,KH,KW] view with that storage to write into (flat gradient slot)."""
     _req(dy, "conv dy")
     _req(x, "conv x")
     Bn, H, W, Cin = x.shape
     Cout, _, KH, KW = w_like.shape
     _, Ho, Wo, _ = dy.shape
-    dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32)
+    dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32) if out is None else weight_krsc(out)
     g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
              tile_hint=tile_hint, splitk_hint=splitk_hint)
     return dwk.permute(0, 3, 1, 2)
 
 
-def colsum_raw(dy2d: torch.Tensor, segments=1):
-    """[S*M, N] -> [S, N] column sums per segment."""
+def colsum_raw(dy2d: torch.Tensor, segments=1, out=None):
+    """[S*M, N] -> [S, N] column sums per segment (`out`: contiguous destination of S*N floats)."""
     lib = _capi.load()
     ws = workspace(dy2d.device)
     rows, N = dy2d.shape
-    out = torch.empty((segments, N), device=dy2d.device, dtype=torch.float32)
+    if out is None:
+        out = torch.empty((segments, N), device=dy2d.device, dtype=torch.float32)
     check(lib.gad_colsum(dy2d.data_ptr(), out.data_ptr(), segments, rows // segments, N, ws.data_ptr(), ws.numel(),
                          _stream()), "gad_colsum")
     return out
@@ -208,10 +245,10 @@ def linear_dgrad_raw(dy2d, w):
     return dx
 
 
-def linear_wgrad_raw(dy2d, x2d):
+def linear_wgrad_raw(dy2d, x2d, out=None):
     M, N = dy2d.shape
     K = x2d.shape[1]
-    dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32)
+    dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32) if out is None else out
     gemm_raw(dy2d, x2d, dw, A_MC, B_MC, N, K, M, N, K, K)
     return dw
 
@@ -219,6 +256,16 @@ def linear_wgrad_raw(dy2d, x2d):
 # ----------------------------------------------------------------------------------
 # autograd functions
 # ----------------------------------------------------------------------------------
+def _param_grad(param, compute):
+    """compute(out) produces the gradient, writing into `out` when given.  With a sink: first gradient of the
+    step goes straight into the slot, later ones are added."""
+    v, first = _sink(param)
+    if v is None or not first:
+        return compute(None)          # later gradients of the step: autograd accumulates them into .grad (= slot)
+    compute(v)
+    return v
+
+
 class Conv2dFn(torch.autograd.Function):
     """y = conv(x) + bias + rowadd[b] (time-embedding add) + residual, all fused in the
     contraction epilogue (ResnetBlock2D / Downsample2D / Upsample2D)."""
@@ -226,6 +273,7 @@ class Conv2dFn(torch.autograd.Function):
     @staticmethod
     def forward(ctx, x, w, bias, rowadd, residual, stride, pad, upsample):
         ctx.save_for_backward(x, w)
+        ctx.bias_ref = bias
         ctx.cfg = (stride, pad, upsample, bias is not None, rowadd is not None, residual is not None)
         return conv2d_fwd_raw(x, w, bias, stride, pad, upsample, rowadd, residual)
 
@@ -236,14 +284,16 @@ class Conv2dFn(torch.autograd.Function):
         dy = dy.contiguous()
         Bn, Ho, Wo, Cout = dy.shape
         dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample) if ctx.needs_input_grad[0] else None
-        dw = conv2d_wgrad_raw(dy, x, w, stride, pad, upsample) if ctx.needs_input_grad[1] else None
+        dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o)) \
+            if ctx.needs_input_grad[1] else None
         db = dr = None
+        b = ctx.bias_ref
         if has_r and ctx.needs_input_grad[3]:
             dr = colsum_raw(dy.view(Bn * Ho * Wo, Cout), segments=Bn)
             if has_b and ctx.needs_input_grad[2]:
-                db = colsum_raw(dr, 1).view(Cout)
+                db = _param_grad(b, lambda o: colsum_raw(dr, 1, out=o).view(Cout))
         elif has_b and ctx.needs_input_grad[2]:
-            db = colsum_raw(dy.view(Bn * Ho * Wo, Cout), 1).view(Cout)
+            db = _param_grad(b, lambda o: colsum_raw(dy.view(Bn * Ho * Wo, Cout), 1, out=o).view(Cout))
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         return dx, dw, db, dr, dres, None, None, None
 
@@ -259,6 +309,7 @@ class LinearFn(torch.autograd.Function):
         x2 = _req(x, "linear x").view(-1, shp[-1])
         ctx.save_for_backward(x2, w)
         ctx.shp = shp
+        ctx.bias_ref = bias
         ctx.flags = (bias is not None, residual is not None)
         r2 = residual.view(-1, w.shape[0]) if residual is not None else None
         return linear_fwd_raw(x2, w, bias, r2).view(*shp[:-1], w.shape[0])
@@ -268,8 +319,9 @@ class LinearFn(torch.autograd.Function):
         x2, w = ctx.saved_tensors
         dy2 = dy.contiguous().view(-1, w.shape[0])
         dx = linear_dgrad_raw(dy2, w).view(ctx.shp) if ctx.needs_input_grad[0] else None
-        dw = linear_wgrad_raw(dy2, x2) if ctx.needs_input_grad[1] else None
-        db = colsum_raw(dy2, 1).view(-1) if (ctx.flags[0] and ctx.needs_input_grad[2]) else None
+        dw = _param_grad(w, lambda o: linear_wgrad_raw(dy2, x2, out=o)) if ctx.needs_input_grad[1] else None
+        db = _param_grad(ctx.bias_ref, lambda o: colsum_raw(dy2, 1, out=o).view(-1)) \
+            if (ctx.flags[0] and ctx.needs_input_grad[2]) else None
         dres = dy if (ctx.flags[1] and ctx.needs_input_grad[3]) else None
         return dx, dw, db, dres
 
@@ -312,7 +364,10 @@ class GroupNormSiluFn(torch.autograd.Function):
         G, eps, silu = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
-        dgamma, dbeta = torch.empty_like(gamma), torch.empty_like(beta)
+        (sg, fg), (sb, fb) = _sink(gamma), _sink(beta)
+        direct_g, direct_b = sg is not None and fg, sb is not None and fb
+        dgamma = sg if direct_g else torch.empty_like(gamma)
+        dbeta = sb if direct_b else torch.empty_like(beta)
         a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
         a.dy, a.dgamma, a.dbeta = dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
         check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
@@ -551,6 +606,7 @@ class LayerNormFn(torch.autograd.Function):
         check(_capi.load().gad_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(),
                                              mean.data_ptr(), rstd.data_ptr(), rows, C_, eps, _stream()), "gad_layernorm_fwd")
         ctx.save_for_backward(x, gamma, mean, rstd)
+        ctx.beta_ref = beta
         return y
 
     @staticmethod
@@ -565,7 +621,7 @@ class LayerNormFn(torch.autograd.Function):
         check(_capi.load().gad_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
                                              rstd.data_ptr(), dgb.data_ptr(), rows, C_, ws.data_ptr(), ws.numel(),
                                              _stream()), "gad_layernorm_bwd")
-        return dx, dgb[:C_], dgb[C_:], None
+        return dx, _deliver(gamma, dgb[:C_]), _deliver(ctx.beta_ref, dgb[C_:]), None
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):

@@ -30,7 +30,9 @@ def flatten_params(params):
             v = view_like(flat)
             v.copy_(p)
             p.data = v
-            p.grad = view_like(gflat)
+            p.grad = None
+            p._gad_sink = view_like(gflat)               # gradient kernels write here directly (ops._sink)
+            p._gad_sink_epoch = -1
             off += sz
     return flat, gflat
 
@@ -165,11 +167,14 @@ class FusedTrainer:
         self.model, self.scheduler, self.ema = model, scheduler, ema
         if params is None:                      # train everything (DDPM); else only `params` (LoRA: base frozen)
             self.flat, self.gflat = model.flatten_parameters() if model._flat is None else model.flat
+            self.params = list(model.parameters())
         else:
             if ema is not None:
                 raise ValueError("EMA over a parameter subset is not used by the reference's LoRA trainer")
-            self.flat, self.gflat = flatten_params(params)
+            self.params = list(params)
+            self.flat, self.gflat = flatten_params(self.params)
         self.base_lr, self.lr_schedule = lr, lr_schedule
+        self._sinks_checked, self._unwritten = False, []
         self.m = torch.zeros_like(self.flat)
         self.v = torch.zeros_like(self.flat)
         self.ema_flat = ema.bind_flat(model) if ema is not None else None
@@ -181,11 +186,19 @@ class FusedTrainer:
 
     def step(self, image_nchw, noise_nchw, timesteps, *model_args):
         model = self.model
-        self.gflat.zero_()
         noisy = self.scheduler.add_noise(image_nchw, noise_nchw, timesteps)
         eps = model(noisy, timesteps, *model_args).sample
         loss, d = ops.mse_fwd_bwd_raw(eps.contiguous(), noise_nchw.contiguous(), grad_scale=self.loss_sign)
+        ops.begin_backward_step()        # every parameter's first gradient of this step overwrites its flat slot
+        for p in self.params:
+            p.grad = None                # (a stale .grad would make autograd add the slot to itself)
         eps.backward(d)
+        if not self._sinks_checked:      # a parameter that got no gradient would keep a stale slot: zero it each step
+            ep = ops._SINK_EPOCH[0]
+            self._unwritten = [p._gad_sink for p in self.params if getattr(p, "_gad_sink_epoch", -1) != ep]
+            self._sinks_checked = True
+        for v in self._unwritten:
+            v.zero_()
         self.optimizer_step()
         self.last_loss = loss
         return loss
