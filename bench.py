@@ -166,10 +166,16 @@ def main():
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
     import torch.distributed as dist
+    backend = os.environ.get("GAD_DIST_BACKEND", "nccl")          # "gloo" only to rehearse the N>1 path on one GPU
+    if os.environ.get("GAD_SHARE_GPU0"):
+        local = 0
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
         torch.cuda.set_device(local)
-        dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        if backend == "nccl":
+            dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
+        else:
+            dist.init_process_group(backend)
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
 
@@ -217,8 +223,10 @@ def main():
         recs = [CoalitionRecord(rank, len(run.loader.x), 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
     # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
     if world > 1:
-        packed = gather_records([r.pack(engine.n_groups) for r in recs], 8 + engine.n_groups, dev)
-        tmax = torch.tensor([dt], device=dev, dtype=torch.float64)
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        packed = gather_records([r.pack(engine.n_groups) for r in recs], 8 + engine.n_groups, cdev)
+        assert len(packed) == world * len(recs)
+        tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
     value = units / (dt / 3600.0)

@@ -90,3 +90,32 @@ def fid_against_dataset(images01, dataset, device, batch_size=512, feature_dims=
         _REF_STATS[key] = feature_stats(compute_features(net, ref, max(batch_size, 256), device))
     mu, sigma = feature_stats(compute_features(net, images01, max(batch_size, 256), device))
     return frechet_distance(mu, sigma, *_REF_STATS[key])
+
+
+def global_scores_against_dataset(images01, dataset, device, batch_size=512, feature_dims=2048, nhood_size=3):
+    """All four global behaviours unlearn.py writes for the CIFAR family (:807-837): fid_value, is, precision,
+    recall - with the seeded stand-in extractor in place of Inception / VGG16 (URL-fetched weights):
+    IS uses the softmax of the first 1000 feature dims as class probabilities, P/R the fp16 features."""
+    import torch
+    from src.attributions.global_scores.inception_score import inception_score_from_probs
+    from src.attributions.global_scores.precision_recall import calc_pr, make_manifold
+    net = _REF_STATS.get("net")
+    if net is None:
+        net = FeatureNet(feature_dims).to(device)
+        _REF_STATS["net"] = net
+    key = ("feats", id(dataset))
+    if key not in _REF_STATS:
+        ref = dataset.device_tensor(device).add_(1).div_(2)
+        _REF_STATS[key] = compute_features(net, ref, max(batch_size, 256), device)
+    ref_f = _REF_STATS[key]
+    gen_f = compute_features(net, images01, max(batch_size, 256), device)
+    fid = frechet_distance(*feature_stats(gen_f), *feature_stats(ref_f))
+    logits = torch.from_numpy(gen_f[:, :1000])
+    is_value = inception_score_from_probs(torch.softmax(logits, dim=1).numpy())
+    m_gen = make_manifold(torch.from_numpy(gen_f).float(), nhood_size, 10000, 10000, device)
+    m_ref = _REF_STATS.get(("manifold", id(dataset)))
+    if m_ref is None:
+        m_ref = make_manifold(torch.from_numpy(ref_f).float(), nhood_size, 10000, 10000, device)
+        _REF_STATS[("manifold", id(dataset))] = m_ref
+    precision, recall = calc_pr(m_gen, m_ref, 10000, 10000, device)
+    return {"fid_value": fid, "is": is_value, "precision": precision, "recall": recall}

@@ -12,8 +12,10 @@ Manifold = namedtuple("Manifold", ["features", "kth"])
 def compute_distance(row_features, col_features, row_batch_size, col_batch_size, device):
     rows = []
     for rb in row_features.split(row_batch_size, dim=0):
-        cols = [torch.cdist(rb.to(device).unsqueeze(0), cb.to(device).unsqueeze(0)).squeeze(0).cpu()
-                for cb in col_features.split(col_batch_size, dim=0)]
+        # distances are accumulated in fp32 and stored in the features' dtype (fp16 in the reference call);
+        # ROCm has no half cdist kernel and an fp16 accumulation would only add noise
+        cols = [torch.cdist(rb.to(device).float().unsqueeze(0), cb.to(device).float().unsqueeze(0)).squeeze(0)
+                .to(rb.dtype).cpu() for cb in col_features.split(col_batch_size, dim=0)]
         rows.append(torch.cat(cols, dim=1))
     return torch.cat(rows, dim=0)
 

@@ -146,8 +146,11 @@ def main(args, backend=None):
     if args.model_behavior == "global":
         print(f"Generating {args.n_samples}...")
         images = generate_images(args, pipeline)
-        info["fid_value"] = backend.fid_against_dataset(images, dataset, device, args.batch_size)
-        print(f"FID score: {info['fid_value']}")
+        if hasattr(backend, "global_scores_against_dataset"):      # fid_value, is, precision, recall (:807-837)
+            info.update(backend.global_scores_against_dataset(images, dataset, device, args.batch_size))
+        else:
+            info["fid_value"] = backend.fid_against_dataset(images, dataset, device, args.batch_size)
+        print("; ".join(f"{k}: {info[k]}" for k in ("fid_value", "precision", "recall", "is") if k in info))
     info.update(total_steps_time=total_steps_time, trained_steps=steps_goal,
                 remaining_idx=np.asarray(remaining_idx).tolist(), removed_idx=np.asarray(removed_idx).tolist(),
                 device=str(device), total_sampling_time=time.time() - t1)

@@ -98,6 +98,7 @@ def test_entry_points_and_sharded_runner_on_gpu(tmp_path, monkeypatch):
     assert unlearn_main.main(u)
     row = json.loads(open(db).readline())
     assert np.isfinite(row["fid_value"]) and len(row["remaining_idx"]) == 64 and row["trained_steps"] == 3
+    assert 0.0 <= row["precision"] <= 1.0 and 0.0 <= row["recall"] <= 1.0 and row["is"] >= 1.0
     # in-process scheduler on the same toy problem
     from gad.coalition import CoalitionEngine, run_sharded
     eng = CoalitionEngine("toy2", device=dev, gd_steps=2, n_samples=16, sample_batch=8, fuse=2, num_inference_steps=5,

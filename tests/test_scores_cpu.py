@@ -45,8 +45,8 @@ def test_precision_recall_bruteforce():
 
     def brute(probe, target):
         ft, fp = target.features, probe.features
-        kth = torch.cdist(ft, ft).float().kthvalue(4, dim=1).values.half()
-        return (torch.cdist(fp, ft) <= kth.unsqueeze(0)).any(1).float().mean().item()
+        kth = torch.cdist(ft.float(), ft.float()).half().float().kthvalue(4, dim=1).values.half()
+        return (torch.cdist(fp.float(), ft.float()).half() <= kth.unsqueeze(0)).any(1).float().mean().item()
     assert abs(p - brute(m_fake, m_real)) < 1e-6 and abs(r - brute(m_real, m_fake)) < 1e-6
     assert 0 < p <= 1 and 0 < r <= 1
     assert calc_pr(m_real, m_real, 64, 90, "cpu") == (1.0, 1.0)
