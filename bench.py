@@ -224,7 +224,7 @@ def main():
     # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
     if world > 1:
         cdev = dev if backend == "nccl" else torch.device("cpu")
-        packed = gather_records([r.pack(engine.n_groups) for r in recs], 8 + engine.n_groups, cdev)
+        packed = gather_records([r.pack(engine.n_groups) for r in recs], CoalitionRecord.NSCALAR + engine.n_groups, cdev)
         assert len(packed) == world * len(recs)
         tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)

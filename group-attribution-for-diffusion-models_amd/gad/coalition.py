@@ -126,23 +126,28 @@ class CoalitionRecord:
     total_sampling_time: float
     trained_steps: int
     remaining_classes: List[int] = field(default_factory=list)
+    inception_score: float = float("nan")
+    precision: float = float("nan")
+    recall: float = float("nan")
 
-    PACK = 8 + 32   # doubles: 8 scalars + class mask (up to 256 contributors as 32 x 8-bit... stored as doubles)
+    NSCALAR = 11        # float64 scalars ahead of the contributor mask in the packed record
 
     def pack(self, n_groups: int) -> torch.Tensor:
-        v = torch.zeros(8 + n_groups, dtype=torch.float64)
-        v[:8] = torch.tensor([self.removal_seed, self.n_remaining, self.n_removed, self.fid_value, self.loss_last,
-                              self.total_steps_time, self.total_sampling_time, self.trained_steps], dtype=torch.float64)
+        v = torch.zeros(self.NSCALAR + n_groups, dtype=torch.float64)
+        v[:self.NSCALAR] = torch.tensor([self.removal_seed, self.n_remaining, self.n_removed, self.fid_value,
+                                         self.loss_last, self.total_steps_time, self.total_sampling_time,
+                                         self.trained_steps, self.inception_score, self.precision, self.recall],
+                                        dtype=torch.float64)
         for c in self.remaining_classes:
-            v[8 + int(c)] = 1.0
+            v[self.NSCALAR + int(c)] = 1.0
         return v
 
     @classmethod
     def unpack(cls, v: torch.Tensor):
-        s = v[:8].tolist()
-        mask = v[8:]
+        s = v[:cls.NSCALAR].tolist()
+        mask = v[cls.NSCALAR:]
         return cls(int(s[0]), int(s[1]), int(s[2]), s[3], s[4], s[5], s[6], int(s[7]),
-                   [i for i in range(mask.numel()) if mask[i] > 0.5])
+                   [i for i in range(mask.numel()) if mask[i] > 0.5], s[8], s[9], s[10])
 
 
 class CoalitionEngine:
@@ -150,7 +155,7 @@ class CoalitionEngine:
 
     def __init__(self, dataset_name="cifar100", device="cuda:0", base_state: Optional[dict] = None,
                  gd_steps: Optional[int] = None, n_samples=10240, sample_batch=32, fuse=16,
-                 num_inference_steps=100, opt_seed=42, by_class=True, preview=True, reference_stats=None,
+                 num_inference_steps=100, opt_seed=42, by_class=True, preview=True,
                  unet_overrides: Optional[dict] = None, feature_dims=2048):
         from src.datasets import create_dataset
         from src.ddpm_config import DDPMConfig
@@ -179,8 +184,9 @@ class CoalitionEngine:
             ema.optimization_step = 10000                   # as after prune_fine_tune (ddpm_config.py:207-215)
             base_state = {"unet": {k: v.clone() for k, v in m.state_dict().items()}, "unet_ema": ema.state_dict()}
         self.base_state = base_state
+        from . import scoring
         self.feature_net = FeatureNet(feature_dims).to(self.device)
-        self.reference_stats = reference_stats
+        scoring._REF_STATS["net"] = self.feature_net          # one extractor for every score of this process
         self.opt_kwargs = dict(self.config["optimizer_config"]["kwargs"])
         self.adamw = self.config["optimizer_config"]["class_name"] == "AdamW"
 
@@ -202,19 +208,10 @@ class CoalitionEngine:
         return FusedTrainer(model, self.train_scheduler, ema, lr=kw.get("lr", 1e-4),
                             weight_decay=kw.get("weight_decay", 0.0), adamw=self.adamw, max_grad_norm=1.0)
 
-    def reference_statistics(self):
-        """mu/sigma of the training set under the feature net (stats.pkl of fid_score.py:42-58)."""
-        if self.reference_stats is None:
-            from .scoring import compute_features, feature_stats
-            x = self.dataset.device_tensor(self.device).add_(1).div_(2)
-            self.reference_stats = feature_stats(compute_features(self.feature_net, x, 512, self.device))
-        return self.reference_stats
-
-    def score(self, images01: torch.Tensor) -> float:
-        from .scoring import compute_features, feature_stats, frechet_distance
-        mu, sigma = feature_stats(compute_features(self.feature_net, images01, 512, self.device))
-        mu_r, sigma_r = self.reference_statistics()
-        return frechet_distance(mu, sigma, mu_r, sigma_r)
+    def score(self, images01: torch.Tensor) -> dict:
+        """fid_value, is, precision, recall (unlearn.py:807-837) under the stand-in feature net."""
+        from .scoring import global_scores_against_dataset
+        return global_scores_against_dataset(images01, self.dataset, self.device, 512, self.feature_net.dims)
 
     # -- the cycle -------------------------------------------------------------------------------
     def run_coalition(self, removal_seed: int, verbose=False) -> CoalitionRecord:
@@ -248,11 +245,13 @@ class CoalitionEngine:
                  output_type="tensor")
         sampler = FusedSampler(model, self.sample_scheduler, self.sample_batch, self.fuse)
         images = sampler.generate(self.n_samples, self.num_inference_steps)
-        fid = self.score(images)
+        sc = self.score(images)
+        fid = sc["fid_value"]
         torch.cuda.synchronize(self.device)
         rec = CoalitionRecord(removal_seed, len(remaining_idx), len(removed_idx), fid, float(loss.item()),
                               total_steps_time, time.time() - t1, steps,
-                              sorted(set(int(self.dataset.targets[i]) for i in remaining_idx)))
+                              sorted(set(int(self.dataset.targets[i]) for i in remaining_idx)),
+                              sc["is"], sc["precision"], sc["recall"])
         if verbose:
             print(f"[coalition {removal_seed}] |S|={rec.n_remaining} train {total_steps_time:.1f}s "
                   f"sample+score {rec.total_sampling_time:.1f}s fid {fid:.4f}", flush=True)
@@ -265,7 +264,8 @@ class CoalitionEngine:
         row = dict(dataset=self.dataset_name, method="gd", removal_dist="shapley", removal_seed=rec.removal_seed,
                    datamodel_alpha=None, exp_name=f"gd_shapley_seed_{rec.removal_seed}", gd_steps=self.gd_steps,
                    opt_seed=self.opt_seed, n_samples=self.n_samples, num_inference_steps=self.num_inference_steps,
-                   model_behavior="global", fid_value=rec.fid_value, total_steps_time=rec.total_steps_time,
+                   model_behavior="global", fid_value=rec.fid_value, precision=rec.precision, recall=rec.recall,
+                   total_steps_time=rec.total_steps_time, **{"is": rec.inception_score},
                    trained_steps=rec.trained_steps, remaining_idx=np.asarray(remaining_idx).tolist(),
                    removed_idx=np.asarray(removed_idx).tolist(), device=str(self.device),
                    total_sampling_time=rec.total_sampling_time)
@@ -318,7 +318,7 @@ def run_sharded(engine: CoalitionEngine, seeds: Sequence[int], db_path: Optional
                     pass
     mine = shard_seeds([s for s in seeds if s not in done], rank, world)
     recs = [engine.run_coalition(s, verbose=verbose) for s in mine]
-    width = 8 + engine.n_groups
+    width = CoalitionRecord.NSCALAR + engine.n_groups
     packed = [r.pack(engine.n_groups) for r in recs]
     if dist_on:
         packed = gather_records(packed, width, engine.device if dist.get_backend() == "nccl" else "cpu")

@@ -65,6 +65,26 @@ def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
     return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
 
 
+def feature_stats_torch(features: torch.Tensor):
+    """float64 mean / unbiased covariance on the tensor's device (np.mean / np.cov(rowvar=False) semantics)."""
+    f = features.double()
+    mu = f.mean(dim=0)
+    d = f - mu
+    return mu, d.T @ d / (f.shape[0] - 1)
+
+
+def frechet_distance_torch(mu1, sigma1, mu2, sigma2):
+    """Same quantity as frechet_distance without the host sqrtm: Tr sqrt(S1 S2) = sum sqrt(eig(S1^1/2 S2 S1^1/2)),
+    two symmetric float64 eigendecompositions on the tensors' device (the score-tail-on-device step of SURVEY
+    section 8f-2; agrees with scipy's sqrtm route to ~1e-9 relative on well-conditioned inputs)."""
+    diff = mu1 - mu2
+    w, v = torch.linalg.eigh(sigma1)
+    root1 = (v * w.clamp_min(0).sqrt()) @ v.T
+    inner = root1 @ sigma2 @ root1
+    ev = torch.linalg.eigvalsh((inner + inner.T) / 2).clamp_min(0)
+    return float(diff @ diff + torch.trace(sigma1) + torch.trace(sigma2) - 2 * ev.sqrt().sum())
+
+
 def compute_features(net: FeatureNet, images: torch.Tensor, batch_size: int, device) -> np.ndarray:
     """images [N,3,H,W] float in [0,1] (host or device) -> float64 [N, dims] (fid_score.py:74-102)."""
     out = np.empty((len(images), net.dims))
@@ -92,30 +112,33 @@ def fid_against_dataset(images01, dataset, device, batch_size=512, feature_dims=
     return frechet_distance(mu, sigma, *_REF_STATS[key])
 
 
+def compute_features_torch(net: FeatureNet, images: torch.Tensor, batch_size: int, device) -> torch.Tensor:
+    """Like compute_features but the [N, dims] fp32 feature matrix stays in HBM."""
+    return torch.cat([net(images[s:s + batch_size].to(device)) for s in range(0, len(images), batch_size)], 0)
+
+
 def global_scores_against_dataset(images01, dataset, device, batch_size=512, feature_dims=2048, nhood_size=3):
     """All four global behaviours unlearn.py writes for the CIFAR family (:807-837): fid_value, is, precision,
     recall - with the seeded stand-in extractor in place of Inception / VGG16 (URL-fetched weights):
-    IS uses the softmax of the first 1000 feature dims as class probabilities, P/R the fp16 features."""
-    import torch
+    IS uses the softmax of the first 1000 feature dims as class probabilities, P/R the fp16 features.
+    Features, float64 moments, the Frechet eigendecompositions and the P/R distance tiles all stay on the
+    device; only the four scalars come back to the host."""
     from src.attributions.global_scores.inception_score import inception_score_from_probs
     from src.attributions.global_scores.precision_recall import calc_pr, make_manifold
     net = _REF_STATS.get("net")
     if net is None:
         net = FeatureNet(feature_dims).to(device)
         _REF_STATS["net"] = net
-    key = ("feats", id(dataset))
+    key = ("dev", id(dataset))
     if key not in _REF_STATS:
         ref = dataset.device_tensor(device).add_(1).div_(2)
-        _REF_STATS[key] = compute_features(net, ref, max(batch_size, 256), device)
-    ref_f = _REF_STATS[key]
-    gen_f = compute_features(net, images01, max(batch_size, 256), device)
-    fid = frechet_distance(*feature_stats(gen_f), *feature_stats(ref_f))
-    logits = torch.from_numpy(gen_f[:, :1000])
-    is_value = inception_score_from_probs(torch.softmax(logits, dim=1).numpy())
-    m_gen = make_manifold(torch.from_numpy(gen_f).float(), nhood_size, 10000, 10000, device)
-    m_ref = _REF_STATS.get(("manifold", id(dataset)))
-    if m_ref is None:
-        m_ref = make_manifold(torch.from_numpy(ref_f).float(), nhood_size, 10000, 10000, device)
-        _REF_STATS[("manifold", id(dataset))] = m_ref
-    precision, recall = calc_pr(m_gen, m_ref, 10000, 10000, device)
+        ref_f = compute_features_torch(net, ref, max(batch_size, 256), device)
+        _REF_STATS[key] = (feature_stats_torch(ref_f), make_manifold(ref_f, nhood_size, 10000, 10000, device))
+    (mu_r, sig_r), m_ref = _REF_STATS[key]
+    gen_f = compute_features_torch(net, images01, max(batch_size, 256), device)
+    mu, sig = feature_stats_torch(gen_f)
+    fid = frechet_distance_torch(mu, sig, mu_r, sig_r)
+    probs = torch.softmax(gen_f[:, :1000].double(), dim=1).cpu().numpy()
+    is_value = inception_score_from_probs(probs)
+    precision, recall = calc_pr(make_manifold(gen_f, nhood_size, 10000, 10000, device), m_ref, 10000, 10000, device)
     return {"fid_value": fid, "is": is_value, "precision": precision, "recall": recall}

@@ -15,7 +15,7 @@ def compute_distance(row_features, col_features, row_batch_size, col_batch_size,
         # distances are accumulated in fp32 and stored in the features' dtype (fp16 in the reference call);
         # ROCm has no half cdist kernel and an fp16 accumulation would only add noise
         cols = [torch.cdist(rb.to(device).float().unsqueeze(0), cb.to(device).float().unsqueeze(0)).squeeze(0)
-                .to(rb.dtype).cpu() for cb in col_features.split(col_batch_size, dim=0)]
+                .to(rb.dtype) for cb in col_features.split(col_batch_size, dim=0)]      # tiles stay on `device`
         rows.append(torch.cat(cols, dim=1))
     return torch.cat(rows, dim=0)
 
@@ -39,6 +39,6 @@ def calc_pr(manifold_1, manifold_2, row_batch_size, col_batch_size, device):
         hits = []
         for pb in probe.features.split(row_batch_size):
             d = compute_distance(pb, target.features, row_batch_size, col_batch_size, device)
-            hits.append((d <= target.kth.unsqueeze(0)).any(dim=1))
+            hits.append((d <= target.kth.to(d.device).unsqueeze(0)).any(dim=1))
         return torch.cat(hits).to(torch.float32).mean().item()
     return covered(manifold_1, manifold_2), covered(manifold_2, manifold_1)

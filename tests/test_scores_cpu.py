@@ -63,3 +63,17 @@ def test_diversity_entropy():
     assert sorted(count) == [10, 10, 10, 10] and abs(ent - 2.0) < 1e-9 and len(set(labels)) == 4
     ent1, count1, *_ = diversity_from_embeddings(ref, gen_uniform[:10], 4)
     assert abs(ent1) < 1e-9 and sorted(count1) == [0, 0, 0, 10]
+
+
+def test_frechet_eigh_route_matches_sqrtm_route():
+    from gad.scoring import feature_stats_torch, frechet_distance_torch
+    rng = np.random.RandomState(3)
+    a = rng.randn(400, 24) @ rng.randn(24, 24) * 0.3
+    b = rng.randn(300, 24) @ rng.randn(24, 24) * 0.3 + 0.2
+    m1, s1 = compute_features_stats(a)
+    m2, s2 = compute_features_stats(b)
+    want = calculate_frechet_distance(m1, s1, m2, s2)
+    t1, t2 = feature_stats_torch(torch.from_numpy(a)), feature_stats_torch(torch.from_numpy(b))
+    np.testing.assert_allclose(t1[1].numpy(), s1, rtol=1e-10, atol=1e-12)
+    got = frechet_distance_torch(t1[0], t1[1], t2[0], t2[1])
+    assert abs(got - want) < 1e-7 * max(1.0, abs(want))

@@ -56,9 +56,9 @@ def test_shard_seeds_partition():
 
 
 def test_record_pack_roundtrip():
-    r = CoalitionRecord(5, 6500, 3500, 12.25, 0.03, 70.5, 161.0, 1000, [0, 3, 19])
+    r = CoalitionRecord(5, 6500, 3500, 12.25, 0.03, 70.5, 161.0, 1000, [0, 3, 19], 1.75, 0.5, 0.25)
     v = r.pack(20)
-    assert v.dtype == torch.float64 and v.numel() == 28
+    assert v.dtype == torch.float64 and v.numel() == CoalitionRecord.NSCALAR + 20
     assert CoalitionRecord.unpack(v) == r
 
 

@@ -10,7 +10,6 @@ out = sys.argv[4]
 t0 = time.time()
 eng = CoalitionEngine("cifar100", device="cuda:0", gd_steps=gd, n_samples=ns)
 print(f"engine ready in {time.time()-t0:.1f}s", flush=True)
-t0 = time.time(); eng.reference_statistics(); torch.cuda.synchronize(); print(f"reference stats {time.time()-t0:.1f}s", flush=True)
 if os.path.exists(out): os.remove(out)
 t0 = time.time()
 recs = run_sharded(eng, list(range(nseeds)), db_path=out, verbose=True)
