@@ -265,6 +265,7 @@ def main():
                                "frac": d["flops"] / d["ms"] / 1e9 / F32_MFMA_PEAK_TF, "traffic": traffic,
                                "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
                                "share_of_step_time": d["ms"] / (dt * 1e3)}
             all_ms = sum(v["ms"] for v in summ.values())
             all_fl = sum(v["flops"] for v in summ.values())

@@ -51,7 +51,8 @@ struct FastDiv {
 };
 
 struct DevArgs {
-  FastDiv fdC, fdKW, fdHoWo, fdWo, fdRpg;
+  FastDiv fdC, fdKW, fdHoWo, fdWo, fdRpg, fdTaps;
+  int kperm, taps;   // kperm: K steps visit (channel chunk, tap) instead of (tap, channel chunk)
   const float* A;
   const float* B;
   float* C;
@@ -495,6 +496,20 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   int kbeg = split * p.ktiles_per_split * BK;
   int kend = min(p.K, kbeg + p.ktiles_per_split * BK);
   int nkt = (kend - kbeg + BK - 1) / BK;
+  // K-step order.  For the conv gathers the natural (tap-major) order walks a workgroup's whole input
+  // footprint once per tap - (rows+2) x W x C floats, tens to hundreds of KB, evicted from L1/L2 between
+  // taps - so every tap re-fetches it through the fabric.  Visiting the KH*KW taps of one 32-channel chunk
+  // back to back keeps the live footprint at (rows+2) x W x 32 floats and the re-reads on chip.  Any order
+  // gives the same sum up to fp32 reassociation.
+  const int kt0 = split * p.ktiles_per_split;
+  auto k0_of = [&](int kt) -> int {
+    if (!p.kperm) return (kt0 + kt) * BK;
+    int j = kt0 + kt;
+    int chunk = p.fdTaps.div(j), tap = j - chunk * p.taps;
+    return tap * p.g.C + chunk * BK;
+  };
+  if (p.kperm) kend = p.K;
+
   AL al;
   BL bl;
   al.setup(p, A, row0, kend);
@@ -532,8 +547,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
     }
   };
   if (nkt > 0) {
-    al.prep(kbeg, ma);
-    bl.prep(kbeg, mb);
+    al.prep(k0_of(0), ma);
+    bl.prep(k0_of(0), mb);
 #pragma unroll
     for (int q = 0; q < AL::NS + BL::NS; ++q) stage_slot(q, lds, lds + A_TILE);
     stage_commit(lds, lds + A_TILE);
@@ -550,7 +565,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
     float* nxt = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
     const float* la = cur;
     const float* lb = cur + A_TILE;
-    const int knext = kbeg + (kt + 1) * BK;   // past the end: k >= kend, every slot reads zeros
+    const int knext = (kt + 1 < nkt) ? k0_of(kt + 1) : p.K;   // past the end: k >= kend, every slot reads zeros
     al.prep(knext, ma);
     bl.prep(knext, mb);
     f32x4 fa[2][TM], fb[2][TN];
@@ -809,6 +824,9 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   d.fdHoWo = make_fastdiv((unsigned)a->g.Ho * a->g.Wo);
   d.fdWo = make_fastdiv(a->g.Wo);
   d.fdRpg = make_fastdiv(a->rows_per_group > 0 ? a->rows_per_group : 1);
+  d.taps = a->g.KH * a->g.KW;
+  d.fdTaps = make_fastdiv(d.taps > 0 ? d.taps : 1);
+  d.kperm = (convA && d.taps > 1 && a->g.C % BK == 0 && !(getenv("GAD_NO_KPERM") && atoi(getenv("GAD_NO_KPERM")))) ? 1 : 0;
   d.alpha = a->alpha;
   d.bias = a->bias; d.rowadd = a->rowadd; d.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
   d.ld_rowadd = a->ld_rowadd; d.residual = a->residual; d.ldr = a->ldr;

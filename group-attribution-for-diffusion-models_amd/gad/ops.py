@@ -133,7 +133,7 @@ class GemmProfiler:
              (A_KC, B_KC): "gemm_nt", (A_KC, B_MC): "gemm_nn", (A_MC, B_MC): "gemm_tn"}
 
     def __init__(self):
-        self.records = []          # (key, flops, start_event, end_event)
+        self.records = []          # (key, flops, algorithmic bytes, start_event, end_event)
 
     def gemm(self, lib, a, batch):
         tile, sk, vec = C.c_int32(), C.c_int32(), C.c_int32()
@@ -143,16 +143,26 @@ class GemmProfiler:
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
         key = (self.NAMES.get((a.a_mode, a.b_mode), "gemm"), tile.value, sk.value, vec.value)
-        self.records.append((key, 2.0 * a.M * a.N * a.K * max(1, batch), s, e))
+        # algorithmic bytes: every operand once (gathered tensor, not its im2col expansion) + the output
+        g = a.g
+        if a.a_mode in (A_CONV, A_CONVT):
+            a_elems = (a.M // max(1, g.Ho * g.Wo)) * g.H * g.W * g.C
+        else:
+            a_elems = a.M * a.K
+        b_elems = (a.K // max(1, g.Ho * g.Wo)) * g.H * g.W * g.C if a.b_mode == B_CONV else a.N * a.K
+        extra = a.M * a.N if a.residual else 0
+        nbytes = 4.0 * max(1, batch) * (a_elems + b_elems + a.M * a.N + extra)
+        self.records.append((key, 2.0 * a.M * a.N * a.K * max(1, batch), nbytes, s, e))
 
     def summary(self):
         """{key: dict(launches, ms, flops)} - call after a device synchronize."""
         out = {}
-        for key, fl, s, e in self.records:
-            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0))
+        for key, fl, nb, s, e in self.records:
+            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
+            d["bytes"] += nb
         return out
 
 
