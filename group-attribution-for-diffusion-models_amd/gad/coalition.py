@@ -46,9 +46,11 @@ class DeviceLoader:
     index_select views; RandomHorizontalFlip is applied per sample on the device.  The last batch
     of an epoch is short (drop_last=False), as in the reference (unlearn.py:373-379)."""
 
-    def __init__(self, dataset, idx: Sequence[int], batch_size: int, device, flip=True):
+    def __init__(self, dataset, idx: Sequence[int], batch_size: int, device, flip=None):
         self.x = dataset.device_tensor(device, idx)             # [n,3,H,W] in [-1,1]
         self.labels = torch.as_tensor([dataset.targets[i] for i in idx], device=device)
+        if flip is None:                                        # the dataset's own transform chain decides (datasets.py:412-477)
+            flip = bool(getattr(dataset, "flip", True))
         self.bs, self.flip, self.device = batch_size, flip, device
 
     def __len__(self):

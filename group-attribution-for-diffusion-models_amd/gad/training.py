@@ -37,6 +37,58 @@ def flatten_params(params):
     return flat, gflat
 
 
+def flat_views(params, buf):
+    """Logical-shape views of `buf` (a flat buffer laid out by flatten_params) for each parameter, in order."""
+    off = 0
+    for p in params:
+        n = p.numel()
+        if p.ndim == 4:
+            o, i, kh, kw = p.shape
+            yield buf[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
+        else:
+            yield buf[off:off + n].view(p.shape)
+        off += (n + 3) // 4 * 4
+
+
+def adam_state_to_torch(params, m, v, step, hp):
+    """Flat Adam moments -> the dict ``torch.optim.Adam(W).state_dict()`` produces (the `optimizer` entry of the
+    reference's ckpt_steps_*.pt, main.py:827-840), so either side can resume the other's checkpoint."""
+    params = list(params)
+    state = {i: {"step": torch.tensor(float(step)), "exp_avg": a.detach().cpu().contiguous(),
+                 "exp_avg_sq": b.detach().cpu().contiguous()}
+             for i, (a, b) in enumerate(zip(flat_views(params, m), flat_views(params, v)))} if step > 0 else {}
+    group = {"lr": hp["lr"], "betas": tuple(hp["betas"]), "eps": hp["eps"], "weight_decay": hp["weight_decay"],
+             "amsgrad": False, "maximize": False, "foreach": None, "capturable": False, "differentiable": False,
+             "fused": None, "params": list(range(len(params)))}
+    return {"state": state, "param_groups": [group]}
+
+
+def adam_state_from_torch(sd, params, m, v):
+    """Inverse of adam_state_to_torch: fills the flat m / v in place and returns the step count.  Also accepts the
+    flat layout earlier builds of this engine wrote ({"step","exp_avg","exp_avg_sq"})."""
+    if "state" not in sd:
+        m.copy_(sd["exp_avg"].to(m.device))
+        v.copy_(sd["exp_avg_sq"].to(v.device))
+        return int(sd["step"])
+    params = list(params)
+    ids = [i for g in sd["param_groups"] for i in g["params"]]
+    if len(ids) != len(params):
+        raise ValueError(f"optimizer state covers {len(ids)} parameters, the model has {len(params)}")
+    step = 0
+    m.zero_()
+    v.zero_()
+    for i, a, b, p in zip(ids, flat_views(params, m), flat_views(params, v), params):
+        st = sd["state"].get(i)
+        if st is None:
+            continue
+        if tuple(st["exp_avg"].shape) != tuple(p.shape):
+            raise ValueError(f"optimizer state {i}: shape {tuple(st['exp_avg'].shape)} != parameter {tuple(p.shape)}")
+        a.copy_(st["exp_avg"].to(m.device))
+        b.copy_(st["exp_avg_sq"].to(v.device))
+        step = max(step, int(float(st["step"])))
+    return step
+
+
 def lr_lambda(name, num_training_steps, num_warmup_steps=0):
     """diffusers.optimization.get_scheduler multipliers used by the reference: "constant" (main.py) and
     "cosine" (text_to_image LoRA trainer, ddpm_config.py:637); SURVEY A.12."""
@@ -218,11 +270,9 @@ class FusedTrainer:
         return self._sumsq.sqrt()
 
     def state_dict(self):
-        """Optimizer state in the flat layout (the `optimizer` entry of ckpt_steps_*.pt, main.py:827-840)."""
-        return {"step": self.step_count, "exp_avg": self.m.detach().cpu(), "exp_avg_sq": self.v.detach().cpu(),
-                "hyper": dict(self.hp)}
+        """Optimizer state in torch.optim.Adam's own state_dict format (the `optimizer` entry of
+        ckpt_steps_*.pt, main.py:827-840): the reference can resume it and vice versa."""
+        return adam_state_to_torch(self.params, self.m, self.v, self.step_count, self.hp)
 
     def load_state_dict(self, sd):
-        self.step_count = int(sd["step"])
-        self.m.copy_(sd["exp_avg"].to(self.m.device))
-        self.v.copy_(sd["exp_avg_sq"].to(self.v.device))
+        self.step_count = adam_state_from_torch(sd, self.params, self.m, self.v)

@@ -83,6 +83,129 @@ def synthetic_images(n, size, channels, n_cls, per_class_seed=1234):
     return out, labels
 
 
+# ---- torchvision-free readers of the on-disk formats the reference's torchvision classes consume ----
+CIFAR20_CLASSES = [40, 41, 42, 43, 44, 55, 56, 57, 58, 59, 60, 61, 62, 63, 64, 80, 81, 82, 83, 84]  # :80-105
+
+
+def read_cifar_python(root: str, kind: str, train: bool):
+    """The "python version" CIFAR archives as torchvision lays them out under `root`
+    (cifar-10-batches-py/{data_batch_1..5,test_batch}, key `labels`; cifar-100-python/{train,test}, key
+    `fine_labels`): rows are 3072 uint8 in CHW plane order -> ([N,32,32,3] uint8, labels)."""
+    import pickle
+    if kind == "cifar10":
+        base, files, key = "cifar-10-batches-py", ([f"data_batch_{i}" for i in range(1, 6)] if train else ["test_batch"]), "labels"
+    elif kind == "cifar100":
+        base, files, key = "cifar-100-python", (["train"] if train else ["test"]), "fine_labels"
+    else:
+        raise ValueError(kind)
+    data, labels = [], []
+    for f in files:
+        path = os.path.join(root, base, f)
+        if not os.path.exists(path):
+            raise FileNotFoundError(f"{path} is missing (the reference downloads it; there is no network here)")
+        with open(path, "rb") as fh:
+            entry = pickle.load(fh, encoding="latin1")
+        data.append(np.asarray(entry["data"], dtype=np.uint8))
+        labels += list(entry[key])
+    data = np.vstack(data).reshape(-1, 3, 32, 32).transpose(0, 2, 3, 1)
+    return np.ascontiguousarray(data), [int(t) for t in labels]
+
+
+def _keep_classes(data, labels, classes_to_keep):
+    """CIFAR2 (:46-56) / CIFAR100_original (:108-118): keep the listed classes, relabel by list position."""
+    keep = [i for i, t in enumerate(labels) if t in classes_to_keep]
+    return data[keep], [classes_to_keep.index(labels[i]) for i in keep]
+
+
+def _cifar100_filter(data, labels):
+    """CIFAR100_filter.filter_data (:294-309): the first 2*(c+1) samples of class c, labels unchanged."""
+    cap = np.arange(1, 101) * 2
+    count = np.zeros(100, dtype=int)
+    keep = []
+    for i, t in enumerate(labels):
+        if count[t] < cap[t]:
+            keep.append(i)
+            count[t] += 1
+    return data[keep], [labels[i] for i in keep]
+
+
+def read_mnist_idx(root: str, train: bool):
+    """torchvision's MNIST/raw idx files, resized 28->32 bilinear through PIL as transforms.Resize does (:471-477)."""
+    import gzip
+    from PIL import Image
+    stem = "train" if train else "t10k"
+
+    def load(name):
+        for cand in (os.path.join(root, "MNIST", "raw", name), os.path.join(root, "MNIST", "raw", name + ".gz")):
+            if os.path.exists(cand):
+                with (gzip.open if cand.endswith(".gz") else open)(cand, "rb") as fh:
+                    return fh.read()
+        raise FileNotFoundError(os.path.join(root, "MNIST", "raw", name))
+
+    img = np.frombuffer(load(f"{stem}-images-idx3-ubyte"), dtype=np.uint8, offset=16).reshape(-1, 28, 28)
+    lab = np.frombuffer(load(f"{stem}-labels-idx1-ubyte"), dtype=np.uint8, offset=8)
+    out = np.stack([np.asarray(Image.fromarray(x).resize((32, 32), Image.BILINEAR)) for x in img])[..., None]
+    return out, [int(t) for t in lab]
+
+
+class LatentDataset(torch.utils.data.Dataset):
+    """CelebA-HQ in `--precompute_stage reuse` mode (main.py:531-546,675-680): rows of labels.csv (columns
+    `filename`, `celeb`; :319-325) joined with the VQ-VAE latent dictionary `{filename: [3,64,64] float}` stored
+    at {outdir}/{dataset}/precomputed_emb/vqvae_output.pt.  Items are (latent, celeb, filename) like the
+    reference's CelebA.__getitem__ (:338-345) with the image already encoded."""
+
+    def __init__(self, labels_csv: str, latent_file: str):
+        import pandas as pd
+        df = pd.read_csv(labels_csv)
+        assert df["filename"].nunique() == len(df), "filename should be unique"
+        self.filenames = df["filename"].tolist()
+        self.targets = [int(c) for c in df["celeb"].tolist()]
+        lat = torch.load(latent_file, map_location="cpu", weights_only=True)
+        missing = [f for f in self.filenames if f not in lat]
+        if missing:
+            raise KeyError(f"{len(missing)} files of {labels_csv} have no latent in {latent_file}, e.g. {missing[:3]}")
+        self.latents = torch.stack([lat[f].float() for f in self.filenames])
+
+    def __len__(self):
+        return len(self.filenames)
+
+    def __getitem__(self, i):
+        return self.latents[i], self.targets[i], self.filenames[i]
+
+    @property
+    def labels(self):
+        return self.targets
+
+    def device_tensor(self, device, idx=None):
+        x = self.latents if idx is None else self.latents[torch.as_tensor(np.asarray(idx), dtype=torch.long)]
+        return x.to(device)
+
+    flip = False
+
+
+def _real_dataset(dataset_name, train, dataset_dir):
+    """GAD_DATA=real: the same directories the reference reads (:412-512), no download."""
+    if dataset_name == "cifar":
+        return ArrayDataset(*read_cifar_python(os.path.join(dataset_dir, "cifar"), "cifar10", train), train=train)
+    if dataset_name == "cifar2":
+        d, l = read_cifar_python(os.path.join(dataset_dir, "cifar2"), "cifar10", train)
+        return ArrayDataset(*_keep_classes(d, l, [1, 7]), train=train)
+    if dataset_name == "cifar100":
+        d, l = read_cifar_python(os.path.join(dataset_dir, "cifar100"), "cifar100", train)
+        return ArrayDataset(*_keep_classes(d, l, CIFAR20_CLASSES), train=train)
+    if dataset_name == "cifar100_f":
+        d, l = read_cifar_python(os.path.join(dataset_dir, "cifar100"), "cifar100", train)
+        return ArrayDataset(*_cifar100_filter(d, l), train=train)
+    if dataset_name == "mnist":
+        return ArrayDataset(*read_mnist_idx(os.path.join(dataset_dir, "mnist"), train), train=train, flip=False)
+    if dataset_name == "celeba":
+        root = os.path.join(dataset_dir, "celeba_hq_256_50_resized")
+        lat = os.environ.get("GAD_LATENTS", os.path.join(constants.OUTDIR, "celeba", "precomputed_emb", "vqvae_output.pt"))
+        return LatentDataset(os.path.join(root, "labels.csv"), lat)
+    raise ValueError(f"dataset_name={dataset_name}: no local reader (cifar100_new needs a pretrained resnet18, "
+                     "imagenette an image decoder pipeline; both are off the attribution path)")
+
+
 _SYNTH_SPECS = {
     # name: (n_train, n_test, size, channels, n_classes)  -- cardinalities of the reference datasets
     "cifar": (50000, 10000, 32, 3, 10),
@@ -99,9 +222,9 @@ def create_dataset(dataset_name: str, train: bool, dataset_dir: str = None) -> t
     dataset_dir = dataset_dir or constants.DATASET_DIR
     real = os.path.join(dataset_dir, dataset_name, "train.npz" if train else "test.npz")
     if os.environ.get("GAD_DATA", "synthetic") == "real":
-        if not os.path.exists(real):
-            raise FileNotFoundError(f"GAD_DATA=real but {real} is missing")
-        return ArrayDataset.from_npz(real, train=train)
+        if os.path.exists(real):
+            return ArrayDataset.from_npz(real, train=train)
+        return _real_dataset(dataset_name, train, dataset_dir)
     if dataset_name not in _SYNTH_SPECS:
         raise ValueError(f"dataset_name={dataset_name} should be one of {sorted(_SYNTH_SPECS)} "
                          "(celeba / imagenette need local files: GAD_DATA=real)")

@@ -98,6 +98,10 @@ def main(args, backend=None):
         import gad as backend
     if args.mixed_precision != "no" or args.use_8bit_optimizer or args.gradient_accumulation_steps != 1:
         raise NotImplementedError("the MI355X engine runs the reference default: fp32, Adam(W), no accumulation")
+    if args.dataset == "celeba" and args.precompute_stage != "reuse":
+        # :486-530 encode with the hub-fetched CompVis/ldm-celebahq-256 VQ-VAE; only the latent path is on the card
+        raise NotImplementedError("celeba trains on precomputed VQ-VAE latents: pass --precompute_stage reuse with "
+                                  "{outdir}/celeba/precomputed_emb/vqvae_output.pt (or GAD_LATENTS) in place")
     device = torch.device(args.device)
     config = dataset_config(args.dataset)
     removal_dir = removal_directory(args)

@@ -198,3 +198,35 @@ def test_structural_magnitude_pruning(tmp_path):
     ck = torch.load(os.path.join(out, "ckpt_steps_00000000.pt"), weights_only=False)
     assert ck["unet_config"]["block_out_channels"] == [96, 192, 192, 192]
     assert out.endswith("toy2/pruned/models/pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
+
+
+def test_artbench_metadata_to_latent_cache(tmp_path):
+    """metadata.csv / {style}_artists.csv grammar of the reference (create_metadata.py:77-95,113-114) joined with
+    precomputed latents into the trainer's latent cache."""
+    import pandas as pd
+    import torch
+    from text_to_image.artbench.metadata import assemble_latent_cache, read_metadata, unit_table
+    rows = []
+    for style, n in (("post_impressionism", 5), ("ukiyo_e", 3)):
+        for i in range(n):
+            f = f"{style}/artist-{i % 2}_work-{i}.jpg"
+            rows.append({"file_name": f, "caption": f"a {style} painting", "artist": f"artist-{i % 2}", "style": style,
+                         "filename": f})
+    pd.DataFrame(rows).to_csv(tmp_path / "metadata.csv", index=False)
+    pd.DataFrame({"artist": ["artist-0", "artist-1"]}).to_csv(tmp_path / "post_impressionism_artists.csv", index=False)
+    assert len(read_metadata(str(tmp_path))) == 8
+    assert len(read_metadata(str(tmp_path), "style", "post_impressionism")) == 5
+    assert unit_table(str(tmp_path), "post_impressionism", "artist")["artist"].tolist() == ["artist-0", "artist-1"]
+    lat = {r["file_name"]: torch.full((4, 2, 2), float(k)) for k, r in enumerate(rows)}
+    cache = assemble_latent_cache(str(tmp_path), lat, torch.ones(77, 8), cls="post_impressionism")
+    assert cache["latents"].shape == (5, 4, 2, 2) and cache["latents"][:, 0, 0, 0].tolist() == [0., 1., 2., 3., 4.]
+    assert cache["text_emb"].shape == (1, 77, 8) and cache["artist"] == ["artist-0", "artist-1"] * 2 + ["artist-0"]
+    back = torch.load(tmp_path / "latent_cache.pt", weights_only=False)
+    assert back["filename"] == cache["filename"]
+    per_caption = assemble_latent_cache(str(tmp_path), lat, {"a ukiyo_e painting": torch.zeros(77, 8)}, cls="ukiyo_e",
+                                        out=str(tmp_path / "u.pt"))
+    assert per_caption["text_emb"].shape == (3, 77, 8)
+    del lat[rows[0]["file_name"]]
+    import pytest
+    with pytest.raises(KeyError):
+        assemble_latent_cache(str(tmp_path), lat, torch.ones(77, 8), cls="post_impressionism")

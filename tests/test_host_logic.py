@@ -125,3 +125,90 @@ def test_synthetic_cifar20_shape():
     assert len(d) == 200 and len(set(d.targets)) == 20
     x, y = d[0]
     assert x.shape == (3, 32, 32) and x.min() >= -1 and x.max() <= 1 and y == 0
+
+
+def test_optimizer_state_round_trips_through_torch_adam():
+    """ckpt_steps_*.pt `optimizer` entry (reference main.py:827-840) = torch.optim.Adam.state_dict(): the flat
+    moments must import from it and export a dict torch.optim.Adam itself accepts, conv weights included
+    (flat storage is [Cout,KH,KW,Cin], the state dict is logical [Cout,Cin,KH,KW])."""
+    import torch
+    from gad.training import adam_state_from_torch, adam_state_to_torch, flat_views
+
+    torch.manual_seed(0)
+    net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Flatten(), torch.nn.Linear(5 * 36, 7))
+    params = list(net.parameters())
+    opt = torch.optim.Adam(params, lr=1e-3)
+    for _ in range(3):
+        opt.zero_grad()
+        net(torch.randn(2, 3, 8, 8)).square().mean().backward()
+        opt.step()
+    sd = opt.state_dict()
+    total = sum((p.numel() + 3) // 4 * 4 for p in params)
+    m, v = torch.full((total,), 9.0), torch.full((total,), 9.0)
+    assert adam_state_from_torch(sd, params, m, v) == 3
+    for i, (a, b) in enumerate(zip(flat_views(params, m), flat_views(params, v))):
+        assert torch.equal(a, sd["state"][i]["exp_avg"]) and torch.equal(b, sd["state"][i]["exp_avg_sq"])
+    # conv moments really are stored tap-major / channel-minor in the flat buffer
+    assert torch.equal(m[:5 * 27].view(5, 3, 3, 3), sd["state"][0]["exp_avg"].permute(0, 2, 3, 1))
+    back = adam_state_to_torch(params, m, v, 3, dict(lr=1e-3, betas=(0.9, 0.999), eps=1e-8, weight_decay=0.0))
+    opt2 = torch.optim.Adam(params, lr=1e-3)
+    opt2.load_state_dict(back)                                   # torch accepts the exported dict
+    for i in range(len(params)):
+        assert torch.equal(opt2.state[params[i]]["exp_avg"], opt.state[params[i]]["exp_avg"])
+        assert float(opt2.state[params[i]]["step"]) == 3.0
+    # legacy flat layout still loads
+    m2, v2 = torch.zeros(total), torch.zeros(total)
+    assert adam_state_from_torch({"step": 3, "exp_avg": m, "exp_avg_sq": v}, params, m2, v2) == 3 and torch.equal(m2, m)
+    with pytest.raises(ValueError):
+        adam_state_from_torch(sd, params[:-1], m, v)
+
+
+def test_real_data_readers(tmp_path, monkeypatch):
+    """torchvision-free readers of the archives the reference's dataset classes consume
+    (reference src/datasets.py:22-118,294-309,412-477) on miniature files in the same on-disk format."""
+    import pickle
+    import torch
+    rng = np.random.RandomState(0)
+    root = tmp_path / "datasets"
+    c100 = root / "cifar100" / "cifar-100-python"
+    c100.mkdir(parents=True)
+    labels = [int(t) for t in rng.randint(0, 100, size=600)]
+    rows = rng.randint(0, 256, size=(600, 3072)).astype(np.uint8)
+    with open(c100 / "train", "wb") as f:
+        pickle.dump({"data": rows, "fine_labels": labels, "coarse_labels": [0] * 600}, f)
+    c10 = root / "cifar2" / "cifar-10-batches-py"
+    c10.mkdir(parents=True)
+    l10 = [int(t) for t in rng.randint(0, 10, size=50)]
+    for i in range(1, 6):
+        with open(c10 / f"data_batch_{i}", "wb") as f:
+            pickle.dump({"data": rows[10 * (i - 1):10 * i], "labels": l10[10 * (i - 1):10 * i]}, f)
+    monkeypatch.setenv("GAD_DATA", "real")
+    d = ds.create_dataset("cifar100", train=True, dataset_dir=str(root))
+    keep = [i for i, t in enumerate(labels) if t in ds.CIFAR20_CLASSES]
+    assert len(d) == len(keep) and d.targets == [ds.CIFAR20_CLASSES.index(labels[i]) for i in keep]
+    # CHW planes -> HWC pixels: pixel (y,x) channel c of row r is rows[r, c*1024 + y*32 + x]
+    assert d.data[3, 5, 7, 2] == rows[keep[3], 2 * 1024 + 5 * 32 + 7]
+    x, y = d[0]
+    assert x.shape == (3, 32, 32) and float(x.min()) >= -1 and float(x.max()) <= 1 and y == d.targets[0]
+    f = ds.create_dataset("cifar100_f", train=True, dataset_dir=str(root))
+    cnt = np.bincount(f.targets, minlength=100)
+    full = np.bincount(labels, minlength=100)
+    assert (cnt == np.minimum(full, 2 * np.arange(1, 101))).all()
+    c2 = ds.create_dataset("cifar2", train=True, dataset_dir=str(root))
+    assert c2.targets == [[1, 7].index(t) for t in l10 if t in (1, 7)]
+    with pytest.raises(FileNotFoundError):
+        ds.create_dataset("cifar", train=True, dataset_dir=str(root))
+    # CelebA in precompute "reuse" mode: labels.csv joined with the latent dictionary
+    import pandas as pd
+    cel = root / "celeba_hq_256_50_resized"
+    cel.mkdir()
+    names = [f"{i:05d}.jpg" for i in range(6)]
+    pd.DataFrame({"filename": names, "celeb": [3, 3, 1, 0, 1, 2]}).to_csv(cel / "labels.csv", index=False)
+    lat = {n: torch.full((3, 4, 4), float(i)) for i, n in enumerate(names)}
+    torch.save(lat, tmp_path / "vqvae_output.pt")
+    monkeypatch.setenv("GAD_LATENTS", str(tmp_path / "vqvae_output.pt"))
+    L = ds.create_dataset("celeba", train=True, dataset_dir=str(root))
+    assert len(L) == 6 and L.targets == [3, 3, 1, 0, 1, 2] and L[4][2] == "00004.jpg" and float(L[4][0].mean()) == 4.0
+    assert L.device_tensor("cpu", [5, 0]).flatten(1).mean(1).tolist() == [5.0, 0.0] and L.flip is False
+    remaining, removed = ds.remove_data_by_shapley(L, seed=1, by_class=True)
+    assert len(remaining) + len(removed) == 6
