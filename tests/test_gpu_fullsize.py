@@ -1,0 +1,121 @@
+"""Parity at BASELINE.json's full sizes through size-independent properties (the CPU oracle would take minutes to
+hours there): linearity, invariance to the tiling / split-K / K-step order the planner may pick, a spot check of
+sampled output pixels against an fp64 dot product, adjointness of dgrad / wgrad, run-to-run bit-exactness of a whole
+training step, and the fused sampler at the bench's launch width against per-batch launches."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+@pytest.fixture(scope="module")
+def ops():
+    from gad import ops as o
+    return o
+
+
+def _conv_case(Cin, Cout, B=512, H=32):
+    g = torch.Generator(device=dev).manual_seed(Cin * 7 + Cout)
+    x = torch.randn(B, H, H, Cin, device=dev, generator=g)
+    w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * (Cin * 9) ** -0.5
+    b = torch.randn(Cout, device=dev, generator=g)
+    return x, w.contiguous(memory_format=torch.channels_last), b
+
+
+@pytest.mark.parametrize("Cin,Cout", [(128, 128), (256, 128)])
+def test_conv_fwd_full_size_properties(ops, Cin, Cout):
+    """B=512 (16 fused reference batches) x 32x32: the dominant launch of the sampler."""
+    x, w, b = _conv_case(Cin, Cout)
+    y = ops.conv2d_fwd_raw(x, w, b)
+    # (1) spot check 64 output pixels x all channels against an fp64 dot product over the 3x3xCin patch
+    gi = torch.Generator().manual_seed(0)
+    xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
+    wk = w.permute(0, 2, 3, 1).double()                                    # [Cout,3,3,Cin]
+    for n, i, j in zip(torch.randint(0, 512, (64,), generator=gi).tolist(), torch.randint(0, 32, (64,), generator=gi).tolist(),
+                       torch.randint(0, 32, (64,), generator=gi).tolist()):
+        patch = xp[n, i:i + 3, j:j + 3, :].double()
+        ref = (wk * patch[None]).sum((1, 2, 3)) + b.double()
+        assert torch.allclose(y[n, i, j].double(), ref, atol=2e-5 * (9 * Cin) ** 0.5), (n, i, j)
+    # (2) the plan does not change the result beyond fp32 summation order: tile 64, split-K 2, tap-major K order
+    tol = 2e-5 * (9 * Cin) ** 0.5
+    assert (ops.conv2d_fwd_raw(x, w, b, tile_hint=64) - y).abs().max().item() < tol
+    assert (ops.conv2d_fwd_raw(x, w, b, splitk_hint=2) - y).abs().max().item() < tol
+    os.environ["GAD_NO_KPERM"] = "1"
+    try:
+        y_tapmajor = ops.conv2d_fwd_raw(x, w, b)
+    finally:
+        del os.environ["GAD_NO_KPERM"]
+    assert (y_tapmajor - y).abs().max().item() < tol
+    # (3) determinism: the same launch twice is bit-identical
+    assert torch.equal(ops.conv2d_fwd_raw(x, w, b), y)
+    # (4) linearity in x (bias removed): conv(2x - 3x') = 2 conv(x) - 3 conv(x')
+    x2 = torch.randn_like(x)
+    lhs = ops.conv2d_fwd_raw(2 * x - 3 * x2, w, None)
+    rhs = 2 * ops.conv2d_fwd_raw(x, w, None) - 3 * ops.conv2d_fwd_raw(x2, w, None)
+    assert (lhs - rhs).abs().max().item() < 4 * tol
+
+
+def test_conv_backward_adjoint_full_size(ops):
+    """<dy, conv(x)> = <dgrad(dy), x> = <wgrad(x,dy), w> at the training batch (B=128, 256->256 @16x16 and
+    128->128 @32x32): the three kernels are mutually consistent without an oracle."""
+    for Cin, Cout, H in ((256, 256, 16), (128, 128, 32)):
+        x, w, _ = _conv_case(Cin, Cout, B=128, H=H)
+        dy = torch.randn(128, H, H, Cout, device=dev)
+        y = ops.conv2d_fwd_raw(x, w, None)
+        dx = ops.conv2d_dgrad_raw(dy, w, x.shape)
+        dw = ops.conv2d_wgrad_raw(dy, x, w)
+        a = (dy.double() * y.double()).sum()
+        bb = (dx.double() * x.double()).sum()
+        c = (dw.double() * w.double()).sum()
+        scale = (dy.double().square().sum() * y.double().square().sum()).sqrt()
+        assert abs(a - bb) / scale < 1e-6 and abs(a - c) / scale < 1e-6, (Cin, H, float(a), float(bb), float(c))
+
+
+def test_training_step_is_bit_reproducible_at_full_size():
+    """Full CIFAR U-Net (35.7 M parameters), B=128: two engines from the same seed give bit-identical losses,
+    weights, Adam moments and EMA after 2 steps (every reduction in the path is order-deterministic)."""
+    import gad
+    from src.ddpm_config import DDPMConfig
+    cfg = DDPMConfig.cifar100_config
+    outs = []
+    for _ in range(2):
+        torch.manual_seed(0)
+        net = gad.UNet2DModel(**cfg["unet_config"]).to(dev)
+        assert sum(p.numel() for p in net.parameters()) == 35_746_307
+        ema = gad.EMAModel(net.parameters())
+        tr = gad.FusedTrainer(net, gad.DDPMScheduler(**cfg["scheduler_config"]), ema, lr=1e-4)
+        g = torch.Generator(device=dev).manual_seed(5)
+        losses = []
+        for _s in range(2):
+            x = torch.rand(128, 3, 32, 32, device=dev, generator=g) * 2 - 1
+            n = torch.randn(128, 3, 32, 32, device=dev, generator=g)
+            t = torch.randint(0, 1000, (128,), device=dev, generator=g)
+            losses.append(tr.step(x, n, t).item())
+        outs.append((losses, tr.flat.clone(), tr.m.clone(), tr.v.clone(), tr.ema_flat.clone()))
+        del net, ema, tr
+    assert outs[0][0] == outs[1][0]
+    for a, b in zip(outs[0][1:], outs[1][1:]):
+        assert torch.equal(a, b)
+    assert all(torch.isfinite(a).all() for a in outs[0][1:])
+    assert not torch.equal(outs[0][1], outs[0][4])                         # EMA lags the weights
+
+
+def test_fused_sampler_at_bench_width_equals_per_batch_launches():
+    """16 reference batches of 32 fused into one B=512 launch (the bench's sampler width) against launching each
+    batch alone, full-width U-Net, 2 DDIM steps: GroupNorm / attention are per sample, so only fp32 summation order in
+    the split-K plans may differ."""
+    import gad
+    from gad.coalition import FusedSampler
+    from src.ddpm_config import DDPMConfig
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**DDPMConfig.cifar100_config["unet_config"]).to(dev).eval()
+    fused = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=16).generate(512, 2)
+    single = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=1).generate(512, 2)
+    assert fused.shape == single.shape == (512, 3, 32, 32)
+    q = (fused * 255).round()
+    assert torch.equal(q / 255, fused)                                      # uint8 round trip of generate_images
+    assert ((fused - single).abs() * 255 > 1.5).float().mean().item() == 0.0   # never more than one grey level apart
+    assert ((fused - single).abs() > 0).float().mean().item() < 0.01
