@@ -7,8 +7,8 @@
 //                    wavefront-free LDS combine; written to the caller's workspace;
 //   pass 2 (apply):  every workgroup re-combines the (tiny) partials of its image with
 //                    Chan's formula - no atomics, deterministic - then normalises its chunk.
-// The second read of x hits the 256 MiB Infinity Cache for the tensors on this path
-// (<= 67 MB at B=128), so HBM traffic stays near the 8 B/elem algorithmic figure.
+// Forward has a one-pass plan (gn_slab_kernel, below) that reads x once when an (image, channel slab) fits
+// in one workgroup's registers; the two-pass plan remains for the other shapes.
 #include "gad_common.h"
 #include "gad_reduce.h"
 
@@ -163,6 +163,126 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
   }
 }
 
+
+// ---------------------------------------------------------- forward, one pass ----
+// When a whole (image, channel slab) fits in the registers of one workgroup the forward reads x ONCE (8 B/elem, the
+// algorithmic figure): workgroup = (image b, slab of SC channels made of whole groups), thread = (pixel lane pl,
+// channel quad q) holding NV float4 (pixels pl, pl+PL, ...).  Two-pass moments in registers (mean, then centred
+// sum of squares), LDS tree reductions in a fixed order (deterministic), then normalise + SiLU from registers.
+struct SlabGeo {
+  int HW, C, G, cpg, SC, qpr, PL, P2, nslab, gps, qpg;   // qpr quads per slab row, PL pixel lanes, P2 = pow2 >= PL
+};
+
+// sum over the pixel lanes of each quad; result for quad q in red[q]
+__device__ __forceinline__ void slab_reduce(float* red, float val, const SlabGeo& s, int pl, bool act) {
+  red[threadIdx.x] = val;
+  for (int st = s.P2 >> 1; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (act && pl < st && pl + st < s.PL) red[threadIdx.x] += red[threadIdx.x + st * s.qpr];
+  }
+  __syncthreads();
+}
+
+template <int NV>
+__global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, float* __restrict__ y,
+                                                     const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                     float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                     SlabGeo s, float eps, int silu) {
+  __shared__ float red[NT];
+  __shared__ float s_mean[64], s_rstd[64];
+  const int b = blockIdx.x / s.nslab, sl = blockIdx.x - b * s.nslab;
+  const int tid = threadIdx.x;
+  const int pl = tid / s.qpr, q = tid - pl * s.qpr;
+  const bool act = pl < s.PL;
+  const int c0 = sl * s.SC + q * 4;
+  const long base = ((long)b * s.HW) * s.C + c0;
+  f32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = pl + i * s.PL;
+    v[i] = (act && p < s.HW) ? *reinterpret_cast<const f32x4*>(x + base + (long)p * s.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc += v[i];
+  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  const float inv_n = 1.f / (float)((long)s.HW * s.cpg);
+  if (tid < s.gps) {
+    float S = 0.f;
+    for (int j = 0; j < s.qpg; ++j) S += red[tid * s.qpg + j];
+    s_mean[tid] = S * inv_n;
+  }
+  __syncthreads();
+  const float mu = act ? s_mean[q / s.qpg] : 0.f;
+  acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = pl + i * s.PL;
+    f32x4 d = v[i] - mu;
+    if (act && p < s.HW) acc += d * d;
+  }
+  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  if (tid < s.gps) {
+    float SS = 0.f;
+    for (int j = 0; j < s.qpg; ++j) SS += red[tid * s.qpg + j];
+    float rs = rsqrtf(SS * inv_n + eps);
+    s_rstd[tid] = rs;
+    mean_out[b * s.G + sl * s.gps + tid] = s_mean[tid];
+    rstd_out[b * s.G + sl * s.gps + tid] = rs;
+  }
+  __syncthreads();
+  if (!act) return;
+  const float rs = s_rstd[q / s.qpg];
+  f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 scale = ga * rs, shift = be - scale * mu;
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = pl + i * s.PL;
+    if (p < s.HW) {
+      f32x4 z = v[i] * scale + shift;
+      if (silu) {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+      }
+      *reinterpret_cast<f32x4*>(y + base + (long)p * s.C) = z;
+    }
+  }
+}
+
+// pick the channel slab; returns NV (0 = no one-pass plan: odd channels-per-group or too many pixels)
+static int make_slab(const gad_groupnorm_args* a, SlabGeo* out) {
+  const int cpg = a->C / a->G;
+  if (cpg % 4 != 0) return 0;
+  SlabGeo best{};
+  int best_nv = 0;
+  long best_score = -1;
+  const char* mx = getenv("GAD_GN_MAXNV");
+  const int maxnv = mx ? atoi(mx) : 32;
+  for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
+    int SC = k * cpg;
+    if (a->C % SC != 0) continue;
+    if ((SC * 4) % 128 != 0 && SC != a->C) continue;   // slab rows must be whole 128-B lines, or two workgroups fetch each line
+    int qpr = SC / 4;
+    if (qpr > NT) break;
+    int PL = NT / qpr;
+    int nv = (a->HW + PL - 1) / PL;
+    if (nv > maxnv) continue;
+    long blocks = (long)a->B * (a->C / SC);
+    // enough workgroups for 256 CUs first, then the longest contiguous run per pixel
+    long score = (blocks >= 1024 ? (1L << 40) : blocks << 16) + SC;
+    if (score > best_score) {
+      best_score = score;
+      best_nv = nv;
+      int P2 = 1;
+      while (P2 < PL) P2 <<= 1;
+      best = SlabGeo{a->HW, a->C, a->G, cpg, SC, qpr, PL, P2, a->C / SC, k, cpg / 4};
+    }
+  }
+  if (!best_nv) return 0;
+  *out = best;
+  return best_nv <= 4 ? 4 : best_nv <= 8 ? 8 : best_nv <= 16 ? 16 : 32;
+}
+
 // --------------------------------------------------------------- backward ----
 // g_e = dy * silu'(z) (or dy);  per channel partials  A_c = sum g_e,  Bx_c = sum g_e * xhat_e
 __device__ __forceinline__ float act_grad(float dy, float z, int silu) {
@@ -305,8 +425,22 @@ extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
 
 extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream) {
   if (check(a, "gad_groupnorm_silu_fwd")) return 1;
-  Geo g = make_geo(a);
   hipStream_t st = (hipStream_t)stream;
+  SlabGeo sg;
+  const char* two = getenv("GAD_GN_TWO_PASS");
+  int nv = (two && atoi(two)) ? 0 : make_slab(a, &sg);
+  if (nv) {
+    dim3 sgrid(a->B * sg.nslab), sblock(NT);
+    switch (nv) {
+      case 4: hipLaunchKernelGGL(gn_slab_kernel<4>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 8: hipLaunchKernelGGL(gn_slab_kernel<8>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 16: hipLaunchKernelGGL(gn_slab_kernel<16>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      default: hipLaunchKernelGGL(gn_slab_kernel<32>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+    }
+    GAD_LAUNCH_CHECK("gn_slab");
+    return 0;
+  }
+  Geo g = make_geo(a);
   dim3 grid(a->B * g.nch), block(NT);
   hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, a->x, (float*)a->ws, g);
   GAD_LAUNCH_CHECK("gn_stats");

@@ -61,21 +61,29 @@ def weight_krsc(w: torch.Tensor) -> torch.Tensor:
 
 # ----------------------------------------------------------------------------------
 # gradient sinks: when a parameter lives in a flat gradient buffer (training.flatten_params) its gradient
-# kernels write straight into that slot and autograd receives the slot itself, so there is no per-parameter
-# accumulate kernel and no memset of the flat buffer.  A second gradient for the same parameter within one
-# step is added on top.
+# kernels write straight into that slot while a FusedTrainer backward is running, and autograd is handed None for
+# that parameter: no AccumulateGrad node runs, so there is no per-parameter clone / accumulate kernel and no
+# memset of the flat buffer.  A second gradient for the same parameter within one step is added on top.
+# Outside begin_/end_backward_step the sinks are ignored and .grad behaves as usual.
 # ----------------------------------------------------------------------------------
 _SINK_EPOCH = [0]        # sinks live on the parameter object: p._gad_sink (view), p._gad_sink_epoch (last write)
+_SINK_ACTIVE = [False]
 
 
 def begin_backward_step():
-    """Call once per training step before backward(): marks every sink as not yet written."""
+    """Call once per training step before backward(): marks every sink as not yet written and routes parameter
+    gradients into the sinks until end_backward_step()."""
     _SINK_EPOCH[0] += 1
+    _SINK_ACTIVE[0] = True
+
+
+def end_backward_step():
+    _SINK_ACTIVE[0] = False
 
 
 def _sink(param):
     """(destination view or None, first_write flag)"""
-    v = getattr(param, "_gad_sink", None) if param is not None else None
+    v = getattr(param, "_gad_sink", None) if (param is not None and _SINK_ACTIVE[0]) else None
     if v is None:
         return None, True
     first = getattr(param, "_gad_sink_epoch", -1) != _SINK_EPOCH[0]
@@ -84,14 +92,16 @@ def _sink(param):
 
 
 def _deliver(param, grad):
-    """Route a freshly computed gradient tensor to the parameter's sink if it has one.  First gradient of the
-    step: copied into the slot and the slot is returned (autograd then adopts it as .grad).  Later gradients
-    are returned as they are - autograd adds them into .grad, which is the slot."""
+    """Route a freshly computed gradient tensor: into the parameter's sink (returning None to autograd) if it has an
+    active one, else back to autograd unchanged."""
     v, first = _sink(param)
-    if v is None or not first:
+    if v is None:
         return grad
-    v.copy_(grad)
-    return v
+    if first:
+        v.copy_(grad)
+    else:
+        v.add_(grad)
+    return None
 
 
 # ----------------------------------------------------------------------------------
@@ -270,10 +280,13 @@ def _param_grad(param, compute):
     """compute(out) produces the gradient, writing into `out` when given.  With a sink: first gradient of the
     step goes straight into the slot, later ones are added."""
     v, first = _sink(param)
-    if v is None or not first:
-        return compute(None)          # later gradients of the step: autograd accumulates them into .grad (= slot)
-    compute(v)
-    return v
+    if v is None:
+        return compute(None)
+    if first:
+        compute(v)
+    else:
+        v.add_(compute(None))
+    return None
 
 
 class Conv2dFn(torch.autograd.Function):
@@ -381,6 +394,14 @@ class GroupNormSiluFn(torch.autograd.Function):
         a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
         a.dy, a.dgamma, a.dbeta = dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
         check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
+        if sg is not None:
+            if not fg:
+                sg.add_(dgamma)
+            dgamma = None
+        if sb is not None:
+            if not fb:
+                sb.add_(dbeta)
+            dbeta = None
         return dx, dgamma, dbeta, None, None, None
 
 

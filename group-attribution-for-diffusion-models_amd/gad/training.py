@@ -242,9 +242,10 @@ class FusedTrainer:
         eps = model(noisy, timesteps, *model_args).sample
         loss, d = ops.mse_fwd_bwd_raw(eps.contiguous(), noise_nchw.contiguous(), grad_scale=self.loss_sign)
         ops.begin_backward_step()        # every parameter's first gradient of this step overwrites its flat slot
-        for p in self.params:
-            p.grad = None                # (a stale .grad would make autograd add the slot to itself)
-        eps.backward(d)
+        try:
+            eps.backward(d)              # parameter gradients land in gflat; autograd sees None for them
+        finally:
+            ops.end_backward_step()
         if not self._sinks_checked:      # a parameter that got no gradient would keep a stale slot: zero it each step
             ep = ops._SINK_EPOCH[0]
             self._unwritten = [p._gad_sink for p in self.params if getattr(p, "_gad_sink_epoch", -1) != ep]

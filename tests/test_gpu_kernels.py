@@ -152,8 +152,15 @@ def test_conv_autograd_function(ops):
 # -------------------------------------------------------------------------- groupnorm ----
 @pytest.mark.parametrize("B,C,H,G,silu", [(2, 128, 32, 32, True), (3, 256, 16, 32, True), (2, 384, 16, 32, True),
                                           (2, 512, 4, 32, True), (2, 224, 8, 32, False), (1, 896, 8, 32, True),
-                                          (32, 128, 32, 32, True), (2, 1280, 8, 32, True), (1, 2560, 4, 32, True)])
-def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu):
+                                          (32, 128, 32, 32, True), (2, 1280, 8, 32, True), (1, 2560, 4, 32, True),
+                                          (2, 384, 32, 32, True), (2, 96, 8, 32, True), (3, 256, 32, 32, False),
+                                          (2, 320, 64, 32, True)])
+@pytest.mark.parametrize("two_pass", [False, True])
+def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu, two_pass, monkeypatch):
+    """Forward has two plans: one pass with the (image, channel slab) held in registers, or stats + apply passes
+    (odd channels per group, slabs that are not whole 128-B lines, too many pixels); both against fp64."""
+    if two_pass:
+        monkeypatch.setenv("GAD_GN_TWO_PASS", "1")
     x = (rnd(B, C, H, H, seed=1) * 2 + 0.7).double().requires_grad_(True)   # non-zero mean stresses the variance
     ga, be = (rnd(C, seed=2) * 0.3 + 1).double().requires_grad_(True), (rnd(C, seed=3) * 0.2).double().requires_grad_(True)
     eps = 1e-6

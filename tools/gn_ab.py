@@ -1,0 +1,29 @@
+import os, sys
+sys.path.insert(0, "/root/repo/group-attribution-for-diffusion-models_amd"); sys.path.insert(0, "/root/repo")
+os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
+import torch
+from gad import ops
+dev = torch.device("cuda:0")
+def timeit(fn, iters=20, warm=3):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters * 1e-3
+for B in (512, 128):
+    for C, H in ((128, 32), (256, 32), (384, 32), (256, 16), (384, 16), (512, 16), (256, 8), (512, 8), (256, 4)):
+        x = torch.randn(B, H, H, C, device=dev); g = torch.randn(C, device=dev); b = torch.randn(C, device=dev)
+        res = []
+        ref = None
+        for label, env in (("two-pass", {"GAD_GN_TWO_PASS": "1"}), ("slab32", {"GAD_GN_MAXNV": "32"}), ("slab16", {"GAD_GN_MAXNV": "16"}), ("slab8", {"GAD_GN_MAXNV": "8"})):
+            for k in ("GAD_GN_TWO_PASS", "GAD_GN_MAXNV"): os.environ.pop(k, None)
+            os.environ.update(env)
+            with torch.no_grad():
+                y = ops.group_norm(x, g, b, 32, 1e-6, True)
+                if ref is None: ref = y
+                err = (y - ref).abs().max().item()
+                t = timeit(lambda: ops.group_norm(x, g, b, 32, 1e-6, True))
+            res.append(f"{label} {t*1e6:7.1f}us {8*x.numel()/t/1e9:5.0f}GB/s err {err:.1e}")
+        print(f"B={B} C={C} {H}x{H}: " + " | ".join(res), flush=True)
