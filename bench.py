@@ -220,6 +220,14 @@ def main():
         log(f"timed region done: {dt:.2f}s for {a.steps} steps")
         ops.PROFILER = None
         units = a.steps * world / float(GD_STEPS)
+        # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
+        n_tr = 10
+        barrier()
+        t1 = time.time()
+        for _ in range(n_tr):
+            run.train_step()
+        barrier()
+        dt_train = time.time() - t1
         recs = [CoalitionRecord(rank, len(run.loader.x), 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
     # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
     if world > 1:
@@ -229,6 +237,10 @@ def main():
         tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
+        if not a.full_coalition:
+            tmax.fill_(dt_train)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_train = float(tmax.item())
     value = units / (dt / 3600.0)
 
     if rank == 0:
@@ -249,6 +261,11 @@ def main():
             train_flop = 3 * UNET_GFLOP_PER_IMG * 1e9 * TRAIN_B
             samp_flop = UNET_GFLOP_PER_IMG * 1e9 * N_SAMPLES * DDIM_STEPS / GD_STEPS
             out["unet_tflops_per_gpu"] = (train_flop + samp_flop) * a.steps / dt / 1e12
+            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / F32_MFMA_PEAK_TF      # whole path, not one kernel
+            out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
+                                             "ms_per_step": dt_train / n_tr * 1e3,
+                                             "tflops_per_gpu": train_flop * n_tr / dt_train / 1e12,
+                                             "reference": 3.81}                       # 3.81 steps/s, 1 GPU
         if prof is not None:
             torch.cuda.synchronize(dev)
             summ = prof.summary()

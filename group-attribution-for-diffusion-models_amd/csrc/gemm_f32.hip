@@ -631,6 +631,148 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// bf16-operand variant (gad_gemm_args.operand_precision == 1): A and B are still fp32 in HBM; the loaders'
+// 16-B gathers go through registers, are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) and stored into bf16 LDS tiles
+// [rows][32 k + 8 pad] (80-B rows: a wave's ds_read_b128 of 16 consecutive rows covers all 64 banks once); the
+// products run on v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8(l>>5)+j) with fp32 accumulation and the same
+// C/D map and epilogue as the fp32 kernel.  Instantiated for the k-contiguous operand pairs (conv forward,
+// Linear forward, Q K^T); the other pairs stay on the fp32 kernel.
+// ------------------------------------------------------------------------------------
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+constexpr int LDK = BK + 8;
+
+__device__ __forceinline__ void store_bf16x4(unsigned short* dst, f32x4 v) {
+  bf16x4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<bf16x4_t*>(dst) = h;
+}
+
+template <int AM, int BM, int BN>
+__global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using AL = ALoader<AM, BM, 4>;
+  using BL = BLoader<GAD_B_KC, BN, 4>;
+  constexpr int A_TILE = LDK * BM;
+  constexpr int B_TILE = LDK * BN;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (A_TILE + B_TILE)];
+
+  int nwg = gridDim.x, bid = blockIdx.x;
+  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  int tiles = p.tiles_m * p.tiles_n;
+  int zs = t / tiles, rem = t - zs * tiles;
+  int tile_m = rem / p.tiles_n, tile_n = rem - tile_m * p.tiles_n;
+  int z = zs / p.splitk, split = zs - z * p.splitk;
+  int z0 = z / p.batch_inner, z1 = z - z0 * p.batch_inner;
+  const float* A = p.A + z0 * p.sA0 + z1 * p.sA1;
+  const float* B = p.B + z0 * p.sB0 + z1 * p.sB1;
+
+  int row0 = tile_m * BM, col0 = tile_n * BN;
+  int kbeg = split * p.ktiles_per_split * BK;
+  int kend = min(p.K, kbeg + p.ktiles_per_split * BK);
+  int nkt = (kend - kbeg + BK - 1) / BK;
+  const int kt0 = split * p.ktiles_per_split;
+  auto k0_of = [&](int kt) -> int {
+    if (!p.kperm) return (kt0 + kt) * BK;
+    int j = kt0 + kt;
+    int chunk = p.fdTaps.div(j), tap = j - chunk * p.taps;
+    return tap * p.g.C + chunk * BK;
+  };
+  if (p.kperm) kend = p.K;
+
+  AL al;
+  BL bl;
+  al.setup(p, A, row0, kend);
+  bl.setup(p, B, col0, kend);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  f32x4 ra[AL::NS], rb[BL::NS];
+  unsigned mdummy = 0;
+  // all of a thread's gathers of one K step are issued together (invalid slots read the zero block)
+  auto fetch = [&](int k0) {
+    al.prep(k0, mdummy);
+    bl.prep(k0, mdummy);
+#pragma unroll
+    for (int i = 0; i < AL::NS; ++i) ra[i] = ldg4(al.src(i));
+#pragma unroll
+    for (int i = 0; i < BL::NS; ++i) rb[i] = ldg4(bl.src(i));
+  };
+  const int kq = KCSlots<BM>::kq4();   // logical k column of this lane's float4 (the loaders' swizzled assignment)
+  auto commit = [&](unsigned short* ta, unsigned short* tb) {
+#pragma unroll
+    for (int i = 0; i < AL::NS; ++i) store_bf16x4(ta + KCSlots<BM>::row(i) * LDK + kq, ra[i]);
+#pragma unroll
+    for (int i = 0; i < BL::NS; ++i) store_bf16x4(tb + KCSlots<BN>::row(i) * LDK + kq, rb[i]);
+  };
+  if (nkt > 0) {
+    fetch(k0_of(0));
+    commit(lds, lds + A_TILE);
+  }
+  __syncthreads();
+
+  for (int kt = 0; kt < nkt; ++kt) {
+    unsigned short* cur = lds + (kt & 1) * (A_TILE + B_TILE);
+    unsigned short* nxt = lds + ((kt + 1) & 1) * (A_TILE + B_TILE);
+    const unsigned short* la = cur;
+    const unsigned short* lb = cur + A_TILE;
+    fetch((kt + 1 < nkt) ? k0_of(kt + 1) : p.K);   // past the end every slot reads zeros
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+        fa[i] = *reinterpret_cast<const bf16x8_t*>(la + (wm * (BM / 2) + i * 32 + l31) * LDK + ks * 16 + 8 * h);
+#pragma unroll
+      for (int j = 0; j < TN; ++j)
+        fb[j] = *reinterpret_cast<const bf16x8_t*>(lb + (wn * (BN / 2) + j * 32 + l31) * LDK + ks * 16 + 8 * h);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    commit(nxt, nxt + A_TILE);   // `nxt` was last read before the previous barrier
+    __syncthreads();
+  }
+
+  const bool direct = p.splitk == 1;
+  float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
+  const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
+  const int ldc = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e];
+        if (direct) {
+          v = v * p.alpha + bias;
+          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
+          if (R) v += R[(long)m * p.ldr + n];
+        }
+        C[(long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
 // split-K: C = epilogue(sum_s ws[z][s][m][n])
 __global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
   long total = (long)batch * p.M * p.N;
@@ -722,6 +864,15 @@ static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC>), grid, block, 0, st, d);
 }
 
+template <int AM>
+static void launch_bf16(const DevArgs& d, const Plan& pl, hipStream_t st) {
+  dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
+  if (pl.bm == 128)
+    hipLaunchKernelGGL((gemm_bf16_kernel<AM, 128, 128>), grid, block, 0, st, d);
+  else
+    hipLaunchKernelGGL((gemm_bf16_kernel<AM, 64, 64>), grid, block, 0, st, d);
+}
+
 }  // namespace
 
 static int pick_vec(const gad_gemm_args* a) {
@@ -734,6 +885,14 @@ static int pick_vec(const gad_gemm_args* a) {
   if ((am == GAD_A_CONV || am == GAD_A_CONVT || bmode == GAD_B_CONV) && (a->g.C % 4 != 0 || a->g.ldx % 4 != 0)) vec = 1;
   return vec;
 }
+
+// bf16 operands are used when the caller allows them and a bf16 instance exists for the operand pair
+static bool use_bf16(const gad_gemm_args* a) {
+  return a->operand_precision == 1 && (a->a_mode == GAD_A_KC || a->a_mode == GAD_A_CONV) && a->b_mode == GAD_B_KC &&
+         pick_vec(a) == 4;
+}
+
+extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
   GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
@@ -834,6 +993,11 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   d.tiles_m = pl.tiles_m; d.tiles_n = pl.tiles_n; d.splitk = pl.splitk; d.ktiles_per_split = pl.ktiles_per_split;
 
   hipStream_t st = (hipStream_t)stream;
+  GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
+  if (use_bf16(a) && vec == 4) {
+    if (am == GAD_A_KC) launch_bf16<GAD_A_KC>(d, pl, st);
+    else launch_bf16<GAD_A_CONV>(d, pl, st);
+  } else
 #define GAD_CASE(AMODE, BMODE_)                                                        \
   if (am == AMODE && bmode == BMODE_) {                                                \
     if (vec == 4) launch_mode<AMODE, BMODE_, 4>(d, pl, st);                            \

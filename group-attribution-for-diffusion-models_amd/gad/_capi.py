@@ -33,7 +33,7 @@ class GemmArgs(C.Structure):
                 ("rows_per_group", C.c_int32), ("ld_rowadd", C.c_int32),
                 ("residual", C.c_void_p), ("ldr", C.c_int32),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32)]
+                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -62,6 +62,7 @@ SIGNATURES = {
     "gad_last_error": (C.c_char_p, []),
     "gad_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
+    "gad_gemm_uses_bf16": (C.c_int, [C.POINTER(GemmArgs)]),
     "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),

@@ -107,6 +107,30 @@ def _deliver(param, grad):
 # ----------------------------------------------------------------------------------
 # raw contraction launches
 # ----------------------------------------------------------------------------------
+OPERAND_PRECISION = [0]      # 0: fp32 operands (reference default); 1: bf16 operands allowed (see gad.h)
+
+
+class operand_precision:
+    """``with ops.operand_precision("bf16"):`` - the analogue of the reference's autocast
+    (`--mixed_precision`, text_to_image/train_text_to_image_lora.py:659-668): contractions that have a bf16
+    instance (conv forward, Linear forward, Q K^T) round A and B to bf16 in flight and accumulate in fp32;
+    everything else, and all storage, stays fp32."""
+
+    def __init__(self, name):
+        if name not in ("f32", "fp32", "no", "bf16"):
+            raise ValueError(f"operand precision {name!r}: use 'f32' or 'bf16'")
+        self.value = 1 if name == "bf16" else 0
+
+    def __enter__(self):
+        self.prev = OPERAND_PRECISION[0]
+        OPERAND_PRECISION[0] = self.value
+        return self
+
+    def __exit__(self, *exc):
+        OPERAND_PRECISION[0] = self.prev
+        return False
+
+
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0):
@@ -130,6 +154,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ldr = ldr
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
+    a.operand_precision = OPERAND_PRECISION[0]
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -152,7 +177,8 @@ class GemmProfiler:
         s.record()
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
-        key = (self.NAMES.get((a.a_mode, a.b_mode), "gemm"), tile.value, sk.value, vec.value)
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("_bf16" if lib.gad_gemm_uses_bf16(C.byref(a)) else "")
+        key = (name, tile.value, sk.value, vec.value)
         # algorithmic bytes: every operand once (gathered tensor, not its im2col expansion) + the output
         g = a.g
         if a.a_mode in (A_CONV, A_CONVT):

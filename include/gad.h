@@ -83,12 +83,19 @@ typedef struct gad_gemm_args {
   int64_t ws_bytes;
   int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64                  */
   int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
+  /* 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products; the reference's default precision).
+   * 1: A and B may be rounded to bf16 (RNE) in flight and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
+   *    accumulation - the analogue of the reference's `--mixed_precision` autocast
+   *    (text_to_image/train_text_to_image_lora.py:659-668) - for the operand pairs that have a bf16 instance
+   *    (A_KC or A_CONV with B_KC, 16-B aligned); other pairs run in fp32.  gad_gemm_uses_bf16() tells which. */
+  int32_t operand_precision;
 } gad_gemm_args;
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
 /* which kernel instance gad_gemm would launch: block tile edge (128 or 64), split-K factor, vector width (4 or 1) */
 int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec);
 int gad_gemm(const gad_gemm_args* a, void* stream);
+int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would multiply bf16-rounded operands */
 
 /* ------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in

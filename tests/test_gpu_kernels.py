@@ -367,3 +367,55 @@ def test_unet_forward_pruned_widths(ops):
     ref, mine, cfg = _models(shrink=dict(block_out_channels=[96, 192, 192, 192]))
     x, t = rnd(2, 3, 32, 32, seed=1), torch.tensor([3, 700])
     close(mine(x.to(dev), t.to(dev)).sample, ref(x, t).sample, atol=1e-4)
+
+
+# ------------------------------------------------------------------- bf16-operand mode ----
+def _bf16_round(t):
+    return t.to(torch.bfloat16).to(torch.float64)
+
+
+@pytest.mark.parametrize("case", [dict(B=2, Cin=64, Cout=96, H=16, k=3, stride=1, pad=(1, 1, 1, 1), ups=False),
+                                  dict(B=3, Cin=128, Cout=128, H=8, k=3, stride=2, pad=(0, 1, 0, 1), ups=False),
+                                  dict(B=2, Cin=32, Cout=64, H=8, k=3, stride=1, pad=(1, 1, 1, 1), ups=True),
+                                  dict(B=2, Cin=96, Cout=40, H=8, k=1, stride=1, pad=(0, 0, 0, 0), ups=False),
+                                  dict(B=1, Cin=36, Cout=20, H=5, k=3, stride=1, pad=(1, 1, 1, 1), ups=False)])
+@pytest.mark.parametrize("tile", [0, 1, 2])
+def test_conv_fwd_bf16_operands(ops, case, tile):
+    """operand_precision=1: x and w are rounded to bf16 (RNE) inside the kernel, products are exact in fp32 and
+    accumulated in fp32 -> against an fp64 convolution of the bf16-rounded operands only the fp32 summation
+    order differs (tight tolerance); bias / time-embedding add / residual stay fp32."""
+    c = case
+    x, w, b = rnd(c["B"], c["Cin"], c["H"], c["H"], seed=1), rnd(c["Cout"], c["Cin"], c["k"], c["k"], seed=2) * 0.1, rnd(c["Cout"], seed=3)
+    xin = _bf16_round(x)
+    if c["ups"]:
+        xin = F.interpolate(xin, scale_factor=2.0, mode="nearest")
+    pt, pb, pl, pr = c["pad"]
+    want = F.conv2d(F.pad(xin, (pl, pr, pt, pb)), _bf16_round(w), b.double(), stride=c["stride"])
+    temb = rnd(c["B"], c["Cout"], seed=4)
+    res = rnd(*want.shape, seed=5)
+    want = want + temb.double()[:, :, None, None] + res.double()
+    with ops.operand_precision("bf16"):
+        got = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), c["stride"], c["pad"], c["ups"], rowadd=temb.to(dev),
+                                 residual=nhwc(res), tile_hint=tile)
+    K = c["Cin"] * c["k"] ** 2
+    close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-6 * math.sqrt(K))
+    # and it is a different result from the fp32-operand kernel by about bf16 rounding, not more
+    exact = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), c["stride"], c["pad"], c["ups"], rowadd=temb.to(dev),
+                               residual=nhwc(res), tile_hint=tile)
+    d = (got - exact).abs().max().item()
+    assert 0 < d < 2.0 ** -7 * 0.1 * 3 * math.sqrt(K)
+
+
+def test_linear_and_attention_scores_bf16_operands(ops):
+    x, w, b = rnd(300, 256, seed=1), rnd(192, 256, seed=2) * 0.1, rnd(192, seed=3)
+    want = _bf16_round(x) @ _bf16_round(w).T + b.double()
+    with ops.operand_precision("bf16"):
+        got = ops.linear_fwd_raw(x.to(dev), w.to(dev), b.to(dev))
+        assert ops.OPERAND_PRECISION[0] == 1
+    assert ops.OPERAND_PRECISION[0] == 0
+    close(got, want, rtol=1e-5, atol=2e-6 * 16)
+    # K = 27 (conv_in) has no 16-B aligned float4 path: the flag is a permission, the launch stays fp32-exact
+    x3, w3 = rnd(2, 3, 8, 8, seed=5), rnd(16, 3, 3, 3, seed=6)
+    with ops.operand_precision("bf16"):
+        y3 = ops.conv2d_fwd_raw(nhwc(x3), cl_weight(w3), None)
+    close(y3.permute(0, 3, 1, 2), F.conv2d(x3.double(), w3.double(), padding=1), atol=1e-5)
