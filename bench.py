@@ -32,6 +32,7 @@ import torch  # noqa: E402
 
 GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128, 32, 16
 UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
+BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
@@ -47,6 +48,10 @@ def parse():
     ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
+    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
+                    help="f32 = the reference's default precision and the headline number; bf16 = bf16-operand "
+                         "contractions (fp32 storage/accumulation), the analogue of --mixed_precision: a separate, "
+                         "explicitly labelled line, never the default")
     ap.add_argument("--gd-steps", type=int, default=GD_STEPS)
     ap.add_argument("--n-samples", type=int, default=N_SAMPLES)
     return ap.parse_args()
@@ -183,6 +188,8 @@ def main():
     from gad import ops
     from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
 
+    gad.set_operand_precision(a.precision)
+    peak_tf = F32_MFMA_PEAK_TF if a.precision == "f32" else BF16_MFMA_PEAK_TF
     log(f"rank {rank}/{world} on {dev}: building engine")
     engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
                              sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS)
@@ -247,21 +254,23 @@ def main():
         out = {
             "metric": "shapley_coalitions_per_hour", "value": value, "unit": "coalitions/hour", "n_gpus": world,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None, "dtype": "f32", "data": "synthetic",
+            "scaling": "weak", "vs_baseline": None,
+            "dtype": "f32" if a.precision == "f32" else "bf16 operands, f32 accumulate/storage (NOT the reference default)",
+            "data": "synthetic",
             "config": {"workload": ("CIFAR-20 DDPM sFT coalition (BASELINE configs[1]): gd_steps=1000 @B=128 + 10240 samples"
-                                    " x 100 DDIM steps @B=32 (16 batches fused/launch), UNet2DModel 35.75M params fp32; "
+                                    " x 100 DDIM steps @B=32 (16 batches fused/launch), UNet2DModel 35.75M params fp32" + ("" if a.precision == "f32" else " storage, bf16 MFMA operands") + "; "
                                     + ("step = one complete coalition" if a.full_coalition else
                                        "step = 1/1000 coalition = 1 train step + 2 sampler steps @B=512")),
                        "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"},
         }
         # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU
         # (empirical_verification.ipynb:128,132) -> per-GPU ratio
-        out["vs_baseline"] = value / world / 3.27
+        out["vs_baseline"] = value / world / 3.27 if a.precision == "f32" else None   # the published figure is fp32
         if not a.full_coalition:
             train_flop = 3 * UNET_GFLOP_PER_IMG * 1e9 * TRAIN_B
             samp_flop = UNET_GFLOP_PER_IMG * 1e9 * N_SAMPLES * DDIM_STEPS / GD_STEPS
             out["unet_tflops_per_gpu"] = (train_flop + samp_flop) * a.steps / dt / 1e12
-            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / F32_MFMA_PEAK_TF      # whole path, not one kernel
+            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
             out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
                                              "ms_per_step": dt_train / n_tr * 1e3,
                                              "tflops_per_gpu": train_flop * n_tr / dt_train / 1e12,
@@ -278,8 +287,9 @@ def main():
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("dominant_kernel_hbm_bytes_per_launch")
             out["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dom_key[0]}, tile {dom_key[1]}, splitk {dom_key[2]}>",
-                               "achieved": d["flops"] / d["ms"] / 1e9, "peak": F32_MFMA_PEAK_TF, "unit": "TFLOP/s",
-                               "frac": d["flops"] / d["ms"] / 1e9 / F32_MFMA_PEAK_TF, "traffic": traffic,
+                               "achieved": d["flops"] / d["ms"] / 1e9, "peak": peak_tf, "unit": "TFLOP/s",
+                               "frac": d["flops"] / d["ms"] / 1e9 / peak_tf,
+                               "traffic": traffic if a.precision == "f32" else None,
                                "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
                                "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
                                "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],

@@ -636,25 +636,66 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
 // 16-B gathers go through registers, are rounded to bf16 (RNE, v_cvt_pk_bf16_f32) and stored into bf16 LDS tiles
 // [rows][32 k + 8 pad] (80-B rows: a wave's ds_read_b128 of 16 consecutive rows covers all 64 banks once); the
 // products run on v_mfma_f32_32x32x16_bf16 (lane l: row l&31, k = 8(l>>5)+j) with fp32 accumulation and the same
-// C/D map and epilogue as the fp32 kernel.  Instantiated for the k-contiguous operand pairs (conv forward,
-// Linear forward, Q K^T); the other pairs stay on the fp32 kernel.
+// C/D map and epilogue as the fp32 kernel.  Row-contiguous (MC-type) operands keep their [k][row] image and are
+// read with the transposing ds_read_b64_tr_b16.  All six operand pairs are instantiated; launches whose operands
+// cannot be read as aligned float4 (Cin = 3, Tk = 77 ...) stay on the fp32 kernel.
 // ------------------------------------------------------------------------------------
 typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
 typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
 constexpr int LDK = BK + 8;
+// MC-type tiles [32 k][rows + pad]: the row stride in dwords is 16 (mod 64) (rows 128) or 48 (mod 64) (rows 64), so the
+// 4 k-rows x 16-dword segments one 32-lane half of a ds_read_b64_tr_b16 touches are 64 distinct banks
+template <int ROWS> struct LdmOf { static constexpr int v = ROWS == 128 ? 160 : 96; };
 
 __device__ __forceinline__ void store_bf16x4(unsigned short* dst, f32x4 v) {
   bf16x4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
   *reinterpret_cast<bf16x4_t*>(dst) = h;
 }
 
-template <int AM, int BM, int BN>
+// bf16 tile of one operand: element count, where a thread's slot i goes, and the MFMA fragment of a 32-row
+// block (rows r0 .. r0+31) for k sub-step ks (16 k each): lane l holds k = 16 ks + 8 (l>>5) + j, j = 0..7
+template <bool KC, int ROWS>
+struct Bf16Tile;
+template <int ROWS>
+struct Bf16Tile<true, ROWS> {
+  static constexpr int ELEMS = LDK * ROWS;
+  __device__ static void put(unsigned short* tile, int i, f32x4 v) {
+    store_bf16x4(tile + KCSlots<ROWS>::row(i) * LDK + KCSlots<ROWS>::kq4(), v);
+  }
+  __device__ static bf16x8_t frag(const unsigned short* tile, int r0, int ks, int lane) {
+    return *reinterpret_cast<const bf16x8_t*>(tile + (r0 + (lane & 31)) * LDK + ks * 16 + 8 * (lane >> 5));
+  }
+};
+template <int ROWS>
+struct Bf16Tile<false, ROWS> {
+  static constexpr int LDM = LdmOf<ROWS>::v;
+  static constexpr int ELEMS = BK * LDM;
+  __device__ static void put(unsigned short* tile, int i, f32x4 v) {
+    store_bf16x4(tile + MCSlots<ROWS>::krow(i) * LDM + MCSlots<ROWS>::rq4(), v);
+  }
+  // transposed read: per 16-lane group a 4(k) x 16(row) block; lane 4q+p supplies row q, columns 4p..4p+3 and
+  // receives the 4 k-values of column (lane & 15)  (every lane must be active: EXEC all ones)
+  __device__ static bf16x8_t frag(const unsigned short* tile, int r0, int ks, int lane) {
+    const int q = (lane & 15) >> 2, pp = lane & 3;
+    const unsigned short* a0 = tile + (ks * 16 + 8 * (lane >> 5) + q) * LDM + r0 + 16 * ((lane >> 4) & 1) + 4 * pp;
+    s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+    s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 4 * LDM));
+    typedef short s16x8_t __attribute__((ext_vector_type(8)));
+    s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+    return __builtin_bit_cast(bf16x8_t, both);
+  }
+};
+
+template <int AM, int BMODE, int BM, int BN>
 __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   using AL = ALoader<AM, BM, 4>;
-  using BL = BLoader<GAD_B_KC, BN, 4>;
-  constexpr int A_TILE = LDK * BM;
-  constexpr int B_TILE = LDK * BN;
+  using BL = BLoader<BMODE, BN, 4>;
+  using AT = Bf16Tile<AL::KC, BM>;
+  using BT = Bf16Tile<BL::KC, BN>;
+  constexpr int A_TILE = AT::ELEMS;
+  constexpr int B_TILE = BT::ELEMS;
   __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (A_TILE + B_TILE)];
 
   int nwg = gridDim.x, bid = blockIdx.x;
@@ -708,12 +749,11 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
 #pragma unroll
     for (int i = 0; i < BL::NS; ++i) rb[i] = ldg4(bl.src(i));
   };
-  const int kq = KCSlots<BM>::kq4();   // logical k column of this lane's float4 (the loaders' swizzled assignment)
   auto commit = [&](unsigned short* ta, unsigned short* tb) {
 #pragma unroll
-    for (int i = 0; i < AL::NS; ++i) store_bf16x4(ta + KCSlots<BM>::row(i) * LDK + kq, ra[i]);
+    for (int i = 0; i < AL::NS; ++i) AT::put(ta, i, ra[i]);
 #pragma unroll
-    for (int i = 0; i < BL::NS; ++i) store_bf16x4(tb + KCSlots<BN>::row(i) * LDK + kq, rb[i]);
+    for (int i = 0; i < BL::NS; ++i) BT::put(tb, i, rb[i]);
   };
   if (nkt > 0) {
     fetch(k0_of(0));
@@ -731,11 +771,9 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
     for (int ks = 0; ks < 2; ++ks) {
       bf16x8_t fa[TM], fb[TN];
 #pragma unroll
-      for (int i = 0; i < TM; ++i)
-        fa[i] = *reinterpret_cast<const bf16x8_t*>(la + (wm * (BM / 2) + i * 32 + l31) * LDK + ks * 16 + 8 * h);
+      for (int i = 0; i < TM; ++i) fa[i] = AT::frag(la, wm * (BM / 2) + i * 32, ks, lane);
 #pragma unroll
-      for (int j = 0; j < TN; ++j)
-        fb[j] = *reinterpret_cast<const bf16x8_t*>(lb + (wn * (BN / 2) + j * 32 + l31) * LDK + ks * 16 + 8 * h);
+      for (int j = 0; j < TN; ++j) fb[j] = BT::frag(lb, wn * (BN / 2) + j * 32, ks, lane);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
@@ -805,6 +843,17 @@ static FastDiv make_fastdiv(unsigned d) {
   return f;
 }
 
+static int pick_vec(const gad_gemm_args* a) {
+  int vec = 4;
+  const int am = a->a_mode, bmode = a->b_mode;
+  if (am == GAD_A_KC && (a->K % 4 != 0 || a->lda % 4 != 0)) vec = 1;
+  if (am == GAD_A_MC && (a->M % 4 != 0 || a->lda % 4 != 0)) vec = 1;
+  if (bmode == GAD_B_KC && (a->K % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
+  if (bmode == GAD_B_MC && (a->N % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
+  if ((am == GAD_A_CONV || am == GAD_A_CONVT || bmode == GAD_B_CONV) && (a->g.C % 4 != 0 || a->g.ldx % 4 != 0)) vec = 1;
+  return vec;
+}
+
 struct Plan {
   int bm, tiles_m, tiles_n, splitk, ktiles_per_split;
   long nblocks;
@@ -823,8 +872,13 @@ static Plan make_plan(const gad_gemm_args* a) {
   for (int bm = 128; bm >= 64; bm -= 64) {
     if (a->tile_hint == 1 && bm != 128) continue;
     if (a->tile_hint == 2 && bm != 64) continue;
-    const int cap = bm == 128 ? 2 : 4;
-    const double mfma = bm == 128 ? 4096.0 : 1100.0, X = bm == 128 ? 1200.0 : 600.0, fixed = bm == 128 ? 6000.0 : 3000.0;
+    // bf16-operand kernels: 3 / 6 workgroups per CU; a K step is bound by staging (gather + convert + LDS), not by
+    // the 8 / 2 MFMAs, so the per-step cost of a 64x64 tile is about a third of a 128x128 tile's, not a quarter
+    const bool bf = a->operand_precision == 1 && pick_vec(a) == 4;
+    const int cap = bf ? (bm == 128 ? 3 : 6) : (bm == 128 ? 2 : 4);
+    const double mfma = bf ? (bm == 128 ? 1200.0 : 420.0) : (bm == 128 ? 4096.0 : 1100.0);
+    const double X = bf ? (bm == 128 ? 600.0 : 300.0) : (bm == 128 ? 1200.0 : 600.0);
+    const double fixed = bf ? (bm == 128 ? 4000.0 : 2000.0) : (bm == 128 ? 6000.0 : 3000.0);
     const long tiles = gad_ceil_div(a->M, bm) * gad_ceil_div(a->N, bm) * batch;
     for (int sk : sks) {
       if (a->splitk_hint > 0) sk = a->splitk_hint < kt ? a->splitk_hint : kt;
@@ -864,32 +918,21 @@ static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC>), grid, block, 0, st, d);
 }
 
-template <int AM>
+template <int AM, int BMODE>
 static void launch_bf16(const DevArgs& d, const Plan& pl, hipStream_t st) {
   dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
   if (pl.bm == 128)
-    hipLaunchKernelGGL((gemm_bf16_kernel<AM, 128, 128>), grid, block, 0, st, d);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AM, BMODE, 128, 128>), grid, block, 0, st, d);
   else
-    hipLaunchKernelGGL((gemm_bf16_kernel<AM, 64, 64>), grid, block, 0, st, d);
+    hipLaunchKernelGGL((gemm_bf16_kernel<AM, BMODE, 64, 64>), grid, block, 0, st, d);
 }
 
 }  // namespace
 
-static int pick_vec(const gad_gemm_args* a) {
-  int vec = 4;
-  const int am = a->a_mode, bmode = a->b_mode;
-  if (am == GAD_A_KC && (a->K % 4 != 0 || a->lda % 4 != 0)) vec = 1;
-  if (am == GAD_A_MC && (a->M % 4 != 0 || a->lda % 4 != 0)) vec = 1;
-  if (bmode == GAD_B_KC && (a->K % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
-  if (bmode == GAD_B_MC && (a->N % 4 != 0 || a->ldb % 4 != 0)) vec = 1;
-  if ((am == GAD_A_CONV || am == GAD_A_CONVT || bmode == GAD_B_CONV) && (a->g.C % 4 != 0 || a->g.ldx % 4 != 0)) vec = 1;
-  return vec;
-}
 
 // bf16 operands are used when the caller allows them and a bf16 instance exists for the operand pair
 static bool use_bf16(const gad_gemm_args* a) {
-  return a->operand_precision == 1 && (a->a_mode == GAD_A_KC || a->a_mode == GAD_A_CONV) && a->b_mode == GAD_B_KC &&
-         pick_vec(a) == 4;
+  return a->operand_precision == 1 && pick_vec(a) == 4;
 }
 
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
@@ -994,13 +1037,11 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
-  if (use_bf16(a) && vec == 4) {
-    if (am == GAD_A_KC) launch_bf16<GAD_A_KC>(d, pl, st);
-    else launch_bf16<GAD_A_CONV>(d, pl, st);
-  } else
+  const bool bf16 = use_bf16(a) && vec == 4;
 #define GAD_CASE(AMODE, BMODE_)                                                        \
   if (am == AMODE && bmode == BMODE_) {                                                \
-    if (vec == 4) launch_mode<AMODE, BMODE_, 4>(d, pl, st);                            \
+    if (bf16) launch_bf16<AMODE, BMODE_>(d, pl, st);                                   \
+    else if (vec == 4) launch_mode<AMODE, BMODE_, 4>(d, pl, st);                       \
     else launch_mode<AMODE, BMODE_, 1>(d, pl, st);                                     \
   } else
   GAD_CASE(GAD_A_KC, GAD_B_KC)

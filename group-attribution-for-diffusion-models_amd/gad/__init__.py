@@ -4,6 +4,7 @@ The names exported here are the ones the reference takes from `diffusers`
 (main.py:22-24, src/diffusion_utils.py:15-23): entry points import this module in place of
 diffusers for the objects on the hot path."""
 from . import _capi, ops  # noqa: F401
+from .ops import operand_precision, set_operand_precision  # noqa: F401
 from .nn import LoRALinearLayer, UNet2DModel  # noqa: F401
 from .pipelines import DDIMPipeline, DDPMPipeline, StableDiffusionLatentPipeline, sd_simple_loss  # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401

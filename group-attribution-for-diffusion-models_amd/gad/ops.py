@@ -131,6 +131,13 @@ class operand_precision:
         return False
 
 
+def set_operand_precision(name):
+    """Process-wide form of `operand_precision` for the entry points' --mixed_precision flag.  "fp16" maps to
+    bf16 operands: bf16 is the MI355X-native 16-bit operand type and, with fp32's exponent range, needs no loss
+    scaling (the reference's GradScaler, accelerate's fp16 path) - storage and accumulation stay fp32 either way."""
+    OPERAND_PRECISION[0] = 0 if name in (None, "no", "f32", "fp32") else operand_precision("bf16" if name in ("fp16", "bf16") else name).value
+
+
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0):

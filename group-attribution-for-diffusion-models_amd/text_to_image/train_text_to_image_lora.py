@@ -150,9 +150,9 @@ def coalition_rows(a, model_outdir, units_df):
 def main(a, backend=None):
     if backend is None:
         import gad as backend
-    if a.mixed_precision not in (None, "no"):
-        raise NotImplementedError("the MI355X engine's contraction kernels are fp32 (exact MFMA); fp16/bf16 autocast "
-                                  "is not offered - the reference's fp16 flag changes numerics, not the algorithm")
+    # :659-668 autocast -> bf16 operands in the contraction kernels (fp32 storage / accumulation; no loss scaling needed)
+    if hasattr(backend, "set_operand_precision"):
+        backend.set_operand_precision(a.mixed_precision)
     removal_dir = removal_directory(a)
     a.dataset = "artbench" if "artbench" in a.train_data_dir else os.path.basename(os.path.normpath(a.train_data_dir))
     if a.cls is not None and a.cls_key is not None:

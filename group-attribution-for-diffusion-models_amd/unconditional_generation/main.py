@@ -96,8 +96,10 @@ def split_contributors(args, dataset):
 def main(args, backend=None):
     if backend is None:
         import gad as backend
-    if args.mixed_precision != "no" or args.use_8bit_optimizer or args.gradient_accumulation_steps != 1:
-        raise NotImplementedError("the MI355X engine runs the reference default: fp32, Adam(W), no accumulation")
+    if args.use_8bit_optimizer or args.gradient_accumulation_steps != 1:
+        raise NotImplementedError("the MI355X engine runs the reference default: Adam(W) in fp32, no accumulation")
+    if hasattr(backend, "set_operand_precision"):      # --mixed_precision fp16|bf16 -> bf16 operands, fp32 everything else
+        backend.set_operand_precision(args.mixed_precision)
     if args.dataset == "celeba" and args.precompute_stage != "reuse":
         # :486-530 encode with the hub-fetched CompVis/ldm-celebahq-256 VQ-VAE; only the latent path is on the card
         raise NotImplementedError("celeba trains on precomputed VQ-VAE latents: pass --precompute_stage reuse with "

@@ -93,6 +93,8 @@ def main(args, backend=None):
                                   "iu / lora / esd are baseline methods outside the hot path")
     if args.model_behavior == "local":
         raise NotImplementedError("local model behaviours (SSIM / per-image losses) are outside the hot path")
+    if hasattr(backend, "set_operand_precision"):      # --mixed_precision fp16|bf16 -> bf16 operands, fp32 everything else
+        backend.set_operand_precision(args.mixed_precision)
     device = torch.device(args.device)
     args.device = device
     info = dict(vars(args))

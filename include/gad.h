@@ -86,8 +86,8 @@ typedef struct gad_gemm_args {
   /* 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products; the reference's default precision).
    * 1: A and B may be rounded to bf16 (RNE) in flight and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
    *    accumulation - the analogue of the reference's `--mixed_precision` autocast
-   *    (text_to_image/train_text_to_image_lora.py:659-668) - for the operand pairs that have a bf16 instance
-   *    (A_KC or A_CONV with B_KC, 16-B aligned); other pairs run in fp32.  gad_gemm_uses_bf16() tells which. */
+   *    (text_to_image/train_text_to_image_lora.py:659-668) - whenever both operands can be read as 16-B aligned
+   *    float4 (else the launch runs in fp32).  gad_gemm_uses_bf16() tells which. */
   int32_t operand_precision;
 } gad_gemm_args;
 

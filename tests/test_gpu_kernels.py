@@ -419,3 +419,60 @@ def test_linear_and_attention_scores_bf16_operands(ops):
     with ops.operand_precision("bf16"):
         y3 = ops.conv2d_fwd_raw(nhwc(x3), cl_weight(w3), None)
     close(y3.permute(0, 3, 1, 2), F.conv2d(x3.double(), w3.double(), padding=1), atol=1e-5)
+
+
+@pytest.mark.parametrize("M,N,K", [(200, 132, 100), (512, 256, 1024), (128, 64, 32)])
+@pytest.mark.parametrize("tile", [1, 2])
+def test_gemm_row_contiguous_layouts_bf16_operands(ops, M, N, K, tile):
+    """[k][row]-stored operands in bf16 mode: their LDS image keeps the [k][row] order and the MFMA fragments are
+    fetched with the transposing LDS read."""
+    from gad._capi import A_KC, A_MC, B_MC
+    a, b = rnd(M, K, seed=1), rnd(K, N, seed=2)
+    want = _bf16_round(a) @ _bf16_round(b)
+    with ops.operand_precision("bf16"):
+        c = torch.empty(M, N, device=dev)
+        ops.gemm_raw(a.to(dev), b.to(dev), c, A_KC, B_MC, M, N, K, K, N, N, tile_hint=tile)
+        close(c, want, rtol=1e-5, atol=2e-6 * math.sqrt(K))
+        c2 = torch.empty(M, N, device=dev)
+        ops.gemm_raw(a.T.contiguous().to(dev), b.to(dev), c2, A_MC, B_MC, M, N, K, M, N, N, tile_hint=tile, splitk_hint=2)
+        close(c2, want, rtol=1e-5, atol=2e-6 * math.sqrt(K))
+
+
+@pytest.mark.parametrize("case", [c for c in CONV_CASES if c[1] % 4 == 0 and c[2] % 4 == 0])
+def test_conv_bwd_bf16_operands(ops, case):
+    """dgrad (transposed gather x weight read as [k=(tap,co)][ci]) and wgrad (dy^T x im2col columns) with bf16
+    operands against fp64 on the bf16-rounded tensors."""
+    B, Cin, Cout, H, k, stride, pad, ups = case
+    x = _bf16_round(rnd(B, Cin, H, H, seed=1)).requires_grad_(True)
+    w = _bf16_round(rnd(Cout, Cin, k, k, seed=2, scale=1 / math.sqrt(Cin * k * k))).requires_grad_(True)
+    y = conv_ref(x, w, None, stride, pad, ups)
+    dy = rnd(*y.shape, seed=6)
+    y.backward(_bf16_round(dy))
+    with ops.operand_precision("bf16"):
+        dx = ops.conv2d_dgrad_raw(nhwc(dy), cl_weight(w.detach().float()), (B, H, H, Cin), stride, pad, ups)
+        dw = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x.detach().float()), cl_weight(w.detach().float()), stride, pad, ups)
+    close(dx.permute(0, 3, 1, 2), x.grad, rtol=1e-5, atol=3e-6 * math.sqrt(Cout * k * k))
+    close(dw, w.grad, rtol=1e-5, atol=3e-6 * math.sqrt(B * y.shape[-1] * y.shape[-2]))
+
+
+def test_unet_forward_backward_bf16_close_to_fp32(ops):
+    """Whole U-Net, fwd + bwd with bf16 operands vs the fp32-operand engine: outputs within bf16 rounding noise
+    (relative rms < 2e-2), parameter gradients correlated > 0.999."""
+    import gad
+    from src.ddpm_config import DDPMConfig
+    cfg = dict(DDPMConfig.cifar100_config["unet_config"], block_out_channels=[32, 64, 64, 64], norm_num_groups=8)
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**cfg).to(dev)
+    x, t, tgt = rnd(4, 3, 32, 32, seed=1).to(dev), torch.tensor([3, 500, 900, 41], device=dev), rnd(4, 3, 32, 32, seed=2).to(dev)
+    outs, grads = {}, {}
+    for prec in ("f32", "bf16"):
+        net.zero_grad(set_to_none=True)
+        with ops.operand_precision(prec):
+            y = net(x, t).sample
+            (y - tgt).square().mean().backward()
+        outs[prec] = y.detach()
+        grads[prec] = torch.cat([p.grad.flatten() for p in net.parameters()])
+    rel = ((outs["bf16"] - outs["f32"]).norm() / outs["f32"].norm()).item()
+    assert 0 < rel < 2e-2, rel
+    cos = torch.nn.functional.cosine_similarity(grads["bf16"], grads["f32"], dim=0).item()
+    assert cos > 0.999, cos

@@ -7,17 +7,18 @@ import gad
 from gad import ops
 dev = torch.device("cuda:0")
 B = int(sys.argv[1]) if len(sys.argv) > 1 else 64
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
+gad.set_operand_precision(PREC)
+print(f"operand precision: {PREC}", flush=True)
 net = gad.UNet2DConditionModel().to(dev)
 lora = net.inject_lora(rank=256)
 x, ctx = torch.randn(B, 4, 32, 32, device=dev), torch.randn(B, 77, 768, device=dev)
 t = torch.randint(0, 1000, (B,), device=dev)
 noise = torch.randn_like(x)
+sched = gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+trainer = gad.FusedTrainer(net, sched, None, lr=3e-4, adamw=True, weight_decay=1e-2, max_grad_norm=1.0, params=lora)
 def step():
-    for p in lora: p.grad = None
-    out = net(x, t, ctx).sample
-    loss, d = ops.mse_fwd_bwd_raw(out.contiguous(), noise)
-    out.backward(d)
-    return loss
+    return trainer.step(x, noise, t, ctx)     # add_noise + fwd + mse + bwd + clip + AdamW, as the entry point runs it
 def timeit(fn, n=3, w=1):
     for _ in range(w): fn()
     torch.cuda.synchronize(); t0 = time.time()
