@@ -61,6 +61,14 @@ class DDPMScheduler(_Base):
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
 
 
+def min_snr_weights(alphas_cumprod, timesteps, snr_gamma):
+    """compute_snr + the epsilon-prediction weights of train_text_to_image_lora.py:1276-1290:
+    SNR_t = abar_t / (1 - abar_t);  w_t = min(SNR_t, gamma) / SNR_t."""
+    a = alphas_cumprod.to(timesteps.device)[timesteps].float()
+    snr = a / (1.0 - a)
+    return torch.minimum(snr, torch.full_like(snr, float(snr_gamma))) / snr
+
+
 class DDIMScheduler(_Base):
     def __init__(self, num_train_timesteps=1000, beta_start=0.0001, beta_end=0.02, beta_schedule="linear",
                  trained_betas=None, clip_sample=True, set_alpha_to_one=True, steps_offset=0,

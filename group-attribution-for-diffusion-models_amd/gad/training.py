@@ -236,11 +236,17 @@ class FusedTrainer:
         self._sumsq = torch.zeros(1, device=self.flat.device)
         self.last_loss = None
 
-    def step(self, image_nchw, noise_nchw, timesteps, *model_args):
+    def step(self, image_nchw, noise_nchw, timesteps, *model_args, loss_weights=None):
+        """`loss_weights` [B]: per-sample weights of the squared error (min-SNR-gamma weighting,
+        train_text_to_image_lora.py:1276-1298): loss = mean_b w_b * mean_chw (eps_hat - eps)^2."""
         model = self.model
         noisy = self.scheduler.add_noise(image_nchw, noise_nchw, timesteps)
         eps = model(noisy, timesteps, *model_args).sample
         loss, d = ops.mse_fwd_bwd_raw(eps.contiguous(), noise_nchw.contiguous(), grad_scale=self.loss_sign)
+        if loss_weights is not None:           # tiny [B,4,h,w] tensors: plain torch, off the hot path
+            w = loss_weights.to(d.dtype).view(-1, 1, 1, 1)
+            d = d * w
+            loss = ((eps.detach() - noise_nchw).square().mean(dim=(1, 2, 3)) * w.view(-1)).mean().view(1) * self.loss_sign
         ops.begin_backward_step()        # every parameter's first gradient of this step overwrites its flat slot
         try:
             eps.backward(d)              # parameter gradients land in gflat; autograd sees None for them

@@ -52,6 +52,8 @@ def parse_args(argv=None):
     p.add_argument("--adam_weight_decay", type=float, default=1e-2)
     p.add_argument("--adam_epsilon", type=float, default=1e-08)
     p.add_argument("--max_grad_norm", type=float, default=1.0)
+    p.add_argument("--snr_gamma", type=float, default=None, help="min-SNR loss weighting (reference :319)")
+    p.add_argument("--noise_offset", type=float, default=0.0, help="offset noise scale (reference :458)")
     p.add_argument("--mixed_precision", type=str, default=None, choices=["no", "fp16", "bf16"])
     p.add_argument("--rank", type=int, default=4)
     p.add_argument("--cls_key", type=str, default=None)
@@ -243,9 +245,15 @@ def main(a, backend=None):
             sel = perm[s:s + a.train_batch_size]
             x0 = latents.index_select(0, sel)
             noise = torch.randn_like(x0)
+            if a.noise_offset:                                                          # :1227-1232
+                noise += a.noise_offset * torch.randn((x0.shape[0], x0.shape[1], 1, 1), device=device)
             ts = torch.randint(0, 1000, (x0.shape[0],), device=device).long()
             ctx = text.expand(x0.shape[0], -1, -1) if text.shape[0] == 1 else text.index_select(0, sel)
-            loss = trainer.step(x0, noise, ts, ctx.contiguous())
+            lw = None
+            if a.snr_gamma is not None:                                                  # :1276-1298
+                from gad.schedulers import min_snr_weights
+                lw = min_snr_weights(sched.alphas_cumprod, ts, a.snr_gamma)
+            loss = trainer.step(x0, noise, ts, ctx.contiguous(), loss_weights=lw)
             step += 1
             if a.max_train_steps is not None:
                 if device.type == "cuda":

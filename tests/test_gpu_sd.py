@@ -173,6 +173,37 @@ def test_sd_lora_entry_point(tmp_path):
     ridx = pd.read_csv(mdir / "removal_idx.csv")
     assert set(ridx.columns) == {"idx", "remaining"} and len(ridx) == 20
     assert T.main(a) is False                                                          # skip-if-done
+    # min-SNR weighting + offset noise + bf16 operands (reference flags --snr_gamma/--noise_offset/--mixed_precision)
+    import gad
+    try:
+        b = T.parse_args(common + ["--method", "retrain", "--rank", "4", "--max_train_steps", "2", "--snr_gamma", "5.0",
+                                   "--noise_offset", "0.1", "--mixed_precision", "fp16"])
+        assert T.main(b) and gad.ops.OPERAND_PRECISION[0] == 1
+    finally:
+        gad.set_operand_precision("no")
+
+
+def test_trainer_loss_weights_and_min_snr():
+    """loss = mean_b w_b mse_b (train_text_to_image_lora.py:1276-1298): w = 1 is the unweighted step bit for bit,
+    w = 2 doubles loss and gradient; the weights follow min(SNR, gamma) / SNR."""
+    import gad
+    from gad.schedulers import min_snr_weights
+    sch = gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+    ts = torch.tensor([0, 10, 500, 999])
+    a = sch.alphas_cumprod[ts].double()
+    snr = a / (1 - a)
+    assert torch.allclose(min_snr_weights(sch.alphas_cumprod, ts, 5.0).double(), torch.clamp(snr, max=5.0) / snr, rtol=1e-5)
+    x, ctx, t = rnd(4, 4, 16, 16, seed=1).to(dev), rnd(4, 77, 96, seed=2).to(dev), ts.to(dev)
+    noise = rnd(4, 4, 16, 16, seed=3).to(dev)
+    res = []
+    for w in (None, torch.ones(4, device=dev), 2 * torch.ones(4, device=dev)):
+        _, net = _pair(lora_rank=8)
+        params = [p for n, p in net.named_parameters() if "lora_layer" in n]
+        tr = gad.FusedTrainer(net, sch, None, lr=0.0, max_grad_norm=None, params=params)
+        loss = tr.step(x, noise, t, ctx, loss_weights=w)
+        res.append((loss.item(), tr.gflat.clone()))
+    assert res[0][0] == pytest.approx(res[1][0], rel=1e-6) and torch.equal(res[0][1], res[1][1])
+    assert res[2][0] == pytest.approx(2 * res[0][0], rel=1e-6) and torch.allclose(res[2][1], 2 * res[0][1], rtol=1e-6, atol=0)
 
 
 def test_guided_latent_sampling_matches_oracle_loop():
