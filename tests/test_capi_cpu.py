@@ -54,3 +54,24 @@ def test_product_path_has_no_cpu_fallback():
                           sample_size=8)
     with pytest.raises(_capi.GadError):
         net(torch.zeros(1, 3, 8, 8), torch.tensor([1]))
+
+
+def test_error_state_is_per_thread():
+    """the library is re-entrant; the last-error string is thread-local, so concurrent host threads
+    (one per sampling stream) cannot read each other's failures."""
+    import threading
+    lib = _capi.load()
+    seen = {}
+
+    def worker(name, make_error):
+        if make_error:
+            a = _capi.GemmArgs()
+            assert lib.gad_gemm(ctypes.byref(a), None) != 0
+        barrier.wait()
+        seen[name] = bytes(lib.gad_last_error())
+
+    barrier = threading.Barrier(2)
+    ts = [threading.Thread(target=worker, args=("bad", True)), threading.Thread(target=worker, args=("good", False))]
+    [t.start() for t in ts]
+    [t.join() for t in ts]
+    assert b"null" in seen["bad"] and seen["good"] == b""
