@@ -1,7 +1,7 @@
 // Two-stage, deterministic, segmented column sums:  out[s][n] = sum_m x[s][m][n].
 // Stage 1: grid (nparts, S); a 256-thread block covers N/4 float4 columns x R row lanes
 //          (coalesced float4 reads along n), LDS-combines the row lanes -> part[s][p][n].
-// Stage 2: grid (ceil(N/64), S); 64 columns x 4 part lanes per block -> out.
+// Stage 2: grid (ceil(N/16), S); 16 columns x 16 part lanes per block, LDS tree -> out.
 // Used for bias / time-embedding gradients and GroupNorm dgamma / dbeta.
 #pragma once
 #include "gad_common.h"
@@ -46,18 +46,33 @@ __global__ __launch_bounds__(NT) void colsum_part_scalar(const float* __restrict
 
 // out0/out1: plain (out1 == nullptr): out0[s][n].  De-interleaving (out1 != nullptr, S == 1):
 // even columns -> out0[n/2], odd columns -> out1[n/2]   (GroupNorm: (dbeta, dgamma) pairs)
+// Block = 16 columns x 16 part lanes: the partials are few hundred rows of a small matrix, so the kernel is a
+// latency chain - short per-thread loops and many blocks matter, not bandwidth.  Fixed summation order.
+constexpr int FC = 16, FL = NT / FC;
 __global__ __launch_bounds__(NT) void colsum_final(const float* __restrict__ part, float* __restrict__ out0,
                                                    float* __restrict__ out1, int nparts, int N) {
   __shared__ float red[NT];
-  const int seg = blockIdx.y, col = threadIdx.x & 63, lane = threadIdx.x >> 6;
-  const int n = blockIdx.x * 64 + col;
-  float t = 0.f;
-  if (n < N)
-    for (int k = lane; k < nparts; k += 4) t += part[((long)seg * nparts + k) * N + n];
-  red[threadIdx.x] = t;
+  const int seg = blockIdx.y, col = threadIdx.x % FC, lane = threadIdx.x / FC;
+  const int n = blockIdx.x * FC + col;
+  float t0 = 0.f, t1 = 0.f;
+  if (n < N) {
+    const float* p = part + (long)seg * nparts * N + n;
+    int k = lane;
+    for (; k + FL < nparts; k += 2 * FL) {     // two independent chains per thread
+      t0 += p[(long)k * N];
+      t1 += p[(long)(k + FL) * N];
+    }
+    if (k < nparts) t0 += p[(long)k * N];
+  }
+  red[threadIdx.x] = t0 + t1;
   __syncthreads();
+#pragma unroll
+  for (int st = FL / 2; st >= 1; st >>= 1) {
+    if (lane < st) red[threadIdx.x] += red[threadIdx.x + st * FC];
+    __syncthreads();
+  }
   if (lane == 0 && n < N) {
-    float v = red[col] + red[64 + col] + red[128 + col] + red[192 + col];
+    float v = red[col];
     if (out1 == nullptr) out0[(long)seg * N + n] = v;
     else if (n & 1) out1[n >> 1] = v;
     else out0[n >> 1] = v;
@@ -88,7 +103,7 @@ static inline void launch(const float* x, float* out0, float* out1, int S, long 
     hipLaunchKernelGGL(colsum_part_vec, dim3(p.nparts, S), dim3(NT), 0, st, x, ws, M, N, p.rows_per, p.nparts);
   else
     hipLaunchKernelGGL(colsum_part_scalar, dim3(p.nparts, S), dim3(NT), 0, st, x, ws, M, N, p.rows_per, p.nparts);
-  hipLaunchKernelGGL(colsum_final, dim3((N + 63) / 64, S), dim3(NT), 0, st, (const float*)ws, out0, out1, p.nparts, N);
+  hipLaunchKernelGGL(colsum_final, dim3((N + FC - 1) / FC, S), dim3(NT), 0, st, (const float*)ws, out0, out1, p.nparts, N);
 }
 
 }  // namespace

@@ -56,6 +56,8 @@ struct DevArgs {
   const float* A;
   const float* B;
   float* C;
+  const float* A2;   // two-source conv gather (virtual channel concat): channels >= a_split come from A2
+  int a_split, ldx2;
   int M, N, K;
   int lda, ldb, ldc;
   int batch_inner;
@@ -208,10 +210,12 @@ struct LoadMCDense : MCSlots<ROWS> {
 
 // im2col gather, rows = output pixels, k = (r, s, c).  TRANSPOSED = dgrad form:
 // rows = pixels of the conv INPUT grid, source = dy, src = (row + pad - tap)/stride.
-template <int ROWS, bool TRANSPOSED, int VEC>
+template <int ROWS, bool TRANSPOSED, int VEC, bool TWO = false>
 struct LoadConvRows : KCSlots<ROWS> {
   using S = KCSlots<ROWS>;
   const float* x;
+  const float* x2;    // TWO: second source of the channel concatenation
+  int csplit, ldx2;
   gad_conv_geom g;
   FastDiv fdC, fdKW;
   int bh[S::NS], bw[S::NS], boff[S::NS];  // per row: base h, base w, image pixel offset
@@ -221,6 +225,9 @@ struct LoadConvRows : KCSlots<ROWS> {
   bool kok;
   __device__ void init(const float* x_, const DevArgs& p, int row0, int nrows, int kend_) {
     x = x_;
+    x2 = p.A2;
+    csplit = p.a_split;
+    ldx2 = p.ldx2;
     g = p.g;
     fdC = p.fdC;
     fdKW = p.fdKW;
@@ -247,7 +254,8 @@ struct LoadConvRows : KCSlots<ROWS> {
     }
   }
   // element offset of slot i's pixel for tap (rr,ss); computed unconditionally, `ok` says if it is real
-  __device__ __forceinline__ long pix(int i, int rr, int ss, bool& ok) const {
+  __device__ __forceinline__ long pix(int i, int rr, int ss, bool& ok) const { return (long)pixidx(i, rr, ss, ok) * g.ldx; }
+  __device__ __forceinline__ int pixidx(int i, int rr, int ss, bool& ok) const {
     int ih, iw;
     if (TRANSPOSED) {
       int nh = bh[i] - rr, nw = bw[i] - ss;
@@ -273,7 +281,7 @@ struct LoadConvRows : KCSlots<ROWS> {
       ih >>= 1;
       iw >>= 1;
     }
-    return (long)(boff[i] + ih * g.W + iw) * g.ldx;
+    return boff[i] + ih * g.W + iw;
   }
   __device__ __forceinline__ void prep(int k0, unsigned& mask) {
     k = k0 + S::kq4();
@@ -287,6 +295,13 @@ struct LoadConvRows : KCSlots<ROWS> {
   }
   __device__ __forceinline__ const float* src(int i) const {
     bool ok;
+    if (TWO) {
+      int pi = pixidx(i, r, s, ok);
+      ok = ok && kok && ((rowmask >> i) & 1u);
+      const bool second = c >= csplit;   // a 32-channel K step lies inside one source (a_split % 32 == 0)
+      long off = second ? (long)pi * ldx2 + (c - csplit) : (long)pi * g.ldx + c;
+      return sel_src(second ? x2 : x, off, ok);
+    }
     long off = pix(i, r, s, ok) + c;
     ok = ok && kok && ((rowmask >> i) & 1u);
     return sel_src(x, off, ok);
@@ -425,6 +440,12 @@ struct ALoader<GAD_A_MC, ROWS, VEC> : LoadMCDense<ROWS, VEC> {
 };
 template <int ROWS, int VEC>
 struct ALoader<GAD_A_CONV, ROWS, VEC> : LoadConvRows<ROWS, false, VEC> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p, row0, p.M, kend); }
+};
+constexpr int A_CONV2 = 16;   // internal: A_CONV reading a two-source channel concatenation
+template <int ROWS, int VEC>
+struct ALoader<A_CONV2, ROWS, VEC> : LoadConvRows<ROWS, false, VEC, true> {
   static constexpr bool KC = true;
   __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p, row0, p.M, kend); }
 };
@@ -981,8 +1002,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   }
   if (convA || geomB) {
     const gad_conv_geom& g = a->g;
-    GAD_CHECK(g.H > 0 && g.W > 0 && g.C > 0 && g.Ho > 0 && g.Wo > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0 && g.ldx >= g.C,
-              "gad_gemm: bad conv geometry");
+    GAD_CHECK(g.H > 0 && g.W > 0 && g.C > 0 && g.Ho > 0 && g.Wo > 0 && g.KH > 0 && g.KW > 0 && g.stride > 0 &&
+              g.ldx >= (a->A2 ? a->a_split : g.C), "gad_gemm: bad conv geometry");
     GAD_CHECK((long)g.H * g.W * g.ldx < (1L << 31), "gad_gemm: image too large for 32-bit pixel offsets");
     if (convA) {
       GAD_CHECK(a->K == g.KH * g.KW * g.C, "gad_gemm: conv K=%d != KH*KW*C=%d", a->K, g.KH * g.KW * g.C);
@@ -1001,6 +1022,13 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       if (g.C % 4 != 0 || g.ldx % 4 != 0) vec = 1;
     }
   }
+  if (a->A2) {
+    GAD_CHECK(am == GAD_A_CONV && bmode == GAD_B_KC, "gad_gemm: A2 (two-source gather) is an A_CONV x B_KC feature");
+    GAD_CHECK(a->a_split > 0 && a->a_split < a->g.C && a->a_split % 32 == 0 && a->g.C % 32 == 0,
+              "gad_gemm: two-source gather needs a_split and C multiples of 32 (a_split=%d C=%d)", a->a_split, a->g.C);
+    GAD_CHECK(a->ldx2 >= a->g.C - a->a_split && a->ldx2 % 4 == 0 && gad_aligned16(a->A2) && vec == 4,
+              "gad_gemm: two-source gather: bad ldx2 / alignment");
+  }
   if (a->rowadd) GAD_CHECK(a->rows_per_group > 0 && a->ld_rowadd >= a->N, "gad_gemm: bad rowadd");
   if (a->residual) GAD_CHECK(a->ldr >= a->N, "gad_gemm: bad residual stride");
   GAD_CHECK(a->ldc >= a->N, "gad_gemm: ldc < N");
@@ -1015,6 +1043,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
+  d.A2 = a->A2; d.a_split = a->a_split; d.ldx2 = a->ldx2;
   d.M = a->M; d.N = a->N; d.K = a->K;
   d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
   d.batch_inner = a->batch_inner > 0 ? a->batch_inner : 1;
@@ -1038,6 +1067,10 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (a->A2) {
+    if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
+    else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);
+  } else
 #define GAD_CASE(AMODE, BMODE_)                                                        \
   if (am == AMODE && bmode == BMODE_) {                                                \
     if (bf16) launch_bf16<AMODE, BMODE_>(d, pl, st);                                   \

@@ -183,8 +183,10 @@ __device__ __forceinline__ void slab_reduce(float* red, float val, const SlabGeo
   __syncthreads();
 }
 
+// x2 != nullptr: channels [C1, C) of the (virtual) concatenation live in x2 ([B][HW][C-C1]); a slab never straddles C1
 template <int NV>
-__global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, float* __restrict__ y,
+__global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
+                                                     float* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      SlabGeo s, float eps, int silu) {
@@ -196,11 +198,14 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   const bool act = pl < s.PL;
   const int c0 = sl * s.SC + q * 4;
   const long base = ((long)b * s.HW) * s.C + c0;
+  const bool second = c0 >= C1;                       // block-uniform: slabs do not straddle the split
+  const int ldin = second ? s.C - C1 : C1;
+  const float* xin = (second ? x2 + (c0 - C1) : x + c0) + ((long)b * s.HW) * ldin;
   f32x4 v[NV];
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     int p = pl + i * s.PL;
-    v[i] = (act && p < s.HW) ? *reinterpret_cast<const f32x4*>(x + base + (long)p * s.C) : f32x4{0.f, 0.f, 0.f, 0.f};
+    v[i] = (act && p < s.HW) ? *reinterpret_cast<const f32x4*>(xin + (long)p * ldin) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
@@ -261,6 +266,7 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out) {
   for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
     int SC = k * cpg;
     if (a->C % SC != 0) continue;
+    if (a->x2 && (a->C1 % SC != 0)) continue;          // two sources: a slab must lie inside one of them
     if ((SC * 4) % 128 != 0 && SC != a->C) continue;   // slab rows must be whole 128-B lines, or two workgroups fetch each line
     int qpr = SC / 4;
     if (qpr > NT) break;
@@ -423,19 +429,32 @@ extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
   return parts + gad_reduce::ws_bytes(1, (long)a->B * g.nch, 2 * a->C);       // + dgamma/dbeta reduction
 }
 
+extern "C" int gad_groupnorm_one_pass(const gad_groupnorm_args* a) {
+  if (!a || a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G != 0 || a->C % 4 != 0) return 0;
+  const char* two = getenv("GAD_GN_TWO_PASS");
+  if (two && atoi(two)) return 0;
+  SlabGeo sg;
+  return make_slab(a, &sg) ? 1 : 0;
+}
+
 extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream) {
   if (check(a, "gad_groupnorm_silu_fwd")) return 1;
   hipStream_t st = (hipStream_t)stream;
   SlabGeo sg;
   const char* two = getenv("GAD_GN_TWO_PASS");
   int nv = (two && atoi(two)) ? 0 : make_slab(a, &sg);
+  if (a->x2) {
+    GAD_CHECK(nv, "gad_groupnorm_silu_fwd: the two-source input needs the one-pass plan (check gad_groupnorm_one_pass)");
+    GAD_CHECK(a->C1 > 0 && a->C1 < a->C && a->C1 % 4 == 0 && gad_aligned16(a->x2), "gad_groupnorm_silu_fwd: bad C1 / x2");
+  }
   if (nv) {
+    const int c1 = a->x2 ? a->C1 : a->C;
     dim3 sgrid(a->B * sg.nslab), sblock(NT);
     switch (nv) {
-      case 4: hipLaunchKernelGGL(gn_slab_kernel<4>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      case 8: hipLaunchKernelGGL(gn_slab_kernel<8>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      case 16: hipLaunchKernelGGL(gn_slab_kernel<16>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      default: hipLaunchKernelGGL(gn_slab_kernel<32>, sgrid, sblock, 0, st, a->x, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 4: hipLaunchKernelGGL(gn_slab_kernel<4>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 8: hipLaunchKernelGGL(gn_slab_kernel<8>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 16: hipLaunchKernelGGL(gn_slab_kernel<16>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      default: hipLaunchKernelGGL(gn_slab_kernel<32>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
     }
     GAD_LAUNCH_CHECK("gn_slab");
     return 0;

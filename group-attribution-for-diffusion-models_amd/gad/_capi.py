@@ -33,7 +33,8 @@ class GemmArgs(C.Structure):
                 ("rows_per_group", C.c_int32), ("ld_rowadd", C.c_int32),
                 ("residual", C.c_void_p), ("ldr", C.c_int32),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32)]
+                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32),
+                ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -41,7 +42,8 @@ class GroupNormArgs(C.Structure):
                 ("mean", C.c_void_p), ("rstd", C.c_void_p), ("dy", C.c_void_p),
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("G", C.c_int32),
-                ("eps", C.c_float), ("silu", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64)]
+                ("eps", C.c_float), ("silu", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+                ("x2", C.c_void_p), ("C1", C.c_int32)]
 
 
 class AdamArgs(C.Structure):
@@ -63,6 +65,7 @@ SIGNATURES = {
     "gad_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "gad_gemm_uses_bf16": (C.c_int, [C.POINTER(GemmArgs)]),
+    "gad_groupnorm_one_pass": (C.c_int, [C.POINTER(GroupNormArgs)]),
     "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),

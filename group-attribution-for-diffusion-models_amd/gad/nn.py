@@ -39,7 +39,9 @@ class Conv2d(nn.Module):
         self.bias = nn.Parameter(ref.bias.detach().clone())
         self.stride, self.pad, self.upsample = stride, tuple(pad), upsample
 
-    def forward(self, x, rowadd=None, residual=None):
+    def forward(self, x, rowadd=None, residual=None, x2=None):
+        if x2 is not None:       # channel concat read in place (inference only: the raw launch has no autograd node)
+            return ops.conv2d_fwd_raw(x, self.weight, self.bias, self.stride, self.pad, self.upsample, rowadd, residual, x2=x2)
         return ops.conv2d(x, self.weight, self.bias, rowadd, residual, self.stride, self.pad, self.upsample)
 
 
@@ -91,7 +93,9 @@ class GroupNorm(nn.Module):
         self.bias = nn.Parameter(torch.zeros(channels))
         self.num_groups, self.eps = groups, eps
 
-    def forward(self, x, silu=False):
+    def forward(self, x, silu=False, x2=None):
+        if x2 is not None:
+            return ops.group_norm_cat_raw(x, x2, self.weight, self.bias, self.num_groups, self.eps, silu)
         return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu)
 
 
@@ -108,12 +112,19 @@ class ResnetBlock2D(nn.Module):
         self.conv2 = Conv2d(cout, cout, 3)
         self.conv_shortcut = Conv2d(cin, cout, 1, pad=(0, 0, 0, 0)) if cin != cout else None
 
-    def forward(self, x, temb_act):
-        h = self.norm1(x, silu=True)
+    def forward(self, x, temb_act, x2=None):
+        """x2: the block input is cat([x, x2], channels) (up blocks); norm1 and conv_shortcut read both in place."""
+        h = self.norm1(x, silu=True, x2=x2)
         h = self.conv1(h, rowadd=self.time_emb_proj(temb_act))       # conv + bias + temb add, one kernel
         h = self.norm2(h, silu=True)
-        sc = self.conv_shortcut(x) if self.conv_shortcut is not None else x
+        sc = self.conv_shortcut(x, x2=x2) if self.conv_shortcut is not None else x
         return self.conv2(h, residual=sc)                             # conv + bias + skip add, one kernel
+
+    def cat_in_place_ok(self, x, x2):
+        """Inference only, and only when both consumers of the concatenation can gather from two sources."""
+        return (not torch.is_grad_enabled() and self.conv_shortcut is not None
+                and ops.two_source_ok(x.shape[-1], x2.shape[-1])
+                and ops.group_norm_two_source_ok(x, x2, self.norm1.num_groups))
 
 
 class Attention(nn.Module):
@@ -209,7 +220,8 @@ class UpBlock(nn.Module):
     def forward(self, h, skips, temb_act):
         for i, r in enumerate(self.resnets):
             s, skips = skips[-1], skips[:-1]
-            h = r(ops.concat(h, s), temb_act)
+            # torch.cat([h, skip], 1) of UpBlock2D; when sampling, its two consumers read h and skip in place
+            h = r(h, temb_act, x2=s) if r.cat_in_place_ok(h, s) else r(ops.concat(h, s), temb_act)
             if self.attentions is not None:
                 h = self.attentions[i](h)
         if self.upsamplers is not None:

@@ -140,7 +140,7 @@ def set_operand_precision(name):
 
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -162,6 +162,8 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
     a.operand_precision = OPERAND_PRECISION[0]
+    if A2 is not None:
+        a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -217,23 +219,37 @@ def _conv_out_size(h, k, stride, pad_lo, pad_hi):
 
 
 def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowadd=None, residual=None,
-                   tile_hint=0, splitk_hint=0):
-    """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; pad = (top, bottom, left, right)."""
+                   tile_hint=0, splitk_hint=0, x2=None):
+    """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; pad = (top, bottom, left, right).
+    x2 [B,H,W,C2]: the conv input is cat([x, x2], channels) without materialising it (UpBlock2D's skip concat)."""
     _req(x, "conv x")
-    Bn, H, W, Cin = x.shape
+    Bn, H, W, C1 = x.shape
+    Cin = C1
+    if x2 is not None:
+        _req(x2, "conv x2")
+        if x2.shape[:3] != x.shape[:3]:
+            raise _capi.GadError(f"conv x2 {tuple(x2.shape)} does not match x {tuple(x.shape)}")
+        Cin = C1 + x2.shape[-1]
     wk = weight_krsc(w)
-    Cout, KH, KW, _ = wk.shape
+    Cout, KH, KW, wc = wk.shape
+    if wc != Cin:
+        raise _capi.GadError(f"conv weight expects {wc} input channels, got {Cin}")
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     Ho = _conv_out_size(He, KH, stride, pad[0], pad[1])
     Wo = _conv_out_size(We, KW, stride, pad[2], pad[3])
     y = torch.empty((Bn, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
-    g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
+    g = ConvGeom(H, W, Cin, C1, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     if residual is not None:
         _req(residual, "conv residual")
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
-             tile_hint=tile_hint, splitk_hint=splitk_hint)
+             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1)
     return y
+
+
+def two_source_ok(c1: int, c2: int) -> bool:
+    """Can conv2d_fwd_raw(x, ..., x2=) gather this channel split? (32-channel K steps must not straddle it)"""
+    return c1 % 32 == 0 and c2 % 32 == 0
 
 
 def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0):
@@ -440,6 +456,36 @@ class GroupNormSiluFn(torch.autograd.Function):
 
 def group_norm(x, gamma, beta, G, eps, silu):
     return GroupNormSiluFn.apply(x, gamma, beta, G, eps, silu)
+
+
+def _gn2_args(x, x2, y, gamma, beta, mean, rstd, G, eps, silu):
+    a = _gn_args(y, y, gamma, beta, mean, rstd, G, eps, silu)      # shapes of the concatenated tensor = y's
+    a.x, a.x2, a.C1 = x.data_ptr(), x2.data_ptr(), x.shape[-1]
+    return a
+
+
+def group_norm_two_source_ok(x, x2, G) -> bool:
+    """Does the forward of GroupNorm(cat([x, x2], channels)) have a one-pass plan that reads both sources in place?"""
+    C_ = x.shape[-1] + x2.shape[-1]
+    if C_ % G or C_ % 4:
+        return False
+    a = GroupNormArgs()
+    a.B, a.C, a.G = x.shape[0], C_, G
+    a.HW = x.numel() // (x.shape[0] * x.shape[-1])
+    a.x2, a.C1 = x2.data_ptr(), x.shape[-1]
+    return bool(_capi.load().gad_groupnorm_one_pass(C.byref(a)))
+
+
+def group_norm_cat_raw(x, x2, gamma, beta, G, eps, silu):
+    """[SiLU](GroupNorm(cat([x, x2], -1))) without the concatenated tensor (forward only, no autograd)."""
+    _req(x, "groupnorm x")
+    _req(x2, "groupnorm x2")
+    y = torch.empty((*x.shape[:-1], x.shape[-1] + x2.shape[-1]), device=x.device, dtype=torch.float32)
+    mean = torch.empty((x.shape[0], G), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    a = _gn2_args(x, x2, y, gamma, beta, mean, rstd, G, eps, silu)
+    check(_capi.load().gad_groupnorm_silu_fwd(C.byref(a), _stream()), "gad_groupnorm_silu_fwd")
+    return y
 
 
 class SiluFn(torch.autograd.Function):

@@ -146,7 +146,7 @@ class _UpBlock(nn.Module):
     def forward(self, h, skips, temb_act, context, scale):
         for i, r in enumerate(self.resnets):
             s, skips = skips[-1], skips[:-1]
-            h = r(ops.concat(h, s), temb_act)
+            h = r(h, temb_act, x2=s) if r.cat_in_place_ok(h, s) else r(ops.concat(h, s), temb_act)
             if self.cross:
                 h = self.attentions[i](h, context, scale)
         if self.upsamplers is not None:

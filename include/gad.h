@@ -89,6 +89,11 @@ typedef struct gad_gemm_args {
    *    (text_to_image/train_text_to_image_lora.py:659-668) - whenever both operands can be read as 16-B aligned
    *    float4 (else the launch runs in fp32).  gad_gemm_uses_bf16() tells which. */
   int32_t operand_precision;
+  /* A_CONV only: the gathered tensor is the channel concatenation of A ([..][ldx >= a_split], channels
+   * [0, a_split)) and A2 ([..][ldx2], channels [a_split, g.C)) - UpBlock2D's torch.cat without the copy.
+   * A2 == NULL: single source.  a_split must be a multiple of 32. */
+  const float* A2;
+  int32_t a_split, ldx2;
 } gad_gemm_args;
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
@@ -120,9 +125,16 @@ typedef struct gad_groupnorm_args {
   int32_t silu;
   void* ws;
   int64_t ws_bytes;
+  /* forward only: channel-concatenated input without the concat (UpBlock2D's torch.cat([h, skip], 1),
+   * SURVEY A.1): channels [0, C1) come from x ([B][HW][C1]) and [C1, C) from x2 ([B][HW][C-C1]).
+   * x2 == NULL: single source.  Needs the one-pass plan (gad_groupnorm_one_pass) with slabs inside one source. */
+  const float* x2;
+  int32_t C1;
 } gad_groupnorm_args;
 
 int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a);
+/* 1 if the forward of these shapes (incl. the x2/C1 split, if any) runs as the one-pass register-slab kernel */
+int gad_groupnorm_one_pass(const gad_groupnorm_args* a);
 int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream);
 int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
 

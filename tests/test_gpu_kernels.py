@@ -476,3 +476,53 @@ def test_unet_forward_backward_bf16_close_to_fp32(ops):
     assert 0 < rel < 2e-2, rel
     cos = torch.nn.functional.cosine_similarity(grads["bf16"], grads["f32"], dim=0).item()
     assert cos > 0.999, cos
+
+
+# -------------------------------------------------- channel concat read in place (up blocks) ----
+@pytest.mark.parametrize("C1,C2,H,k", [(128, 128, 16, 1), (256, 128, 8, 1), (64, 32, 8, 3), (256, 256, 4, 3)])
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_conv_two_source_equals_concat(ops, C1, C2, H, k, prec):
+    """conv(cat([x, x2])) with the gather reading x and x2 in place: same kernel arithmetic as on the materialised
+    concatenation, so bit-identical to it; and equal to the fp64 convolution."""
+    x, x2 = rnd(2, C1, H, H, seed=1), rnd(2, C2, H, H, seed=2)
+    w, b = rnd(96, C1 + C2, k, k, seed=3, scale=1 / math.sqrt((C1 + C2) * k * k)), rnd(96, seed=4)
+    pad = (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
+    with ops.operand_precision(prec):
+        got = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), 1, pad, False, x2=nhwc(x2))
+        cat = ops.conv2d_fwd_raw(torch.cat([nhwc(x), nhwc(x2)], -1).contiguous(), cl_weight(w), b.to(dev), 1, pad, False)
+    assert torch.equal(got, cat)
+    if prec == "f32":
+        close(got.permute(0, 3, 1, 2), conv_ref(torch.cat([x, x2], 1), w, b, 1, pad, False), atol=3e-5)
+    with pytest.raises(Exception):
+        ops.conv2d_fwd_raw(nhwc(x)[..., :24].contiguous(), cl_weight(w[:, :24 + C2].contiguous()), None, 1, pad, False, x2=nhwc(x2))
+
+
+@pytest.mark.parametrize("B,C1,C2,H", [(3, 128, 128, 32), (2, 256, 256, 16), (2, 256, 256, 8), (2, 256, 256, 4), (2, 64, 64, 8)])
+def test_groupnorm_two_source_equals_concat(ops, B, C1, C2, H):
+    x, x2 = nhwc(rnd(B, C1, H, H, seed=1) + 0.5), nhwc(rnd(B, C2, H, H, seed=2) * 2)
+    ga, be = (rnd(C1 + C2, seed=3) * 0.3 + 1).to(dev), rnd(C1 + C2, seed=4).to(dev)
+    assert ops.group_norm_two_source_ok(x, x2, 32)
+    got = ops.group_norm_cat_raw(x, x2, ga, be, 32, 1e-6, True)
+    with torch.no_grad():
+        want = ops.group_norm(torch.cat([x, x2], -1).contiguous(), ga, be, 32, 1e-6, True)
+    assert torch.equal(got, want)
+
+
+def test_groupnorm_two_source_needs_a_slab_inside_each_source(ops):
+    x, x2 = nhwc(rnd(1, 256, 16, 16, seed=1)), nhwc(rnd(1, 128, 16, 16, seed=2))     # 384 channels: 12 per group, slab 96
+    assert not ops.group_norm_two_source_ok(x, x2, 32)
+    with pytest.raises(Exception):
+        ops.group_norm_cat_raw(x, x2, torch.ones(384, device=dev), torch.zeros(384, device=dev), 32, 1e-6, True)
+
+
+def test_unet_sampling_forward_without_concat_equals_grad_mode_forward(ops):
+    """no_grad forward (up blocks read h and the skip in place) vs grad-mode forward (materialised torch.cat)."""
+    import gad
+    from src.ddpm_config import DDPMConfig
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**DDPMConfig.cifar100_config["unet_config"]).to(dev)
+    x, t = rnd(3, 3, 32, 32, seed=1).to(dev), torch.tensor([1, 500, 999], device=dev)
+    with torch.no_grad():
+        a = net(x, t).sample
+    b = net(x, t).sample.detach()
+    assert torch.equal(a, b)
