@@ -832,6 +832,162 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution forward with bf16 operands from an LDS-resident input patch.
+// A workgroup owns 128 consecutive output pixels of one image = TR = 128 / W whole rows.  Per 32-channel chunk the
+// (TR+2) x (W+2) input patch (halo included, zeros outside the image) is fetched ONCE, rounded to bf16 and kept in LDS;
+// the nine taps read their A fragments from that patch at shifted pixel offsets (ds_read_b128, 80-B pixel stride:
+// conflict-free), so the input is not re-gathered per tap: global fetch of the A operand drops 9x -> (TR+2)(W+2)/(TR W)x
+// and the per-step address arithmetic disappears.  Weights stream through a double-buffered [128][32+8] bf16 tile
+// per (chunk, tap) exactly as in gemm_bf16_kernel.  K order = (chunk, tap); fp32 accumulation; same epilogue.
+// ------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevArgs p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int TR = BM / W, PW = W + 2, PR = TR + 2, NPIX = PR * PW;
+  constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;      // float4 slots per thread per patch
+  constexpr int P_TILE = NPIX * LDK;                                 // bf16 elements
+  constexpr int B_TILE = BN * LDK;
+  using BL = BLoader<GAD_B_KC, BN, 4>;
+  __shared__ __attribute__((aligned(16))) unsigned short lds[2 * P_TILE + 2 * B_TILE];
+  unsigned short* const patch0 = lds;
+  unsigned short* const btile0 = lds + 2 * P_TILE;
+
+  int nwg = gridDim.x, bid = blockIdx.x;
+  int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int H = p.g.H, C = p.g.C;
+  const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
+  const int nchunks = C / BK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  // patch slots of this thread: slot j = tid + 256 i -> patch pixel j / 8, float4 j % 8
+  int poff[PSLOTS];     // element offsets fit 32 bits (the host checks pixels * ldx < 2^31)
+  unsigned pvalid = 0;
+#pragma unroll
+  for (int i = 0; i < PSLOTS; ++i) {
+    int j = tid + NTHREADS * i;
+    int pp = j >> 3, q4 = (j & 7) * 4;
+    int pr = pp / PW, pc = pp - pr * PW;
+    int ih = oh0 + pr - 1, iw = pc - 1;
+    bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    poff[i] = ok ? ((img * H + ih) * W + iw) * p.g.ldx + q4 : 0;
+    pvalid |= (unsigned)ok << i;
+  }
+  static_assert(PSLOTS <= 8, "one patch slot per tap, committed at the next tap");
+  // slot i of the NEXT chunk's patch is fetched at tap i and written to the other patch buffer at tap i + 1
+  // (that buffer was last read in the previous chunk), so only one float4 of the patch is in registers at a time
+  f32x4 rp1;
+  auto fetch_slot = [&](int i, int chunk) { rp1 = ldg4(sel_src(p.A, (long)poff[i] + chunk * BK, (pvalid >> i) & 1u)); };
+  auto commit_slot = [&](int i, unsigned short* dst) {
+    int j = tid + NTHREADS * i;
+    if (j < NPIX * 8) store_bf16x4(dst + (j >> 3) * LDK + (j & 7) * 4, rp1);
+  };
+
+  BL bl;
+  bl.setup(p, p.B, col0, p.K);
+  f32x4 rb[BL::NS];
+  unsigned mdummy = 0;
+  auto fetch_b = [&](int k0) {
+    bl.prep(k0, mdummy);
+#pragma unroll
+    for (int i = 0; i < BL::NS; ++i) rb[i] = ldg4(bl.src(i));
+  };
+  auto commit_b = [&](unsigned short* tb) {
+#pragma unroll
+    for (int i = 0; i < BL::NS; ++i) Bf16Tile<true, BN>::put(tb, i, rb[i]);
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  // A-fragment base of this lane inside a patch: output pixel m -> patch pixel (m / W) * PW + m % W (+ tap shift)
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int m = wm * (BM / 2) + i * 32 + l31;
+    abase[i] = ((m / W) * PW + (m % W)) * LDK + 8 * h;
+  }
+
+#pragma unroll
+  for (int i = 0; i < PSLOTS; ++i) {
+    fetch_slot(i, 0);
+    commit_slot(i, patch0);
+  }
+  fetch_b(0);
+  commit_b(btile0);
+  __syncthreads();
+
+  const int nsteps = nchunks * 9;
+  int chunk = 0, tap = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    const unsigned short* pa = patch0 + (chunk & 1) * P_TILE;
+    const unsigned short* lb = btile0 + (st & 1) * B_TILE;
+    unsigned short* nb = btile0 + ((st + 1) & 1) * B_TILE;
+    // next step's weights; at the first tap also the next chunk's patch (past the end: zeros / clamped chunk)
+    int ntap = tap + 1, nchunk = chunk;
+    if (ntap == 9) { ntap = 0; ++nchunk; }
+    fetch_b(st + 1 < nsteps ? ntap * C + nchunk * BK : p.K);
+    unsigned short* const pnext = patch0 + ((chunk + 1) & 1) * P_TILE;
+    const int cnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform; the unrolled compare keeps poff[] in registers
+      if (tap == i + 1) commit_slot(i, pnext);
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i)
+      if (tap == i) fetch_slot(i, cnext);
+    const int r = tap / 3, s3 = tap - r * 3;
+    const int tshift = (r * PW + s3) * LDK;
+#pragma unroll
+    for (int ks = 0; ks < 2; ++ks) {
+      bf16x8_t fa[TM], fb[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + abase[i] + tshift + ks * 16);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) fb[j] = Bf16Tile<true, BN>::frag(lb, wn * (BN / 2) + j * 32, ks, lane);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+          acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
+    }
+    commit_b(nb);
+    __syncthreads();
+    tap = ntap;
+    chunk = nchunk;
+  }
+
+  float* Cp = p.C;
+  const float* R = p.residual;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+    float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e] * p.alpha + bias;
+        if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
+        if (R) v += R[(long)m * p.ldr + n];
+        Cp[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
 // split-K: C = epilogue(sum_s ws[z][s][m][n])
 __global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
   long total = (long)batch * p.M * p.N;
@@ -956,6 +1112,16 @@ static bool use_bf16(const gad_gemm_args* a) {
   return a->operand_precision == 1 && pick_vec(a) == 4;
 }
 
+// 3x3 / stride 1 / pad 1 forward conv whose 128-pixel tiles are whole rows of one image: the LDS-patch kernel applies
+static bool use_patch_conv(const gad_gemm_args* a) {
+  const gad_conv_geom& g = a->g;
+  const char* off = getenv("GAD_NO_PATCH_CONV");
+  return use_bf16(a) && a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && !a->A2 && g.KH == 3 && g.KW == 3 &&
+         g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && !g.upsample && g.Ho == g.H && g.Wo == g.W &&
+         (g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
+         (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
+}
+
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
@@ -1067,6 +1233,16 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (bf16 && use_patch_conv(a)) {
+    d.tiles_m = (int)gad_ceil_div(a->M, 128);
+    d.tiles_n = (int)gad_ceil_div(a->N, 128);
+    d.splitk = 1;
+    dim3 grid((unsigned)(d.tiles_m * d.tiles_n)), block(NTHREADS);
+    if (a->g.W == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16>), grid, block, 0, st, d);
+    GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
+    return 0;
+  }
   if (a->A2) {
     if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
     else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);
