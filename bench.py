@@ -52,6 +52,8 @@ def parse():
                     help="f32 = the reference's default precision and the headline number; bf16 = bf16-operand "
                          "contractions (fp32 storage/accumulation), the analogue of --mixed_precision: a separate, "
                          "explicitly labelled line, never the default")
+    ap.add_argument("--no-train-rate", action="store_true",
+                    help="skip the separate U-Net steps/s measurement (PMC passes: keeps the launch mix = the timed region's)")
     ap.add_argument("--gd-steps", type=int, default=GD_STEPS)
     ap.add_argument("--n-samples", type=int, default=N_SAMPLES)
     return ap.parse_args()
@@ -228,7 +230,7 @@ def main():
         ops.PROFILER = None
         units = a.steps * world / float(GD_STEPS)
         # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
-        n_tr = 10
+        n_tr = 0 if a.no_train_rate else 10
         barrier()
         t1 = time.time()
         for _ in range(n_tr):
@@ -271,10 +273,11 @@ def main():
             samp_flop = UNET_GFLOP_PER_IMG * 1e9 * N_SAMPLES * DDIM_STEPS / GD_STEPS
             out["unet_tflops_per_gpu"] = (train_flop + samp_flop) * a.steps / dt / 1e12
             out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
-            out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
-                                             "ms_per_step": dt_train / n_tr * 1e3,
-                                             "tflops_per_gpu": train_flop * n_tr / dt_train / 1e12,
-                                             "reference": 3.81}                       # 3.81 steps/s, 1 GPU
+            if n_tr:
+                out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
+                                                 "ms_per_step": dt_train / n_tr * 1e3,
+                                                 "tflops_per_gpu": train_flop * n_tr / dt_train / 1e12,
+                                                 "reference": 3.81}                   # 3.81 steps/s, 1 GPU
         if prof is not None:
             torch.cuda.synchronize(dev)
             summ = prof.summary()
@@ -286,7 +289,12 @@ def main():
             pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
             if os.path.exists(pmc):
                 traffic = json.load(open(pmc)).get("dominant_kernel_hbm_bytes_per_launch")
-            out["roofline"] = {"bound": "mfma", "kernel": f"gemm_kernel<{dom_key[0]}, tile {dom_key[1]}, splitk {dom_key[2]}>",
+            nm = dom_key[0]
+            if "_patch" in nm:      # the name rocprofv3 shows for it
+                kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{nm.rsplit('_w', 1)[1]}> ({nm})"
+            else:
+                kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
+            out["roofline"] = {"bound": "mfma", "kernel": kname,
                                "achieved": d["flops"] / d["ms"] / 1e9, "peak": peak_tf, "unit": "TFLOP/s",
                                "frac": d["flops"] / d["ms"] / 1e9 / peak_tf,
                                "traffic": traffic if a.precision == "f32" else None,

@@ -858,7 +858,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
   int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
   int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
-  const int H = p.g.H, C = p.g.C;
+  // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
+  // tensor is (H/2) x (W/2) and patch pixel (ih, iw) reads stored pixel (ih>>1, iw>>1)
+  const int H = p.g.Ho, C = p.g.C, ups = p.g.upsample;
   const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
   const int nchunks = C / BK;
 
@@ -875,7 +877,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     int pr = pp / PW, pc = pp - pr * PW;
     int ih = oh0 + pr - 1, iw = pc - 1;
     bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
-    poff[i] = ok ? ((img * H + ih) * W + iw) * p.g.ldx + q4 : 0;
+    poff[i] = ok ? ((img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
     pvalid |= (unsigned)ok << i;
   }
   static_assert(PSLOTS <= 8, "one patch slot per tap, committed at the next tap");
@@ -962,6 +964,164 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     }
     commit_b(nb);
     __syncthreads();
+    tap = ntap;
+    chunk = nchunk;
+  }
+
+  float* Cp = p.C;
+  const float* R = p.residual;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+    float bias = p.bias ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e] * p.alpha + bias;
+        if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
+        if (R) v += R[(long)m * p.ldr + n];
+        Cp[(long)m * p.ldc + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
+// fp32 twin of the LDS-patch convolution: exact f32 MFMAs, weights streamed by LDS-DMA exactly as in gemm_kernel, the
+// A operand read from an fp32 input patch [(TR+2)(W+2)][32 + 4 pad] (144-B pixel stride: a phase of 16 consecutive
+// pixels of a ds_read_b128 covers all 64 banks).  Versus the generic kernel the per-step A gather (half of the LDS-DMA
+// traffic, all of the im2col address arithmetic) is gone; the input is fetched (TR+2)(W+2)/(TR W) ~ 1.6x instead of 9x.
+// One patch buffer: the next chunk's patch is prefetched into registers, one float4 per tap, and written between two
+// barriers after the chunk's last tap (one extra barrier per 9 K steps).
+// ------------------------------------------------------------------------------------
+constexpr int PLD = BK + 4;
+template <int W>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevArgs p) {
+  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int TR = BM / W, PW = W + 2, PR = TR + 2, NPIX = PR * PW;
+  constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;
+  constexpr int B_TILE = BK * BN;
+  using BL = BLoader<GAD_B_KC, BN, 4>;
+  static_assert(PSLOTS <= 9, "one patch slot per tap");
+  __shared__ __attribute__((aligned(16))) float lds[NPIX * PLD + 2 * B_TILE];
+  float* const patch = lds;
+  float* const btile0 = lds + NPIX * PLD;
+
+  int nwg = gridDim.x, bid = blockIdx.x;
+  int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
+  int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
+  // tensor is (H/2) x (W/2) and patch pixel (ih, iw) reads stored pixel (ih>>1, iw>>1)
+  const int H = p.g.Ho, C = p.g.C, ups = p.g.upsample;
+  const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
+  const int nchunks = C / BK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  int poff[PSLOTS];
+  unsigned pvalid = 0;
+#pragma unroll
+  for (int i = 0; i < PSLOTS; ++i) {
+    int j = tid + NTHREADS * i;
+    int pp = j >> 3, q4 = (j & 7) * 4;
+    int pr = pp / PW, pc = pp - pr * PW;
+    int ih = oh0 + pr - 1, iw = pc - 1;
+    bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    poff[i] = ok ? ((img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
+    pvalid |= (unsigned)ok << i;
+  }
+  f32x4 rp[PSLOTS];
+  auto commit_patch = [&]() {
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i) {
+      int j = tid + NTHREADS * i;
+      if (j < NPIX * 8) *reinterpret_cast<f32x4*>(patch + (j >> 3) * PLD + (j & 7) * 4) = rp[i];
+    }
+  };
+
+  BL bl;
+  bl.setup(p, p.B, col0, p.K);
+  unsigned mb = 0;
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  int abase[TM];
+#pragma unroll
+  for (int i = 0; i < TM; ++i) {
+    int m = wm * (BM / 2) + i * 32 + l31;
+    abase[i] = ((m / W) * PW + (m % W)) * PLD + 4 * h;
+  }
+
+  // prologue: patch of chunk 0 and the weights of step 0
+  bl.prep(0, mb);
+#pragma unroll
+  for (int q = 0; q < BL::NS; ++q) glds16(bl.src(q), BL::dma_dst(btile0, q));
+#pragma unroll
+  for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i], (pvalid >> i) & 1u));
+  commit_patch();
+  __syncthreads();
+
+  const int nsteps = nchunks * 9;
+  int chunk = 0, tap = 0;
+  for (int st = 0; st < nsteps; ++st) {
+    const float* lb = btile0 + (st & 1) * B_TILE;
+    float* nb = btile0 + ((st + 1) & 1) * B_TILE;
+    int ntap = tap + 1, nchunk = chunk;
+    if (ntap == 9) { ntap = 0; ++nchunk; }
+    bl.prep(st + 1 < nsteps ? ntap * C + nchunk * BK : p.K, mb);     // past the end: zeros
+    const int cnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
+#pragma unroll
+    for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform: one float4 of the next chunk's patch per tap
+      if (tap == i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + cnext * BK, (pvalid >> i) & 1u));
+    const int r = tap / 3, s3 = tap - r * 3;
+    const float* pa = patch + (r * PW + s3) * PLD;
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pa + abase[i]);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int s = 0; s < 4; ++s) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
+        if (g * 4 + s < BL::NS) glds16(bl.src(g * 4 + s), BL::dma_dst(nb, g * 4 + s));
+        if (s == 1 && g < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(pa + abase[i] + 8 * (g + 1));
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+        }
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    __syncthreads();            // weights of step st+1 landed; every wave is done with this tap's reads
+    if (tap == 8) {             // chunk boundary: swap in the prefetched patch
+      commit_patch();
+      __syncthreads();
+    }
     tap = ntap;
     chunk = nchunk;
   }
@@ -1113,16 +1273,30 @@ static bool use_bf16(const gad_gemm_args* a) {
 }
 
 // 3x3 / stride 1 / pad 1 forward conv whose 128-pixel tiles are whole rows of one image: the LDS-patch kernel applies
-static bool use_patch_conv(const gad_gemm_args* a) {
+static bool patch_conv_geom(const gad_gemm_args* a) {
   const gad_conv_geom& g = a->g;
   const char* off = getenv("GAD_NO_PATCH_CONV");
-  return use_bf16(a) && a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && !a->A2 && g.KH == 3 && g.KW == 3 &&
-         g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && !g.upsample && g.Ho == g.H && g.Wo == g.W &&
-         (g.W == 32 || g.W == 16) && (g.H * g.W) % 128 == 0 && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
+  return pick_vec(a) == 4 && a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && !a->A2 && g.KH == 3 && g.KW == 3 &&
+         g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && g.Ho == (g.upsample ? 2 * g.H : g.H) &&
+         g.Wo == (g.upsample ? 2 * g.W : g.W) && (g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0 && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
          (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
+}
+static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch_conv_geom(a); }
+// fp32: only where the planner would have launched the 128x128 tile without split-K anyway
+static bool use_patch_conv_f32(const gad_gemm_args* a, const Plan& pl) {
+  const char* on = getenv("GAD_PATCH_CONV_F32");
+  return !use_bf16(a) && patch_conv_geom(a) && pl.bm == 128 && pl.splitk == 1 && !(on && !atoi(on));
 }
 
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
+
+extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
+  if (!a) return -1;
+  if (use_patch_conv(a)) return 3;
+  if (use_bf16(a)) return 1;
+  Plan pl = make_plan(a);
+  return use_patch_conv_f32(a, pl) ? 2 : 0;
+}
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
   GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
@@ -1238,9 +1412,16 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     d.tiles_n = (int)gad_ceil_div(a->N, 128);
     d.splitk = 1;
     dim3 grid((unsigned)(d.tiles_m * d.tiles_n)), block(NTHREADS);
-    if (a->g.W == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32>), grid, block, 0, st, d);
+    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
+    return 0;
+  }
+  if (use_patch_conv_f32(a, pl)) {
+    dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
+    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
+    GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch f32)");
     return 0;
   }
   if (a->A2) {

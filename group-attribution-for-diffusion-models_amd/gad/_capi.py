@@ -65,6 +65,7 @@ SIGNATURES = {
     "gad_gemm_workspace_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "gad_gemm_uses_bf16": (C.c_int, [C.POINTER(GemmArgs)]),
+    "gad_gemm_kernel_id": (C.c_int, [C.POINTER(GemmArgs)]),
     "gad_groupnorm_one_pass": (C.c_int, [C.POINTER(GroupNormArgs)]),
     "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),

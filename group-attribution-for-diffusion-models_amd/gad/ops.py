@@ -186,7 +186,8 @@ class GemmProfiler:
         s.record()
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
-        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("_bf16" if lib.gad_gemm_uses_bf16(C.byref(a)) else "")
+        kid = lib.gad_gemm_kernel_id(C.byref(a))
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}")[kid]
         key = (name, tile.value, sk.value, vec.value)
         # algorithmic bytes: every operand once (gathered tensor, not its im2col expansion) + the output
         g = a.g

@@ -100,7 +100,11 @@ int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
 /* which kernel instance gad_gemm would launch: block tile edge (128 or 64), split-K factor, vector width (4 or 1) */
 int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec);
 int gad_gemm(const gad_gemm_args* a, void* stream);
-int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would multiply bf16-rounded operands */
+int gad_gemm_uses_bf16(const gad_gemm_args* a);
+/* which kernel family gad_gemm(a) launches: 0 gemm_kernel (fp32, im2col-gather / dense loaders), 1 gemm_bf16_kernel,
+ * 2 conv3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 forward convs whose 128-pixel tiles
+ * are whole image rows: input patch resident in LDS) */
+int gad_gemm_kernel_id(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would multiply bf16-rounded operands */
 
 /* ------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in

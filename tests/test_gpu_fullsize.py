@@ -17,7 +17,7 @@ def ops():
     return o
 
 
-def _conv_case(Cin, Cout, B=512, H=32):
+def _conv_case(Cin, Cout, B=512, H=32):  # noqa: E302
     g = torch.Generator(device=dev).manual_seed(Cin * 7 + Cout)
     x = torch.randn(B, H, H, Cin, device=dev, generator=g)
     w = torch.randn(Cout, Cin, 3, 3, device=dev, generator=g) * (Cin * 9) ** -0.5
@@ -25,17 +25,21 @@ def _conv_case(Cin, Cout, B=512, H=32):
     return x, w.contiguous(memory_format=torch.channels_last), b
 
 
-@pytest.mark.parametrize("Cin,Cout", [(128, 128), (256, 128)])
-def test_conv_fwd_full_size_properties(ops, Cin, Cout):
-    """B=512 (16 fused reference batches) x 32x32: the dominant launch of the sampler."""
-    x, w, b = _conv_case(Cin, Cout)
+@pytest.mark.parametrize("Cin,Cout,B,H", [(128, 128, 512, 32), (256, 128, 512, 32), (256, 256, 128, 16), (128, 200, 64, 16)])
+def test_conv_fwd_full_size_properties(ops, Cin, Cout, B, H):
+    """B=512 (16 fused reference batches) x 32x32: the dominant launch of the sampler (and the 16x16 level at the
+    training batch).  These shapes run the LDS-patch kernel; tile 64 / split-K / GAD_NO_PATCH_CONV force the generic
+    im2col-gather kernel, so the invariance checks also compare the two kernels."""
+    x, w, b = _conv_case(Cin, Cout, B=B, H=H)
     y = ops.conv2d_fwd_raw(x, w, b)
     # (1) spot check 64 output pixels x all channels against an fp64 dot product over the 3x3xCin patch
     gi = torch.Generator().manual_seed(0)
     xp = torch.nn.functional.pad(x, (0, 0, 1, 1, 1, 1))
     wk = w.permute(0, 2, 3, 1).double()                                    # [Cout,3,3,Cin]
-    for n, i, j in zip(torch.randint(0, 512, (64,), generator=gi).tolist(), torch.randint(0, 32, (64,), generator=gi).tolist(),
-                       torch.randint(0, 32, (64,), generator=gi).tolist()):
+    picks = list(zip(torch.randint(0, B, (64,), generator=gi).tolist(), torch.randint(0, H, (64,), generator=gi).tolist(),
+                     torch.randint(0, H, (64,), generator=gi).tolist()))
+    picks += [(0, 0, 0), (B - 1, H - 1, H - 1), (0, 0, H - 1), (B - 1, H - 1, 0), (1, 3, 0), (1, 4, H - 1)]   # halo corners / tile seams
+    for n, i, j in picks:
         patch = xp[n, i:i + 3, j:j + 3, :].double()
         ref = (wk * patch[None]).sum((1, 2, 3)) + b.double()
         assert torch.allclose(y[n, i, j].double(), ref, atol=2e-5 * (9 * Cin) ** 0.5), (n, i, j)
@@ -44,11 +48,18 @@ def test_conv_fwd_full_size_properties(ops, Cin, Cout):
     assert (ops.conv2d_fwd_raw(x, w, b, tile_hint=64) - y).abs().max().item() < tol
     assert (ops.conv2d_fwd_raw(x, w, b, splitk_hint=2) - y).abs().max().item() < tol
     os.environ["GAD_NO_KPERM"] = "1"
+    os.environ["GAD_NO_PATCH_CONV"] = "1"
     try:
         y_tapmajor = ops.conv2d_fwd_raw(x, w, b)
     finally:
-        del os.environ["GAD_NO_KPERM"]
+        del os.environ["GAD_NO_KPERM"], os.environ["GAD_NO_PATCH_CONV"]
     assert (y_tapmajor - y).abs().max().item() < tol
+    os.environ["GAD_NO_PATCH_CONV"] = "1"
+    try:
+        y_generic = ops.conv2d_fwd_raw(x, w, b)          # same K order (chunk, tap), im2col gather instead of the patch
+    finally:
+        del os.environ["GAD_NO_PATCH_CONV"]
+    assert (y_generic - y).abs().max().item() < tol
     # (3) determinism: the same launch twice is bit-identical
     assert torch.equal(ops.conv2d_fwd_raw(x, w, b), y)
     # (4) linearity in x (bias removed): conv(2x - 3x') = 2 conv(x) - 3 conv(x')
