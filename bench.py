@@ -291,7 +291,8 @@ def main():
                 traffic = json.load(open(pmc)).get("dominant_kernel_hbm_bytes_per_launch")
             nm = dom_key[0]
             if "_patch" in nm:      # the name rocprofv3 shows for it
-                kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{nm.rsplit('_w', 1)[1]}> ({nm})"
+                wo = int(nm.rsplit("_w", 1)[1])
+                kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{wo}, {2 if wo == 8 else 1}> ({nm})"
             else:
                 kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
             out["roofline"] = {"bound": "mfma", "kernel": kname,

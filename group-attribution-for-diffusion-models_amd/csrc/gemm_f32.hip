@@ -841,10 +841,12 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
 // and the per-step address arithmetic disappears.  Weights stream through a double-buffered [128][32+8] bf16 tile
 // per (chunk, tap) exactly as in gemm_bf16_kernel.  K order = (chunk, tap); fp32 accumulation; same epilogue.
 // ------------------------------------------------------------------------------------
-template <int W>
+template <int W, int NI>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  constexpr int TR = BM / W, PW = W + 2, PR = TR + 2, NPIX = PR * PW;
+  // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
+  // each with its own halo'd sub-patch.
+  constexpr int TR = BM / (W * NI), PW = W + 2, PR = TR + 2, NPIX = NI * PR * PW;
   constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;      // float4 slots per thread per patch
   constexpr int P_TILE = NPIX * LDK;                                 // bf16 elements
   constexpr int B_TILE = BN * LDK;
@@ -861,7 +863,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
   // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
   // tensor is (H/2) x (W/2) and patch pixel (ih, iw) reads stored pixel (ih>>1, iw>>1)
   const int H = p.g.Ho, C = p.g.C, ups = p.g.upsample;
-  const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
+  const int img = row0 / (H * W), oh0 = NI == 1 ? (row0 - img * (H * W)) / W : 0;
   const int nchunks = C / BK;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -874,10 +876,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
   for (int i = 0; i < PSLOTS; ++i) {
     int j = tid + NTHREADS * i;
     int pp = j >> 3, q4 = (j & 7) * 4;
-    int pr = pp / PW, pc = pp - pr * PW;
+    int il = pp / (PR * PW), prem = pp - il * (PR * PW);
+    int pr = prem / PW, pc = prem - pr * PW;
     int ih = oh0 + pr - 1, iw = pc - 1;
     bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
-    poff[i] = ok ? ((img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
+    poff[i] = ok ? (((img + il) * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
     pvalid |= (unsigned)ok << i;
   }
   static_assert(PSLOTS <= 8, "one patch slot per tap, committed at the next tap");
@@ -917,7 +920,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int m = wm * (BM / 2) + i * 32 + l31;
-    abase[i] = ((m / W) * PW + (m % W)) * LDK + 8 * h;
+    abase[i] = ((m / (TR * W)) * (PR * PW) + ((m / W) % TR) * PW + (m % W)) * LDK + 8 * h;
   }
 
 #pragma unroll
@@ -999,10 +1002,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
 // barriers after the chunk's last tap (one extra barrier per 9 K steps).
 // ------------------------------------------------------------------------------------
 constexpr int PLD = BK + 4;
-template <int W>
+template <int W, int NI>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
-  constexpr int TR = BM / W, PW = W + 2, PR = TR + 2, NPIX = PR * PW;
+  // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
+  // each with its own halo'd sub-patch.
+  constexpr int TR = BM / (W * NI), PW = W + 2, PR = TR + 2, NPIX = NI * PR * PW;
   constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;
   constexpr int B_TILE = BK * BN;
   using BL = BLoader<GAD_B_KC, BN, 4>;
@@ -1019,7 +1024,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
   // tensor is (H/2) x (W/2) and patch pixel (ih, iw) reads stored pixel (ih>>1, iw>>1)
   const int H = p.g.Ho, C = p.g.C, ups = p.g.upsample;
-  const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
+  const int img = row0 / (H * W), oh0 = NI == 1 ? (row0 - img * (H * W)) / W : 0;
   const int nchunks = C / BK;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
@@ -1031,10 +1036,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   for (int i = 0; i < PSLOTS; ++i) {
     int j = tid + NTHREADS * i;
     int pp = j >> 3, q4 = (j & 7) * 4;
-    int pr = pp / PW, pc = pp - pr * PW;
+    int il = pp / (PR * PW), prem = pp - il * (PR * PW);
+    int pr = prem / PW, pc = prem - pr * PW;
     int ih = oh0 + pr - 1, iw = pc - 1;
     bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
-    poff[i] = ok ? ((img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
+    poff[i] = ok ? (((img + il) * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
     pvalid |= (unsigned)ok << i;
   }
   f32x4 rp[PSLOTS];
@@ -1062,7 +1068,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
     int m = wm * (BM / 2) + i * 32 + l31;
-    abase[i] = ((m / W) * PW + (m % W)) * PLD + 4 * h;
+    abase[i] = ((m / (TR * W)) * (PR * PW) + ((m / W) % TR) * PW + (m % W)) * PLD + 4 * h;
   }
 
   // prologue: patch of chunk 0 and the weights of step 0
@@ -1278,7 +1284,8 @@ static bool patch_conv_geom(const gad_gemm_args* a) {
   const char* off = getenv("GAD_NO_PATCH_CONV");
   return pick_vec(a) == 4 && a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && !a->A2 && g.KH == 3 && g.KW == 3 &&
          g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && g.Ho == (g.upsample ? 2 * g.H : g.H) &&
-         g.Wo == (g.upsample ? 2 * g.W : g.W) && (g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0 && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
+         g.Wo == (g.upsample ? 2 * g.W : g.W) &&
+         (((g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) || (g.Wo == 8 && g.Ho == 8 && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
          (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
 }
 static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch_conv_geom(a); }
@@ -1412,15 +1419,17 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     d.tiles_n = (int)gad_ceil_div(a->N, 128);
     d.splitk = 1;
     dim3 grid((unsigned)(d.tiles_m * d.tiles_n)), block(NTHREADS);
-    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16>), grid, block, 0, st, d);
+    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32, 1>), grid, block, 0, st, d);
+    else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16, 1>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<8, 2>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
     return 0;
   }
   if (use_patch_conv_f32(a, pl)) {
     dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
-    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
+    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1>), grid, block, 0, st, d);
+    else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch f32)");
     return 0;
   }
