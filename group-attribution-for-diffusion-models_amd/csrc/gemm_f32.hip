@@ -1002,7 +1002,10 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
 // barriers after the chunk's last tap (one extra barrier per 9 K steps).
 // ------------------------------------------------------------------------------------
 constexpr int PLD = BK + 4;
-template <int W, int NI>
+// DG = true: the data gradient of the same convolution - rows are input pixels, the patch holds dy, tap (r, s) reads it at
+// (ih + 1 - r, iw + 1 - s) (mirrored shifts) and the weights W[co][r][s][ci] stream as B[k = (tap, co)][n = ci]
+// ([k][n] tiles, read like the generic dgrad).
+template <int W, int NI, bool DG>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevArgs p) {
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
   // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
@@ -1010,7 +1013,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   constexpr int TR = BM / (W * NI), PW = W + 2, PR = TR + 2, NPIX = NI * PR * PW;
   constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;
   constexpr int B_TILE = BK * BN;
-  using BL = BLoader<GAD_B_KC, BN, 4>;
+  using BL = BLoader<DG ? GAD_B_WDGRAD : GAD_B_KC, BN, 4>;
   static_assert(PSLOTS <= 9, "one patch slot per tap");
   __shared__ __attribute__((aligned(16))) float lds[NPIX * PLD + 2 * B_TILE];
   float* const patch = lds;
@@ -1093,12 +1096,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform: one float4 of the next chunk's patch per tap
       if (tap == i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + cnext * BK, (pvalid >> i) & 1u));
     const int r = tap / 3, s3 = tap - r * 3;
-    const float* pa = patch + (r * PW + s3) * PLD;
+    const float* pa = patch + (DG ? (2 - r) * PW + (2 - s3) : r * PW + s3) * PLD;
     f32x4 fa[2][TM], fb[2][TN];
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pa + abase[i]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -1113,7 +1116,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(pa + abase[i] + 8 * (g + 1));
 #pragma unroll
-          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
         }
 #pragma unroll
         for (int q = 0; q < TM * TN; ++q) {
@@ -1279,10 +1282,12 @@ static bool use_bf16(const gad_gemm_args* a) {
 }
 
 // 3x3 / stride 1 / pad 1 forward conv whose 128-pixel tiles are whole rows of one image: the LDS-patch kernel applies
-static bool patch_conv_geom(const gad_gemm_args* a) {
+static bool patch_conv_geom(const gad_gemm_args* a, bool dgrad = false) {
   const gad_conv_geom& g = a->g;
   const char* off = getenv("GAD_NO_PATCH_CONV");
-  return pick_vec(a) == 4 && a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && !a->A2 && g.KH == 3 && g.KW == 3 &&
+  const bool modes = dgrad ? (a->a_mode == GAD_A_CONVT && a->b_mode == GAD_B_WDGRAD && !g.upsample)
+                           : (a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC);
+  return pick_vec(a) == 4 && modes && !a->A2 && g.KH == 3 && g.KW == 3 &&
          g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && g.Ho == (g.upsample ? 2 * g.H : g.H) &&
          g.Wo == (g.upsample ? 2 * g.W : g.W) &&
          (((g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) || (g.Wo == 8 && g.Ho == 8 && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
@@ -1292,7 +1297,7 @@ static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch
 // fp32: only where the planner would have launched the 128x128 tile without split-K anyway
 static bool use_patch_conv_f32(const gad_gemm_args* a, const Plan& pl) {
   const char* on = getenv("GAD_PATCH_CONV_F32");
-  return !use_bf16(a) && patch_conv_geom(a) && pl.bm == 128 && pl.splitk == 1 && !(on && !atoi(on));
+  return !use_bf16(a) && (patch_conv_geom(a) || patch_conv_geom(a, true)) && pl.bm == 128 && pl.splitk == 1 && !(on && !atoi(on));
 }
 
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
@@ -1427,9 +1432,17 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   }
   if (use_patch_conv_f32(a, pl)) {
     dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
-    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1>), grid, block, 0, st, d);
-    else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2>), grid, block, 0, st, d);
+    const bool dg = am == GAD_A_CONVT;
+    if (a->g.Wo == 32) {
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, true>), grid, block, 0, st, d);
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, false>), grid, block, 0, st, d);
+    } else if (a->g.Wo == 16) {
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1, true>), grid, block, 0, st, d);
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1, false>), grid, block, 0, st, d);
+    } else {
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2, true>), grid, block, 0, st, d);
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2, false>), grid, block, 0, st, d);
+    }
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch f32)");
     return 0;
   }

@@ -72,11 +72,17 @@ def test_conv_fwd_full_size_properties(ops, Cin, Cout, B, H):
 def test_conv_backward_adjoint_full_size(ops):
     """<dy, conv(x)> = <dgrad(dy), x> = <wgrad(x,dy), w> at the training batch (B=128, 256->256 @16x16 and
     128->128 @32x32): the three kernels are mutually consistent without an oracle."""
-    for Cin, Cout, H in ((256, 256, 16), (128, 128, 32)):
+    for Cin, Cout, H in ((256, 256, 16), (128, 128, 32), (192, 160, 8)):
         x, w, _ = _conv_case(Cin, Cout, B=128, H=H)
         dy = torch.randn(128, H, H, Cout, device=dev)
         y = ops.conv2d_fwd_raw(x, w, None)
-        dx = ops.conv2d_dgrad_raw(dy, w, x.shape)
+        dx = ops.conv2d_dgrad_raw(dy, w, x.shape)                # LDS-patch dgrad kernel at these shapes
+        os.environ["GAD_NO_PATCH_CONV"] = "1"
+        try:
+            dx_generic = ops.conv2d_dgrad_raw(dy, w, x.shape)    # transposed-gather kernel
+        finally:
+            del os.environ["GAD_NO_PATCH_CONV"]
+        assert (dx - dx_generic).abs().max().item() < 2e-5 * (9 * Cout) ** 0.5 * float(w.abs().max()) * 4
         dw = ops.conv2d_wgrad_raw(dy, x, w)
         a = (dy.double() * y.double()).sum()
         bb = (dx.double() * x.double()).sum()
