@@ -71,6 +71,7 @@ struct DevArgs {
   int ldr;
   float* ws;
   int tiles_m, tiles_n, splitk, ktiles_per_split;
+  int stagger;   // patch kernels: s_sleep(127) count for the workgroups that take the second slot of each CU
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -1074,6 +1075,12 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     abase[i] = ((m / (TR * W)) * (PR * PW) + ((m / W) % TR) * PW + (m % W)) * PLD + 4 * h;
   }
 
+  // The two workgroups that share a CU start together and, doing identical work, stay in lockstep: their prologues
+  // (exposed global latency) and epilogues (64 KB of stores each) coincide and the matrix pipe idles.  Delaying the
+  // workgroups of the second dispatch wave (256 .. 511: the second slot of every CU) by about half a tile's duration
+  // once keeps the pairs out of phase for the rest of the launch - every later workgroup inherits its slot's phase.
+  if (p.stagger > 0 && bid >= 256 && bid < 512)
+    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
   // prologue: patch of chunk 0 and the weights of step 0
   bl.prep(0, mb);
 #pragma unroll
@@ -1395,6 +1402,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
+  d.stagger = 0;
   d.A2 = a->A2; d.a_split = a->a_split; d.ldx2 = a->ldx2;
   d.M = a->M; d.N = a->N; d.K = a->K;
   d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
@@ -1430,8 +1438,16 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
     return 0;
   }
+  d.stagger = 0;
   if (use_patch_conv_f32(a, pl)) {
     dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
+    {   // half of a tile's duration when two workgroups share the SIMDs: K steps x ~3.6 us / 2, in 4-us sleeps
+      const char* sg = getenv("GAD_STAGGER");
+      const int nsteps = a->K / BK;
+      int auto_sg = pl.nblocks > 512 ? (int)(nsteps * 0.45) : 0;
+      d.stagger = sg ? atoi(sg) * (pl.nblocks > 512 ? 1 : 0) : auto_sg;
+      if (sg && atoi(sg) < 0) d.stagger = auto_sg;
+    }
     const bool dg = am == GAD_A_CONVT;
     if (a->g.Wo == 32) {
       if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, true>), grid, block, 0, st, d);

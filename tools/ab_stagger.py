@@ -1,0 +1,28 @@
+"""A/B of the start stagger of the LDS-patch conv kernel (GAD_STAGGER = number of 4-us sleeps for workgroups 256..511)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "group-attribution-for-diffusion-models_amd")); sys.path.insert(0, ROOT)
+os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
+import torch
+from gad import ops
+dev = torch.device("cuda:0")
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+for B in (512, 128):
+    for Cin, Cout, H in ((128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16)):
+        x = torch.randn(B, H, H, Cin, device=dev)
+        w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+        b = torch.randn(Cout, device=dev)
+        fl = 2.0 * B * H * H * Cout * Cin * 9
+        res = []
+        for sg in ("0", "-1", "8", "16", "32", "64"):
+            os.environ["GAD_STAGGER"] = sg
+            ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b))
+            res.append(f"sg{sg}: {fl/ms/1e9:6.1f}")
+        print(f"B={B} {Cin}->{Cout}@{H}: " + " | ".join(res), flush=True)
