@@ -1164,6 +1164,120 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Weight gradient of the 3x3 / stride 1 / pad 1 convolution from an LDS patch:
+//   dW[co][tap][ci] = sum_pixels dy[pix][co] * x[pix + tap shift][ci]
+// A workgroup owns 128 output channels x one 32-channel input chunk x ALL nine taps (a 128 x 288 slab of dW, 9
+// accumulator tiles per wave) and a range of pixels.  A K step is 32 consecutive pixels (one row at W = 32, two rows at
+// W = 16): the dy tile [32 px][128 co] and the halo'd x rows [(rows+2)(W+2) px][32 ci] arrive by LDS-DMA; the nine taps
+// read their B fragments (lane = ci, the two lane halves = two adjacent pixels) from the same patch rows at shifted
+// pixel offsets, and one dy fragment (lane = co) feeds nine MFMAs.  Per 2.36 MFLOP the step stages 29 KB (the im2col
+// kernel: 32 KB per 1.05 MFLOP) and computes no im2col addresses.  Partial slabs of the pixel splits go to the
+// workspace and through splitk_reduce_kernel, as for the generic split-K.
+// ------------------------------------------------------------------------------------
+template <int W>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const DevArgs p) {   // 2 waves / SIMD: <= 256 registers
+  constexpr int BM = 128;
+  constexpr int ROWS = BK / W;                    // image rows per K step (1 or 2)
+  constexpr int PW = W + 2, PRW = ROWS + 2, NPX = PRW * PW;
+  constexpr int PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;      // DMA slots per thread for the patch
+  constexpr int PSIZE = PSL * 32 * BK;                            // floats (whole wave-instructions)
+  constexpr int A_TILE = BK * BM;
+  using AL = ALoader<GAD_A_MC, BM, 4>;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + PSIZE)];
+
+  // block -> (pixel split, co tile, ci chunk); chunks of one (split, co tile) are adjacent: they share the dy tiles in L2
+  const int nci = p.g.C / BK;
+  int bid = blockIdx.x;
+  const int cchunk = bid % nci;
+  bid /= nci;
+  const int tile_m = bid % p.tiles_m, split = bid / p.tiles_m;
+  const int row0 = tile_m * BM, ci0 = cchunk * BK;
+  const int HW = p.g.Ho * p.g.Wo, ups = p.g.upsample;
+  const int kt0 = split * p.ktiles_per_split;
+  const int kend = min(p.K, (kt0 + p.ktiles_per_split) * BK);
+  const int nkt = (kend - kt0 * BK + BK - 1) / BK;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+
+  AL al;
+  al.setup(p, p.A, row0, kend);
+  unsigned ma = 0;
+  // patch slots: slot i covers patch pixel i*32 + tid/8, float4 tid%8
+  int prow[PSL], pcol[PSL];
+#pragma unroll
+  for (int i = 0; i < PSL; ++i) {
+    int px = i * 32 + (tid >> 3);
+    prow[i] = px < NPX ? px / PW : -100000;      // rows far outside -> always invalid
+    pcol[i] = px % PW - 1;
+  }
+  auto patch_src = [&](int i, int k0) -> const float* {
+    int img = k0 / HW, rem = k0 - img * HW;
+    int ih = rem / W - 1 + prow[i], iw = pcol[i];
+    bool ok = k0 < kend && ih >= 0 && ih < p.g.Ho && iw >= 0 && iw < W;
+    long off = ((long)(img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + ci0 + (tid & 7) * 4;
+    return sel_src(p.B, off, ok);
+  };
+  auto stage = [&](int piece, int k0, float* ta, float* tp) {
+    if (piece < AL::NS) glds16(al.src(piece), AL::dma_dst(ta, piece));
+    else if (piece < AL::NS + PSL) glds16(patch_src(piece - AL::NS, k0), tp + ((piece - AL::NS) * 32 + wave * 8) * BK);
+  };
+
+  f32x16 acc[9];
+#pragma unroll
+  for (int t = 0; t < 9; ++t)
+#pragma unroll
+    for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
+
+  if (nkt > 0) {
+    al.prep(kt0 * BK, ma);
+#pragma unroll
+    for (int q = 0; q < AL::NS + PSL; ++q) stage(q, kt0 * BK, lds, lds + A_TILE);
+  }
+  __syncthreads();
+
+  // fragment bases: A[(2j + h)][wave*32 + l31]; B: pixel q = 2j + h -> patch pixel (q / W) * PW + q % W (+ tap shift)
+  for (int kt = 0; kt < nkt; ++kt) {
+    const float* la = lds + (kt & 1) * (A_TILE + PSIZE);
+    const float* lp = la + A_TILE;
+    float* na = lds + ((kt + 1) & 1) * (A_TILE + PSIZE);
+    const int knext = (kt + 1 < nkt) ? (kt0 + kt + 1) * BK : p.K;   // past the end: zeros
+    al.prep(knext, ma);
+    float fa[2], fb[2][9];
+    auto load_frags = [&](int j, int buf) {
+      const int q = 2 * j + h;
+      fa[buf] = la[q * BM + wave * 32 + l31];
+      const float* pb = lp + ((q / W) * PW + (q % W)) * BK + l31;
+#pragma unroll
+      for (int t = 0; t < 9; ++t) fb[buf][t] = pb[((t / 3) * PW + (t % 3)) * BK];
+    };
+    load_frags(0, 0);
+#pragma unroll
+    for (int j = 0; j < 16; ++j) {
+      if (j + 1 < 16) load_frags(j + 1, (j + 1) & 1);
+#pragma unroll
+      for (int t = 0; t < 9; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[j & 1][t], acc[t], 0, 0, 0);
+      stage(j, knext, na, na + A_TILE);     // one DMA slot per pixel pair (AL::NS + PSL <= 16)
+    }
+    __syncthreads();
+  }
+
+  // epilogue: D row = co (wave*32 + (e&3) + 8(e>>2) + 4h), D col = ci (l31); N index = tap * C + ci0 + ci
+  const bool direct = p.splitk == 1;
+  float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
+  const int ldc = direct ? p.ldc : p.N;
+#pragma unroll
+  for (int t = 0; t < 9; ++t) {
+    const int n = t * p.g.C + ci0 + l31;
+#pragma unroll
+    for (int e = 0; e < 16; ++e) {
+      int m = row0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      if (m < p.M) Cp[(long)m * ldc + n] = direct ? acc[t][e] * p.alpha : acc[t][e];
+    }
+  }
+}
+
 // split-K: C = epilogue(sum_s ws[z][s][m][n])
 __global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
   long total = (long)batch * p.M * p.N;
@@ -1307,10 +1421,30 @@ static bool use_patch_conv_f32(const gad_gemm_args* a, const Plan& pl) {
   return !use_bf16(a) && (patch_conv_geom(a) || patch_conv_geom(a, true)) && pl.bm == 128 && pl.splitk == 1 && !(on && !atoi(on));
 }
 
+// 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible)
+static int wgrad_patch_splits(const gad_gemm_args* a) {
+  const gad_conv_geom& g = a->g;
+  const char* off = getenv("GAD_NO_PATCH_CONV");
+  if (off && atoi(off)) return 0;
+  if (use_bf16(a) || pick_vec(a) != 4 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV) return 0;
+  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return 0;
+  if (g.Ho != (g.upsample ? 2 * g.H : g.H) || g.Wo != (g.upsample ? 2 * g.W : g.W)) return 0;
+  if (!(g.Wo == 32 || g.Wo == 16) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
+  if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
+  if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
+  const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, 128) * (g.C / BK);
+  const char* tb = getenv("GAD_WGRAD_BLOCKS");
+  long sp = (tb ? atoi(tb) : 512) / groups;   // default: one round of 2 workgroups per CU
+  if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
+  if (sp < 1) sp = 1;
+  return (int)sp;
+}
+
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
 
 extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
+  if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
   if (use_bf16(a)) return 1;
   Plan pl = make_plan(a);
@@ -1327,6 +1461,7 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
 }
 
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
+  if (int sp = wgrad_patch_splits(a)) return sp > 1 ? (int64_t)sp * a->M * a->N * (int64_t)sizeof(float) : 0;
   Plan pl = make_plan(a);
   if (pl.splitk == 1) return 0;
   long batch = a->batch > 0 ? a->batch : 1;
@@ -1427,6 +1562,27 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (int sp = wgrad_patch_splits(a)) {
+    const long ksteps = a->K / BK;
+    d.tiles_m = (int)gad_ceil_div(a->M, 128);
+    d.ktiles_per_split = (int)gad_ceil_div(ksteps, sp);
+    d.splitk = (int)gad_ceil_div(ksteps, d.ktiles_per_split);
+    if (d.splitk > 1) {
+      int64_t need = (int64_t)d.splitk * a->M * a->N * (int64_t)sizeof(float);
+      GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: wgrad workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
+    }
+    dim3 grid((unsigned)(d.splitk * d.tiles_m * (a->g.C / BK))), block(NTHREADS);
+    if (a->g.Wo == 32) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<32>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
+    GAD_LAUNCH_CHECK("gad_gemm(wgrad3x3 patch)");
+    if (d.splitk > 1) {
+      long total = (long)a->M * a->N;
+      int blocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, 1);
+      GAD_LAUNCH_CHECK("gad_gemm(wgrad splitk reduce)");
+    }
+    return 0;
+  }
   if (bf16 && use_patch_conv(a)) {
     d.tiles_m = (int)gad_ceil_div(a->M, 128);
     d.tiles_n = (int)gad_ceil_div(a->N, 128);

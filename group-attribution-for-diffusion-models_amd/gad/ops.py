@@ -188,6 +188,8 @@ class GemmProfiler:
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
         name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}")[kid]
+        if kid in (2, 3):                    # the patch kernels have their own tiling (128 rows; pixel splits for wgrad)
+            tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)
         # algorithmic bytes: every operand once (gathered tensor, not its im2col expansion) + the output
         g = a.g

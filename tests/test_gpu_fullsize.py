@@ -83,7 +83,13 @@ def test_conv_backward_adjoint_full_size(ops):
         finally:
             del os.environ["GAD_NO_PATCH_CONV"]
         assert (dx - dx_generic).abs().max().item() < 2e-5 * (9 * Cout) ** 0.5 * float(w.abs().max()) * 4
-        dw = ops.conv2d_wgrad_raw(dy, x, w)
+        dw = ops.conv2d_wgrad_raw(dy, x, w)                      # LDS-patch wgrad kernel where W is 32 or 16
+        os.environ["GAD_NO_PATCH_CONV"] = "1"
+        try:
+            dw_generic = ops.conv2d_wgrad_raw(dy, x, w)          # im2col-columns kernel
+        finally:
+            del os.environ["GAD_NO_PATCH_CONV"]
+        assert (dw - dw_generic).abs().max().item() < 2e-5 * (128 * H * H) ** 0.5 * 4
         a = (dy.double() * y.double()).sum()
         bb = (dx.double() * x.double()).sum()
         c = (dw.double() * w.double()).sum()

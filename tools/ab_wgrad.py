@@ -1,0 +1,32 @@
+"""A/B: LDS-patch wgrad kernel vs the generic im2col-columns kernel (B=128 training shapes)."""
+import os, sys
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "group-attribution-for-diffusion-models_amd")); sys.path.insert(0, ROOT)
+os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
+import torch
+from gad import ops
+dev = torch.device("cuda:0")
+def timeit(fn, iters=10, warm=2):
+    for _ in range(warm): fn()
+    torch.cuda.synchronize()
+    s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+    s.record()
+    for _ in range(iters): fn()
+    e.record(); torch.cuda.synchronize()
+    return s.elapsed_time(e) / iters
+B = 128
+for Cin, Cout, H in ((128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (128, 256, 16)):
+    x = torch.randn(B, H, H, Cin, device=dev)
+    w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
+    dy = torch.randn(B, H, H, Cout, device=dev)
+    fl = 2.0 * B * H * H * Cout * Cin * 9
+    res = []
+    outs = []
+    for flag, nb in (("0", "256"), ("0", "512"), ("0", "768"), ("0", "1024"), ("0", "2048"), ("1", "512")):
+        os.environ["GAD_NO_PATCH_CONV"] = flag
+        os.environ["GAD_WGRAD_BLOCKS"] = nb
+        outs.append(ops.conv2d_wgrad_raw(dy, x, w))
+        ms = timeit(lambda: ops.conv2d_wgrad_raw(dy, x, w))
+        res.append(f"{'p' + nb if flag == '0' else 'generic'} {fl/ms/1e9:6.1f}")
+    err = (outs[0] - outs[-1]).abs().max().item()
+    print(f"wgrad B={B} {Cin}->{Cout}@{H}: " + " | ".join(res) + f" | max diff {err:.2e}", flush=True)
