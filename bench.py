@@ -7,9 +7,9 @@
 Workload (config.workload): one coalition of the reference's CIFAR-20 configuration =
 gd_steps=1000 fine-tuning steps at B=128 (noise, antithetic t, add_noise, U-Net fwd, MSE, bwd,
 clip 1.0, Adam 1e-4, EMA) + 10 240 samples x 100 DDIM steps (U-Net fwd + scheduler step;
-reference batches of 32 with per-batch CPU-generator noise, 16 of them fused per launch), fp32.
+reference batches of 32 with per-batch CPU-generator noise, 32 of them fused per launch), fp32.
 ONE BENCH STEP = 1/1000 of that coalition, in the coalition's own proportions:
-    1 training step (B=128)  +  2 sampler steps at B=512 (= 32 reference batches x 32 images x 1 DDIM step).
+    1 training step (B=128)  +  1 sampler step at B=1024 (= 32 reference batches x 32 images x 1 DDIM step).
 value = coalitions/hour summed over all ranks = K * world / 1000 / hours(max-over-ranks time of the K steps).
 The score tail (FID features + float64 Frechet, ~1 % of the FLOPs, once per coalition) is not part of a
 slice; `--full-coalition` runs one real, complete coalition (train -> EMA -> preview -> sample -> score) instead.
@@ -30,7 +30,7 @@ os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
 
 import torch  # noqa: E402
 
-GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128, 32, 16
+GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128, 32, 32
 UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
 BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
@@ -120,7 +120,7 @@ class SliceRunner:
 
     def slice(self):
         loss = self.train_step()
-        for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):      # 2
+        for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):      # 1
             self.sampler_step()
         return loss
 
@@ -260,9 +260,9 @@ def main():
             "dtype": "f32" if a.precision == "f32" else "bf16 operands, f32 accumulate/storage (NOT the reference default)",
             "data": "synthetic",
             "config": {"workload": ("CIFAR-20 DDPM sFT coalition (BASELINE configs[1]): gd_steps=1000 @B=128 + 10240 samples"
-                                    " x 100 DDIM steps @B=32 (16 batches fused/launch), UNet2DModel 35.75M params fp32" + ("" if a.precision == "f32" else " storage, bf16 MFMA operands") + "; "
+                                    " x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel 35.75M params fp32" + ("" if a.precision == "f32" else " storage, bf16 MFMA operands") + "; "
                                     + ("step = one complete coalition" if a.full_coalition else
-                                       "step = 1/1000 coalition = 1 train step + 2 sampler steps @B=512")),
+                                       "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024")),
                        "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"},
         }
         # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU

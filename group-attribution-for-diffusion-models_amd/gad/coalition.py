@@ -75,7 +75,7 @@ class FusedSampler:
     are stacked along N so the contraction kernels see M = fuse*batch_size*H*W rows.  The U-Net
     has no cross-sample op (GroupNorm and attention are per sample), so results are unchanged."""
 
-    def __init__(self, unet: UNet2DModel, scheduler: DDIMScheduler, batch_size=32, fuse=16):
+    def __init__(self, unet: UNet2DModel, scheduler: DDIMScheduler, batch_size=32, fuse=32):
         self.unet, self.sch, self.bs, self.fuse = unet, scheduler, batch_size, fuse
         self.device = unet.device
 
@@ -156,7 +156,7 @@ class CoalitionEngine:
     """Everything one rank needs to run coalitions back to back on its GPU."""
 
     def __init__(self, dataset_name="cifar100", device="cuda:0", base_state: Optional[dict] = None,
-                 gd_steps: Optional[int] = None, n_samples=10240, sample_batch=32, fuse=16,
+                 gd_steps: Optional[int] = None, n_samples=10240, sample_batch=32, fuse=32,
                  num_inference_steps=100, opt_seed=42, by_class=True, preview=True,
                  unet_overrides: Optional[dict] = None, feature_dims=2048):
         from src.datasets import create_dataset

@@ -127,7 +127,7 @@ def test_training_step_is_bit_reproducible_at_full_size():
 
 
 def test_fused_sampler_at_bench_width_equals_per_batch_launches():
-    """16 reference batches of 32 fused into one B=512 launch (the bench's sampler width) against launching each
+    """32 reference batches of 32 fused into one B=1024 launch (the bench's sampler width) against launching each
     batch alone, full-width U-Net, 2 DDIM steps: GroupNorm / attention are per sample, so only fp32 summation order in
     the split-K plans may differ."""
     import gad
@@ -135,9 +135,9 @@ def test_fused_sampler_at_bench_width_equals_per_batch_launches():
     from src.ddpm_config import DDPMConfig
     torch.manual_seed(0)
     net = gad.UNet2DModel(**DDPMConfig.cifar100_config["unet_config"]).to(dev).eval()
-    fused = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=16).generate(512, 2)
-    single = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=1).generate(512, 2)
-    assert fused.shape == single.shape == (512, 3, 32, 32)
+    fused = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=32).generate(1024, 2)
+    single = FusedSampler(net, gad.DDIMScheduler(), batch_size=32, fuse=1).generate(1024, 2)
+    assert fused.shape == single.shape == (1024, 3, 32, 32)
     q = (fused * 255).round()
     assert torch.equal(q / 255, fused)                                      # uint8 round trip of generate_images
     assert ((fused - single).abs() * 255 > 1.5).float().mean().item() == 0.0   # never more than one grey level apart
