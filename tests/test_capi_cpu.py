@@ -75,3 +75,41 @@ def test_error_state_is_per_thread():
     [t.start() for t in ts]
     [t.join() for t in ts]
     assert b"null" in seen["bad"] and seen["good"] == b""
+
+
+def _conv_args(a_mode, b_mode, M, N, K, H, W, C, Ho=None, Wo=None, k=3, stride=1, pad=1, ups=0, prec=0):
+    a = _capi.GemmArgs()
+    a.a_mode, a.b_mode, a.M, a.N, a.K = a_mode, b_mode, M, N, K
+    a.lda, a.ldb, a.ldc = (M if a_mode == _capi.A_MC else K), K, N
+    a.g = _capi.ConvGeom(H, W, C, C, Ho or H, Wo or W, k, k, stride, pad, pad, ups)
+    a.operand_precision = prec
+    return a
+
+
+def test_kernel_family_selection_is_a_pure_host_decision():
+    """gad_gemm_kernel_id: 0 generic fp32, 1 generic bf16, 2 LDS-patch fp32, 3 LDS-patch bf16 - decided from shapes
+    alone, so it can be checked without a GPU (the GPU tests check that each family computes the same numbers)."""
+    lib = _capi.load()
+    kid = lambda a: lib.gad_gemm_kernel_id(ctypes.byref(a))     # noqa: E731
+    big = 512 * 32 * 32
+    fwd = _conv_args(_capi.A_CONV, _capi.B_KC, big, 128, 9 * 128, 32, 32, 128)
+    assert kid(fwd) == 2                                                     # 3x3 s1 p1, whole-row tiles, 128-tile plan
+    fwd.operand_precision = 1
+    assert kid(fwd) == 3
+    assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, big // 4, 128, 9 * 128, 32, 32, 128, Ho=16, Wo=16, stride=2, pad=0)) == 0
+    assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, big, 128, 128, 32, 32, 128, k=1, pad=0)) == 0        # 1x1
+    assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, big, 128, 9 * 100, 32, 32, 100)) == 0               # C % 32 != 0
+    assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, 2 * 32 * 32, 128, 9 * 128, 32, 32, 128)) == 0       # tiny M: split-K plan
+    up = _conv_args(_capi.A_CONV, _capi.B_KC, big, 256, 9 * 256, 16, 16, 256, Ho=32, Wo=32, ups=1)
+    assert kid(up) == 2                                                      # nearest-2x fused into the patch fetch
+    dg = _conv_args(_capi.A_CONVT, _capi.B_WDGRAD, big, 128, 9 * 128, 32, 32, 128)
+    assert kid(dg) == 2
+    wg = _conv_args(_capi.A_MC, _capi.B_CONV, 128, 9 * 128, 128 * 32 * 32, 32, 32, 128)
+    assert kid(wg) == 2 and lib.gad_gemm_workspace_bytes(ctypes.byref(wg)) == 128 * 128 * 1152 * 4     # 128 pixel splits
+    lin = _capi.GemmArgs()
+    lin.a_mode, lin.b_mode, lin.M, lin.N, lin.K, lin.lda, lin.ldb, lin.ldc = _capi.A_KC, _capi.B_KC, 4096, 256, 256, 256, 256, 256
+    assert kid(lin) == 0
+    lin.operand_precision = 1
+    assert kid(lin) == 1 and lib.gad_gemm_uses_bf16(ctypes.byref(lin)) == 1
+    lin.K = lin.lda = lin.ldb = 27                                           # no aligned float4 path: stays fp32
+    assert kid(lin) == 0 and lib.gad_gemm_uses_bf16(ctypes.byref(lin)) == 0
