@@ -1361,6 +1361,21 @@ static Plan make_plan(const gad_gemm_args* a) {
       double cyc = per * ((rounds - 1) * (cap * mfma + X) + (conc * mfma + X)) + rounds * fixed;
       double us = cyc / 2000.0;
       if (sk_eff > 1) us += 4.0 + (double)batch * a->M * a->N * 4.0 * (sk_eff + 1) / 3.0e6;
+      // Short-K launches are not compute-bound: every round moves its operand / residual / output bytes through HBM and
+      // only part of that overlaps the few K steps of a tile.  Measured on the attention projections (tools/ab_linear.py,
+      // K = 256 and 512): the exposed share is ~1.4 x (8 / steps) of the launch's HBM time with 2 workgroups per CU and
+      // ~0.4 x (8 / steps) with 4 (64x64 tiles) - which is what makes the small tile win there.
+      {
+        const bool convA_ = a->a_mode == GAD_A_CONV || a->a_mode == GAD_A_CONVT;
+        const double a_el = convA_ ? (double)(a->M / (a->g.Ho * a->g.Wo > 0 ? a->g.Ho * a->g.Wo : 1)) * a->g.H * a->g.W * a->g.C
+                                   : (double)a->M * a->K;
+        const double b_el = a->b_mode == GAD_B_CONV ? (double)(a->K / (a->g.Ho * a->g.Wo > 0 ? a->g.Ho * a->g.Wo : 1)) * a->g.H * a->g.W * a->g.C
+                                                    : (double)a->N * a->K;
+        const double bytes = 4.0 * batch * (a_el + b_el + (double)a->M * a->N * (a->residual ? 2.0 : 1.0));
+        double ratio = 8.0 / per;
+        if (ratio > 2.0) ratio = 2.0;
+        us += bytes / 4.0e6 * (bm == 128 ? 1.4 : 0.4) * ratio;
+      }
       if (us < best) {
         best = us;
         pl.bm = bm;
