@@ -44,6 +44,14 @@ __device__ __forceinline__ void glds16(const float* src, float* dst_wave_uniform
                                    (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, 0);
 }
 
+// A barrier that publishes LDS-DMA'd tiles: the DMA is a VMEM operation (vmcnt), and the compiler's own waitcnt placement
+// at __syncthreads() only covers it when it happens to track the LDS side effect - so wait for it explicitly.
+// s_waitcnt immediate (gfx9): vmcnt = 0 (bits 3:0 and 15:14), expcnt = 7 (no wait), lgkmcnt = 15 (no wait).
+__device__ __forceinline__ void barrier_after_dma() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+}
+
 // division by a launch-invariant divisor: q = (mulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31
 struct FastDiv {
   unsigned mul, shift;
@@ -575,7 +583,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
     for (int q = 0; q < AL::NS + BL::NS; ++q) stage_slot(q, lds, lds + A_TILE);
     stage_commit(lds, lds + A_TILE);
   }
-  __syncthreads();   // (with DMA in flight hipcc's barrier also waits vmcnt(0))
+  barrier_after_dma();
 
   // One K step = 16 "pieces" of TM*TN MFMAs (4 fragment groups x 4 MFMA steps).  The staging of step
   // kt+1 (into the other buffer, last read before the previous barrier) is issued one slot per piece
@@ -622,7 +630,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
       }
     }
     stage_commit(nxt, nxt + A_TILE);
-    __syncthreads();   // all DMA of step kt+1 landed (vmcnt(0)) and every wave is done reading `cur`
+    barrier_after_dma();   // all DMA of step kt+1 landed (vmcnt(0)) and every wave is done reading `cur`
   }
 
   // ---- epilogue: C/D map col = lane&31, row = (reg&3) + 8*(reg>>2) + 4*(lane>>5) ----
@@ -1088,7 +1096,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
   for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i], (pvalid >> i) & 1u));
   commit_patch();
-  __syncthreads();
+  barrier_after_dma();
 
   const int nsteps = nchunks * 9;
   int chunk = 0, tap = 0;
@@ -1133,7 +1141,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
         __builtin_amdgcn_sched_barrier(0);
       }
     }
-    __syncthreads();            // weights of step st+1 landed; every wave is done with this tap's reads
+    barrier_after_dma();            // weights of step st+1 landed; every wave is done with this tap's reads
     if (tap == 8) {             // chunk boundary: swap in the prefetched patch
       commit_patch();
       __syncthreads();
@@ -1234,7 +1242,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
 #pragma unroll
     for (int q = 0; q < AL::NS + PSL; ++q) stage(q, kt0 * BK, lds, lds + A_TILE);
   }
-  __syncthreads();
+  barrier_after_dma();
 
   // fragment bases: A[(2j + h)][wave*32 + l31]; B: pixel q = 2j + h -> patch pixel (q / W) * PW + q % W (+ tap shift)
   for (int kt = 0; kt < nkt; ++kt) {
@@ -1260,7 +1268,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[j & 1][t], acc[t], 0, 0, 0);
       stage(j, knext, na, na + A_TILE);     // one DMA slot per pixel pair (AL::NS + PSL <= 16)
     }
-    __syncthreads();
+    barrier_after_dma();
   }
 
   // epilogue: D row = co (wave*32 + (e&3) + 8(e>>2) + 4h), D col = ci (l31); N index = tap * C + ci0 + ci

@@ -21,8 +21,12 @@ for B in (512, 128):
         b = torch.randn(Cout, device=dev)
         fl = 2.0 * B * H * H * Cout * Cin * 9
         res = []
-        for flag in ("1", "0"):
-            os.environ["GAD_PATCH_CONV_F32"] = flag
+        outs = []
+        for label, env in (("patch", {}), ("generic", {"GAD_PATCH_CONV_F32": "0"})):
+            for k_ in ("GAD_PATCH3", "GAD_PATCH_CONV_F32"): os.environ.pop(k_, None)
+            os.environ.update(env)
+            outs.append(ops.conv2d_fwd_raw(x, w, b))
             ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b))
-            res.append(f"{'patch' if flag == '1' else 'generic'} {fl/ms/1e9:6.1f} TF/s ({ms*1e3:6.0f} us)")
+            res.append(f"{label} {fl/ms/1e9:6.1f} TF/s ({ms*1e3:6.0f} us)")
+        res.append(f"max|patch-generic| {(outs[0]-outs[1]).abs().max().item():.1e}")
         print(f"B={B} {Cin}->{Cout}@{H}: " + " | ".join(res), flush=True)
