@@ -142,3 +142,34 @@ def test_fused_sampler_at_bench_width_equals_per_batch_launches():
     assert torch.equal(q / 255, fused)                                      # uint8 round trip of generate_images
     assert ((fused - single).abs() * 255 > 1.5).float().mean().item() == 0.0   # never more than one grey level apart
     assert ((fused - single).abs() > 0).float().mean().item() < 0.01
+
+
+def test_whole_model_is_kernel_family_invariant():
+    """Full-width U-Net at the training batch: forward, loss, gradient norm and the updated weights with the LDS-patch
+    kernels (forward, dgrad, wgrad) against the same step on the generic im2col kernels (GAD_NO_PATCH_CONV=1): only
+    fp32 summation order may differ."""
+    import gad
+    from src.ddpm_config import DDPMConfig
+    cfg = DDPMConfig.cifar100_config
+    outs = []
+    for flag in ("0", "1"):
+        os.environ["GAD_NO_PATCH_CONV"] = flag
+        try:
+            torch.manual_seed(0)
+            net = gad.UNet2DModel(**cfg["unet_config"]).to(dev)
+            tr = gad.FusedTrainer(net, gad.DDPMScheduler(**cfg["scheduler_config"]), gad.EMAModel(net.parameters()), lr=1e-4)
+            g = torch.Generator(device=dev).manual_seed(5)
+            x = torch.rand(128, 3, 32, 32, device=dev, generator=g) * 2 - 1
+            n = torch.randn(128, 3, 32, 32, device=dev, generator=g)
+            t = torch.randint(0, 1000, (128,), device=dev, generator=g)
+            with torch.no_grad():
+                y = net(x, t).sample
+            loss = tr.step(x, n, t).item()
+            outs.append((y, loss, tr.grad_norm().item(), tr.flat.clone()))
+            del net, tr
+        finally:
+            del os.environ["GAD_NO_PATCH_CONV"]
+    (y0, l0, g0, w0), (y1, l1, g1, w1) = outs
+    assert (y0 - y1).abs().max().item() < 1e-4 * max(1.0, y1.abs().max().item())
+    assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1
+    assert (w0 - w1).abs().max().item() < 2e-6            # one Adam step of lr 1e-4: updates are +-1e-4, signs must agree
