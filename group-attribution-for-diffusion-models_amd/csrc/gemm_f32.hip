@@ -892,7 +892,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     poff[i] = ok ? (((img + il) * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + q4 : 0;
     pvalid |= (unsigned)ok << i;
   }
-  static_assert(PSLOTS <= 8, "one patch slot per tap, committed at the next tap");
+  static_assert(PSLOTS <= 9, "one patch slot per tap, committed at the next tap");
   // slot i of the NEXT chunk's patch is fetched at tap i and written to the other patch buffer at tap i + 1
   // (that buffer was last read in the previous chunk), so only one float4 of the patch is in registers at a time
   f32x4 rp1;
@@ -975,6 +975,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
     commit_b(nb);
+    if (PSLOTS == 9 && tap == 8) commit_slot(8, pnext);   // a ninth slot (W = 64) has no next tap to ride on
     __syncthreads();
     tap = ntap;
     chunk = nchunk;
@@ -1434,7 +1435,7 @@ static bool patch_conv_geom(const gad_gemm_args* a, bool dgrad = false) {
   return pick_vec(a) == 4 && modes && !a->A2 && g.KH == 3 && g.KW == 3 &&
          g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && g.Ho == (g.upsample ? 2 * g.H : g.H) &&
          g.Wo == (g.upsample ? 2 * g.W : g.W) &&
-         (((g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) || (g.Wo == 8 && g.Ho == 8 && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
+         (((g.Wo == 64 || g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) || (g.Wo == 8 && g.Ho == 8 && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
          (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
 }
 static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch_conv_geom(a); }
@@ -1611,7 +1612,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     d.tiles_n = (int)gad_ceil_div(a->N, 128);
     d.splitk = 1;
     dim3 grid((unsigned)(d.tiles_m * d.tiles_n)), block(NTHREADS);
-    if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32, 1>), grid, block, 0, st, d);
+    if (a->g.Wo == 64) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<64, 1>), grid, block, 0, st, d);
+    else if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32, 1>), grid, block, 0, st, d);
     else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16, 1>), grid, block, 0, st, d);
     else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<8, 2>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
@@ -1628,7 +1630,10 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       if (sg && atoi(sg) < 0) d.stagger = auto_sg;
     }
     const bool dg = am == GAD_A_CONVT;
-    if (a->g.Wo == 32) {
+    if (a->g.Wo == 64) {
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<64, 1, true>), grid, block, 0, st, d);
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<64, 1, false>), grid, block, 0, st, d);
+    } else if (a->g.Wo == 32) {
       if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, true>), grid, block, 0, st, d);
       else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, false>), grid, block, 0, st, d);
     } else if (a->g.Wo == 16) {

@@ -382,7 +382,8 @@ def _bf16_round(t):
                                   # whole-row tiles of 3x3/s1/p1 convs take the LDS-patch kernel (W = 32 and W = 16)
                                   dict(B=2, Cin=128, Cout=256, H=32, k=3, stride=1, pad=(1, 1, 1, 1), ups=False),
                                   dict(B=3, Cin=32, Cout=128, H=16, k=3, stride=1, pad=(1, 1, 1, 1), ups=False),
-                                  dict(B=1, Cin=96, Cout=72, H=32, k=3, stride=1, pad=(1, 1, 1, 1), ups=False)])
+                                  dict(B=1, Cin=96, Cout=72, H=32, k=3, stride=1, pad=(1, 1, 1, 1), ups=False),
+                                  dict(B=1, Cin=64, Cout=96, H=64, k=3, stride=1, pad=(1, 1, 1, 1), ups=False)])
 @pytest.mark.parametrize("tile", [0, 1, 2])
 def test_conv_fwd_bf16_operands(ops, case, tile):
     """operand_precision=1: x and w are rounded to bf16 (RNE) inside the kernel, products are exact in fp32 and
