@@ -72,7 +72,7 @@ def test_conv_fwd_full_size_properties(ops, Cin, Cout, B, H):
 def test_conv_backward_adjoint_full_size(ops):
     """<dy, conv(x)> = <dgrad(dy), x> = <wgrad(x,dy), w> at the training batch (B=128, 256->256 @16x16 and
     128->128 @32x32): the three kernels are mutually consistent without an oracle."""
-    for Cin, Cout, H in ((256, 256, 16), (128, 128, 32), (192, 160, 8), (64, 96, 64)):
+    for Cin, Cout, H in ((256, 256, 16), (128, 128, 32), (192, 160, 8), (64, 96, 64), (96, 160, 16), (160, 96, 32)):
         x, w, _ = _conv_case(Cin, Cout, B=128, H=H)
         dy = torch.randn(128, H, H, Cout, device=dev)
         y = ops.conv2d_fwd_raw(x, w, None)
