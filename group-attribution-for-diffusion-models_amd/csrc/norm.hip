@@ -183,7 +183,8 @@ __device__ __forceinline__ void slab_reduce(float* red, float val, const SlabGeo
   __syncthreads();
 }
 
-// x2 != nullptr: channels [C1, C) of the (virtual) concatenation live in x2 ([B][HW][C-C1]); a slab never straddles C1
+// x2 != nullptr: channels [C1, C) of the (virtual) concatenation live in x2 ([B][HW][C-C1]); the source is chosen per
+// channel quad (C1 % 4 == 0), so a slab may straddle the split
 template <int NV>
 __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
                                                      float* __restrict__ y,
@@ -198,7 +199,7 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   const bool act = pl < s.PL;
   const int c0 = sl * s.SC + q * 4;
   const long base = ((long)b * s.HW) * s.C + c0;
-  const bool second = c0 >= C1;                       // block-uniform: slabs do not straddle the split
+  const bool second = c0 >= C1;                       // per thread (its channel quad lies in one source)
   const int ldin = second ? s.C - C1 : C1;
   const float* xin = (second ? x2 + (c0 - C1) : x + c0) + ((long)b * s.HW) * ldin;
   f32x4 v[NV];
@@ -266,7 +267,6 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out) {
   for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
     int SC = k * cpg;
     if (a->C % SC != 0) continue;
-    if (a->x2 && (a->C1 % SC != 0)) continue;          // two sources: a slab must lie inside one of them
     if ((SC * 4) % 128 != 0 && SC != a->C) continue;   // slab rows must be whole 128-B lines, or two workgroups fetch each line
     int qpr = SC / 4;
     if (qpr > NT) break;

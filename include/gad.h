@@ -131,7 +131,7 @@ typedef struct gad_groupnorm_args {
   int64_t ws_bytes;
   /* forward only: channel-concatenated input without the concat (UpBlock2D's torch.cat([h, skip], 1),
    * SURVEY A.1): channels [0, C1) come from x ([B][HW][C1]) and [C1, C) from x2 ([B][HW][C-C1]).
-   * x2 == NULL: single source.  Needs the one-pass plan (gad_groupnorm_one_pass) with slabs inside one source. */
+   * x2 == NULL: single source.  Needs the one-pass plan (gad_groupnorm_one_pass); C1 % 4 == 0. */
   const float* x2;
   int32_t C1;
 } gad_groupnorm_args;

@@ -503,7 +503,8 @@ def test_conv_two_source_equals_concat(ops, C1, C2, H, k, prec):
         ops.conv2d_fwd_raw(nhwc(x)[..., :24].contiguous(), cl_weight(w[:, :24 + C2].contiguous()), None, 1, pad, False, x2=nhwc(x2))
 
 
-@pytest.mark.parametrize("B,C1,C2,H", [(3, 128, 128, 32), (2, 256, 256, 16), (2, 256, 256, 8), (2, 256, 256, 4), (2, 64, 64, 8)])
+@pytest.mark.parametrize("B,C1,C2,H", [(3, 128, 128, 32), (2, 256, 256, 16), (2, 256, 256, 8), (2, 256, 256, 4), (2, 64, 64, 8),
+                                       (2, 256, 128, 16), (2, 128, 256, 8)])   # slabs of 96 channels straddle the split
 def test_groupnorm_two_source_equals_concat(ops, B, C1, C2, H):
     x, x2 = nhwc(rnd(B, C1, H, H, seed=1) + 0.5), nhwc(rnd(B, C2, H, H, seed=2) * 2)
     ga, be = (rnd(C1 + C2, seed=3) * 0.3 + 1).to(dev), rnd(C1 + C2, seed=4).to(dev)
@@ -514,8 +515,8 @@ def test_groupnorm_two_source_equals_concat(ops, B, C1, C2, H):
     assert torch.equal(got, want)
 
 
-def test_groupnorm_two_source_needs_a_slab_inside_each_source(ops):
-    x, x2 = nhwc(rnd(1, 256, 16, 16, seed=1)), nhwc(rnd(1, 128, 16, 16, seed=2))     # 384 channels: 12 per group, slab 96
+def test_groupnorm_two_source_needs_the_one_pass_plan(ops):
+    x, x2 = nhwc(rnd(1, 256, 32, 32, seed=1)), nhwc(rnd(1, 128, 32, 32, seed=2))     # 384 channels at 32x32: two-pass only
     assert not ops.group_norm_two_source_ok(x, x2, 32)
     with pytest.raises(Exception):
         ops.group_norm_cat_raw(x, x2, torch.ones(384, device=dev), torch.zeros(384, device=dev), 32, 1e-6, True)
