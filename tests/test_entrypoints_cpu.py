@@ -76,6 +76,17 @@ def test_config1_cpu_plumbing(tmp_path, tiny_registry):
     coef = data_shapley(2, X, y, v1=float(y.mean()) - 1.0, v0=float(y.mean()) + 1.0)
     assert coef.shape == (2, 1) and np.isfinite(coef).all()
     assert abs(coef.sum() - (-2.0)) < 1e-8                                           # efficiency: v1 - v0
+    # ---- 5. the acceptance harness: the reference's own reader (lds.py::collect_data, run unchanged by
+    #         tests/golden/make_lds_golden.py on a db this build wrote) extracted exactly these masks / seeds ----
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "lds_collect.json")))
+    for r, g in zip(rows, gold["rows"]):
+        for k in ("dataset", "method", "removal_dist", "removal_seed", "exp_name", "gd_steps", "remaining_idx"):
+            assert r[k] == g[k], k                                                   # same bookkeeping, bit for bit
+        assert isinstance(r["total_steps_time"], float) and isinstance(r["total_sampling_time"], float)
+    assert gold["seeds"] == [r["removal_seed"] for r in rows]
+    assert np.array_equal(np.array(gold["masks"]), X)                                # class masks as the reference builds them
+    assert [b[0] for b in gold["behaviors"]] == [g["fid_value"] for g in gold["rows"]]
+    assert np.allclose(y, [b[0] for b in gold["behaviors"]], rtol=0.05)              # same pipeline, CPU float noise only
 
 
 def test_uniform_removal_reproduces_reference_typeerror(tmp_path, tiny_registry):
