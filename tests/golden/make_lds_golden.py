@@ -9,6 +9,9 @@ Two stages in two processes (this build's `src` package and the reference's `src
                  layout, call collect_data(db, {"dataset","removal_dist","method"}, by_class=True) and dump its outputs.
 Run (build container only):  python tests/golden/make_lds_golden.py
 Output: tests/golden/lds_collect.json = {"rows": [the db rows, keys the reader uses], "masks", "behaviors", "seeds"}
+The Stable-Diffusion evaluator gets the same treatment: rows assembled by this build's
+text_to_image/compute_model_behaviors.py::assemble_row ("write_sd") are read by the reference's
+text_to_image/shapley_lds.py::collect_data ("read_sd") -> tests/golden/sd_lds_collect.json.
 """
 import argparse
 import json
@@ -96,12 +99,59 @@ def stage_read(db, out):
     print("reference collect_data ->", masks.tolist(), behaviors.ravel().tolist(), seeds.tolist())
 
 
+def sd_rows():
+    """Three behaviour rows through this build's text_to_image/compute_model_behaviors.py::assemble_row (pure host code)."""
+    sys.path[:0] = [os.path.join(ROOT, "group-attribution-for-diffusion-models_amd"), ROOT]
+    from text_to_image import compute_model_behaviors as M
+    rows = []
+    for k, remaining in enumerate(([0, 2, 5, 7], [1, 2, 3, 4, 8, 9], [6])):
+        args = M.parse_args(["--reference_lora_dir", "ref", "--lora_dir", f"lora_{k}", "--db", "db.jsonl", "--num_images", "2",
+                             "--exp_name", f"retrain_artist_shapley_seed_{k}"])
+        lists = {b: [0.1 * (k + 1) + 0.01 * i + 0.001 * j for i in range(2)] for j, b in enumerate(M.BEHAVIOURS)}
+        times = {b: [1.0 + i for i in range(2)] for b in M.BEHAVIOURS}
+        rows.append(M.assemble_row(args, lists, times, remaining, [i for i in range(10) if i not in remaining]))
+    return rows
+
+
+def stage_write_sd(db):
+    with open(db, "w") as f:
+        for r in sd_rows():
+            f.write(json.dumps(r) + "\n")
+
+
+def stage_read_sd(db, out):
+    def placeholder(name, **attrs):
+        m = types.ModuleType(name)
+        m.__dict__.update(attrs)
+        sys.modules[name] = m
+        return m
+
+    sys.path[:0] = [REF, os.path.join(REF, "text_to_image")]
+    placeholder("pynvml")
+    placeholder("src.constants", DATASET_DIR="/tmp/_ds", OUTDIR="/tmp/_out", LOGDIR="/tmp/_log", MAX_NUM_SAMPLE_IMAGES_TO_SAVE=64)
+    placeholder("src.diffusers"), placeholder("src.diffusers.models")
+    placeholder("src.diffusers.models.attention_processor", my_get_processor=None)
+    import pandas as pd
+    import shapley_lds                                            # the reference's SD evaluator, unmodified
+    df = pd.read_json(db, lines=True)
+    masks, avg = shapley_lds.collect_data(df, num_groups=10, model_behavior_key="aesthetic_score_avg", n_samples=None)
+    local = shapley_lds.collect_data(df, num_groups=10, model_behavior_key="simple_loss", n_samples=2,
+                                     collect_remaining_masks=False)
+    seeds = df["exp_name"].str.split("seed_", expand=True)[1].astype(int).tolist()     # shapley_lds.py:160-162
+    json.dump({"masks": masks.tolist(), "aesthetic_score_avg": avg.tolist(), "simple_loss": local.tolist(), "subset_seed": seeds},
+              open(out, "w"), separators=(",", ":"))
+    print("reference shapley_lds.collect_data ->", masks.tolist(), avg.ravel().tolist(), local.tolist(), seeds)
+
+
 if __name__ == "__main__":
     if len(sys.argv) > 1:
-        {"write": stage_write, "read": stage_read}[sys.argv[1]](*sys.argv[2:])
+        {"write": stage_write, "read": stage_read, "write_sd": stage_write_sd, "read_sd": stage_read_sd}[sys.argv[1]](*sys.argv[2:])
     else:
         import tempfile
         tmp = tempfile.mkdtemp()
         db = os.path.join(tmp, "db.jsonl")
         subprocess.run([sys.executable, __file__, "write", db], check=True)
         subprocess.run([sys.executable, __file__, "read", db, os.path.join(HERE, "lds_collect.json")], check=True)
+        sdb = os.path.join(tmp, "sd.jsonl")
+        subprocess.run([sys.executable, __file__, "write_sd", sdb], check=True)
+        subprocess.run([sys.executable, __file__, "read_sd", sdb, os.path.join(HERE, "sd_lds_collect.json")], check=True)

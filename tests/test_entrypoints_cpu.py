@@ -241,3 +241,31 @@ def test_artbench_metadata_to_latent_cache(tmp_path):
     import pytest
     with pytest.raises(KeyError):
         assemble_latent_cache(str(tmp_path), lat, torch.ones(77, 8), cls="post_impressionism")
+
+
+def test_sd_behaviour_rows_are_what_the_reference_reader_extracted():
+    """tests/golden/sd_lds_collect.json = the outputs of the reference's text_to_image/shapley_lds.py::collect_data
+    (:105-135, run unchanged) on rows built by compute_model_behaviors.py::assemble_row; the same rows are rebuilt here."""
+    from text_to_image import compute_model_behaviors as M
+    gold = json.load(open(os.path.join(os.path.dirname(__file__), "golden", "sd_lds_collect.json")))
+    rows = []
+    for k, remaining in enumerate(([0, 2, 5, 7], [1, 2, 3, 4, 8, 9], [6])):
+        args = M.parse_args(["--reference_lora_dir", "ref", "--lora_dir", f"lora_{k}", "--db", "db.jsonl", "--num_images", "2",
+                             "--exp_name", f"retrain_artist_shapley_seed_{k}"])
+        lists = {b: [0.1 * (k + 1) + 0.01 * i + 0.001 * j for i in range(2)] for j, b in enumerate(M.BEHAVIOURS)}
+        times = {b: [1.0 + i for i in range(2)] for b in M.BEHAVIOURS}
+        rows.append(json.loads(json.dumps(M.assemble_row(args, lists, times, remaining, [i for i in range(10) if i not in remaining]))))
+    masks = np.zeros((3, 10))
+    for i, r in enumerate(rows):
+        masks[i, r["remaining_idx"]] = 1
+    assert np.array_equal(masks, np.array(gold["masks"]))
+    assert [[r["aesthetic_score_avg"]] for r in rows] == gold["aesthetic_score_avg"]
+    assert [[r[f"generated_image_{i}_simple_loss"] for i in range(2)] for r in rows] == gold["simple_loss"]
+    assert [int(r["exp_name"].split("seed_")[1]) for r in rows] == gold["subset_seed"]
+    # the reference's own column grammar (:459-498): per-image values and times, quantiles, totals
+    r = rows[0]
+    for key in ("generated_image_1_ssim", "generated_image_1_nrmse_time", "aesthetic_score_0.5", "aesthetic_score_0.9",
+                "clip_prompt_score_0.75", "clip_prompt_score_avg", "aesthetic_score_time", "removal_idx", "reference_lora_dir",
+                "lora_steps", "cls", "seed", "no_duplicate"):
+        assert key in r, key
+    assert r["aesthetic_score_0.5"] == pytest.approx(np.quantile([0.105, 0.115], 0.5))

@@ -1,6 +1,7 @@
 """GPU parity of the Stable-Diffusion pieces: LayerNorm, GEGLU, cross-attention with Tk=77,
 UNet2DConditionModel forward and LoRA-only backward vs the CPU oracle (fp64/fp32 torch)."""
 import math
+import os
 
 import pytest
 import torch
@@ -230,3 +231,58 @@ def test_guided_latent_sampling_matches_oracle_loop():
                               got[:1], cond[:1].to(dev), torch.tensor([751, 501, 251, 1]), n_noises=2,
                               generator=torch.Generator(device=dev).manual_seed(0))
     assert loss > 0 and loss == loss
+
+
+def test_sd_model_behaviours_entry_point(tmp_path):
+    """train two LoRAs (full data = reference, one Shapley coalition) with the trainer entry point, then
+    compute_model_behaviors.py: db row grammar of the reference (:459-498), resume from its checkpoint, duplicate guard;
+    a model compared with itself has nrmse 0 / similarity 1."""
+    import json
+    import pandas as pd
+    from text_to_image import compute_model_behaviors as M
+    from text_to_image import train_text_to_image_lora as T
+    data = tmp_path / "artbench"
+    T.synthetic_cache(str(data / "latent_cache.pt"), n=120, n_artists=10, res=128, ctx_dim=96)
+    pd.DataFrame({"artist": sorted({f"artist_{i:03d}" for i in range(10)})}).to_csv(data / "post_impressionism_artists.csv", index=False)
+    over = json.dumps(dict(block_out_channels=(64, 128, 128, 128), attention_head_dim=4, cross_attention_dim=96, sample_size=16))
+    common = ["--train_data_dir", str(data), "--output_dir", str(tmp_path / "out"), "--cls_key", "style", "--cls",
+              "post_impressionism", "--train_batch_size", "8", "--unet_overrides", over, "--seed", "42", "--rank", "4",
+              "--method", "retrain", "--max_train_steps", "3", "--learning_rate", "1e-3"]
+    assert T.main(T.parse_args(common))
+    assert T.main(T.parse_args(common + ["--removal_dist", "shapley", "--removal_unit", "artist", "--removal_seed", "1"]))
+    root = tmp_path / "out" / "artbench_post_impressionism" / "retrain" / "models"
+    full, coal = root / "full", root / "artist_shapley" / "shapley_seed=1"
+    db = str(tmp_path / "behaviours.jsonl")
+    base = ["--reference_lora_dir", str(full), "--db", db, "--num_images", "3", "--resolution", "128", "--seed", "42",
+            "--unet_overrides", over, "--num_inference_steps", "4", "--n_noises", "2", "--no_duplicate"]
+    ck = str(tmp_path / "ck.pt")
+    assert M.main(M.parse_args(base + ["--lora_dir", str(coal), "--exp_name", "retrain_artist_shapley_seed_1", "--ckpt_path", ck,
+                                       "--ckpt_freq", "2"]))
+    assert M.main(M.parse_args(base + ["--lora_dir", str(full), "--exp_name", "retrain_full"]))
+    rows = [json.loads(l) for l in open(db)]
+    assert len(rows) == 2
+    r = rows[0]
+    ridx = pd.read_csv(coal / "removal_idx.csv")
+    assert r["remaining_idx"] == ridx["idx"][ridx["remaining"]].to_list() and r["removal_idx"] == ridx["idx"][~ridx["remaining"]].to_list()
+    for i in range(3):
+        for b in M.BEHAVIOURS:
+            assert f"generated_image_{i}_{b}" in r and f"generated_image_{i}_{b}_time" in r
+        assert math.isfinite(r[f"generated_image_{i}_simple_loss"]) and r[f"generated_image_{i}_simple_loss"] > 0
+    for k in ("aesthetic_score_0.5", "aesthetic_score_0.9", "clip_prompt_score_avg", "aesthetic_score_avg", "exp_name", "seed"):
+        assert k in r
+    assert rows[1]["remaining_idx"] is None                                   # full-data LoRA dir has no removal_idx.csv
+    for i in range(3):                                                         # same weights, same seed -> identical samples
+        assert rows[1][f"generated_image_{i}_nrmse"] == 0.0
+        assert abs(rows[1][f"generated_image_{i}_clip_similarity"] - 1.0) < 1e-5
+    assert any(r[f"generated_image_{i}_nrmse"] > 0 for i in range(3))          # the coalition model differs
+    # duplicate guard (:168-189) and resume from the checkpoint written after 2 of 3 images
+    assert M.main(M.parse_args(base + ["--lora_dir", str(full), "--exp_name", "retrain_full"])) is False
+    assert os.path.exists(ck)
+    db2 = str(tmp_path / "behaviours2.jsonl")
+    resumed = [a if a != db else db2 for a in base]
+    assert M.main(M.parse_args(resumed + ["--lora_dir", str(coal), "--exp_name", "retrain_artist_shapley_seed_1", "--ckpt_path", ck,
+                                          "--ckpt_freq", "2"]))
+    r2 = json.loads(open(db2).readline())
+    for i in range(3):
+        assert r2[f"generated_image_{i}_nrmse"] == pytest.approx(r[f"generated_image_{i}_nrmse"], rel=1e-6)
+        assert r2[f"generated_image_{i}_simple_loss"] == pytest.approx(r[f"generated_image_{i}_simple_loss"], rel=1e-5)
