@@ -259,8 +259,9 @@ def test_sd_behaviour_rows_are_what_the_reference_reader_extracted():
     for i, r in enumerate(rows):
         masks[i, r["remaining_idx"]] = 1
     assert np.array_equal(masks, np.array(gold["masks"]))
-    assert [[r["aesthetic_score_avg"]] for r in rows] == gold["aesthetic_score_avg"]
-    assert [[r[f"generated_image_{i}_simple_loss"] for i in range(2)] for r in rows] == gold["simple_loss"]
+    # (pandas' json float parser may differ from Python's in the last ulp)
+    assert np.allclose([[r["aesthetic_score_avg"]] for r in rows], gold["aesthetic_score_avg"], rtol=1e-14, atol=0)
+    assert np.allclose([[r[f"generated_image_{i}_simple_loss"] for i in range(2)] for r in rows], gold["simple_loss"], rtol=1e-14, atol=0)
     assert [int(r["exp_name"].split("seed_")[1]) for r in rows] == gold["subset_seed"]
     # the reference's own column grammar (:459-498): per-image values and times, quantiles, totals
     r = rows[0]
