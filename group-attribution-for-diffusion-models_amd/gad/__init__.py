@@ -13,5 +13,5 @@ from . import coalition  # noqa: F401,E402
 from .coalition import DeviceLoader, antithetic_timesteps, seed_everything  # noqa: F401,E402
 
 __version__ = "0.1.0"
-from .scoring import fid_against_dataset, global_scores_against_dataset  # noqa: F401,E402
+from .scoring import diversity_against_dataset, fid_against_dataset, global_scores_against_dataset  # noqa: F401,E402
 from .sd import UNet2DConditionModel  # noqa: F401,E402

@@ -142,3 +142,29 @@ def global_scores_against_dataset(images01, dataset, device, batch_size=512, fea
     is_value = inception_score_from_probs(probs)
     precision, recall = calc_pr(make_manifold(gen_f, nhood_size, 10000, 10000, device), m_ref, 10000, 10000, device)
     return {"fid_value": fid, "is": is_value, "precision": precision, "recall": recall}
+
+
+def diversity_against_dataset(images01, dataset, device, num_cluster=20, batch_size=256, feature_dims=768, max_ref=2000):
+    """The CelebA global behaviour unlearn.py writes (:787-803): entropy / cluster_count / cluster_proportions of
+    calculate_diversity_score (diversity_score.py:82-188) - Ward clusters of the reference embeddings, generated samples
+    assigned to the nearest cluster mean, log2 entropy of the proportions.  The BLIP-VQA vision tower (hub-fetched, :89-90)
+    is replaced by the seeded stand-in extractor; the reference set ({OUTDIR}/celeba/cluster_imgs there) is the training
+    set itself (its first `max_ref` items), mapped to [0,1] like the pipeline output.  Embeddings are computed on the
+    device; the Ward linkage stays scipy on the host, as in the reference."""
+    from src.attributions.global_scores.diversity_score import diversity_from_embeddings
+    key = ("div_net", feature_dims)
+    net = _REF_STATS.get(key)
+    if net is None:
+        net = FeatureNet(feature_dims, seed=4321).to(device)
+        _REF_STATS[key] = net
+    rkey = ("div_ref", id(dataset))
+    if rkey not in _REF_STATS:
+        idx = list(range(min(len(dataset), max_ref)))
+        ref = dataset.device_tensor(device, idx).add(1).div(2).clamp(0, 1)
+        f = compute_features_torch(net, ref, batch_size, device)
+        _REF_STATS[rkey] = torch.nn.functional.normalize(f.double(), dim=1).cpu().numpy()
+    emb_ref = _REF_STATS[rkey]
+    f = compute_features_torch(net, images01.to(device), batch_size, device)
+    emb_gen = torch.nn.functional.normalize(f.double(), dim=1).cpu().numpy()
+    entropy, cluster_count, proportions, _, _ = diversity_from_embeddings(emb_ref, emb_gen, num_cluster)
+    return {"entropy": entropy, "cluster_count": cluster_count, "cluster_proportions": proportions}

@@ -76,9 +76,18 @@ def load_ckpt_model(args, model_loaddir, backend=None):
 
 def build_pipeline(args, model, backend=None):
     be = _backend(backend)
-    if args.dataset in ("celeba", "imagenette"):
-        raise NotImplementedError("latent-diffusion pipelines need the VQ-VAE / text encoder weights "
+    if args.dataset == "imagenette":
+        raise NotImplementedError("the text-conditioned LDM needs the VQ-VAE / BERT weights "
                                   "(fetched from the hub in the reference, diffusion_utils.py:214-235)")
+    if args.dataset == "celeba":
+        # LDMPipeline without its (hub-fetched) VQ-VAE: the U-Net half on 3x64x64 latents with the LDM scheduler of the
+        # registry (ddpm_config.py:452-461); `--precompute_stage reuse` keeps the reference in latent space the same way
+        # (main.py:531-546 sets pipeline.vqvae = None)
+        if getattr(args, "precompute_stage", None) != "reuse":
+            raise NotImplementedError("celeba samples in latent space: pass --precompute_stage reuse (no VQ-VAE weights here)")
+        sc = {k: v for k, v in dataset_config("celeba")["scheduler_config"].items() if not k.startswith("_")}
+        pipeline = be.DDPMPipeline(unet=model, scheduler=be.DDIMScheduler(**sc)).to(args.device)
+        return pipeline, None, None
     pipeline = be.DDPMPipeline(unet=model, scheduler=be.DDIMScheduler()).to(args.device)
     return pipeline, None, None
 

@@ -148,7 +148,10 @@ def main(args, backend=None):
     if args.model_behavior == "global":
         print(f"Generating {args.n_samples}...")
         images = generate_images(args, pipeline)
-        if hasattr(backend, "global_scores_against_dataset"):      # fid_value, is, precision, recall (:807-837)
+        if args.dataset == "celeba":                               # entropy, cluster_count, cluster_proportions (:787-803)
+            info.update(backend.diversity_against_dataset(images, dataset, device, num_cluster=20))
+            print(f"entropy: {info['entropy']}")
+        elif hasattr(backend, "global_scores_against_dataset"):      # fid_value, is, precision, recall (:807-837)
             info.update(backend.global_scores_against_dataset(images, dataset, device, args.batch_size))
         else:
             info["fid_value"] = backend.fid_against_dataset(images, dataset, device, args.batch_size)

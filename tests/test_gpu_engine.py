@@ -109,3 +109,53 @@ def test_entry_points_and_sharded_runner_on_gpu(tmp_path, monkeypatch):
     rows = [json.loads(l) for l in open(db2)]
     assert [r["removal_seed"] for r in rows] == [0, 1, 2]
     assert run_sharded(eng, [0, 1, 2], db_path=db2) == []            # idempotent: everything is already in the db
+
+
+def test_celeba_latent_mode_entry_points(tmp_path, monkeypatch):
+    """BASELINE config 3 in latent space: CelebA-HQ rows = labels.csv x the VQ-VAE latent dictionary
+    (`--precompute_stage reuse`, main.py:531-546), sFT by celebrity group, latent sampling with the LDM scheduler, and the
+    demographic-diversity behaviours (entropy / cluster_count / cluster_proportions, unlearn.py:787-803) in the jsonl."""
+    import pandas as pd
+    import src.constants as constants
+    from src.ddpm_config import DDPMConfig
+    cfg = {**DDPMConfig.celeba_config}
+    cfg["unet_config"] = dict(cfg["unet_config"], block_out_channels=[32, 64, 64, 64], attention_head_dim=8,
+                              norm_num_groups=8, sample_size=16)
+    cfg["n_samples"] = 4
+    cfg["batch_size"] = 8
+    for k in ("training_steps", "ckpt_freq", "sample_freq"):
+        cfg[k] = dict(cfg[k], retrain=2)
+    monkeypatch.setattr(DDPMConfig, "celeba_config", cfg)
+    root = tmp_path / "datasets" / "celeba_hq_256_50_resized"
+    root.mkdir(parents=True)
+    names = [f"{i:05d}.jpg" for i in range(60)]
+    pd.DataFrame({"filename": names, "celeb": [i % 5 for i in range(60)]}).to_csv(root / "labels.csv", index=False)
+    g = torch.Generator().manual_seed(0)
+    torch.save({n: torch.randn(3, 16, 16, generator=g) * 0.5 + 0.2 * (i % 5) for i, n in enumerate(names)}, tmp_path / "vqvae_output.pt")
+    monkeypatch.setenv("GAD_DATA", "real")
+    monkeypatch.setenv("GAD_LATENTS", str(tmp_path / "vqvae_output.pt"))
+    monkeypatch.setattr(constants, "DATASET_DIR", str(tmp_path / "datasets"))
+    from unconditional_generation import main as train_main
+    from unconditional_generation import unlearn as unlearn_main
+    out, db = str(tmp_path / "res"), str(tmp_path / "db.jsonl")
+    with pytest.raises(NotImplementedError):                          # pixels would need the VQ-VAE
+        train_main.main(train_main.parse_args(["--dataset", "celeba", "--method", "retrain", "--outdir", out]))
+    a = train_main.parse_args(["--dataset", "celeba", "--method", "retrain", "--outdir", out, "--precompute_stage", "reuse",
+                               "--num_inference_steps", "5", "--log_freq", "1"])
+    assert train_main.main(a)
+    mdir = os.path.join(out, "celeba", "retrain", "models", "full")
+    ck = torch.load(os.path.join(mdir, "ckpt_steps_00000002.pt"), weights_only=False)
+    pdir = os.path.join(out, "celeba", "pruned", "models", "pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
+    os.makedirs(pdir)
+    torch.save({"unet": ck["unet"], "unet_config": ck["unet_config"]}, os.path.join(pdir, "ckpt_steps_00000000.pt"))
+    u = unlearn_main.parse_args(["--dataset", "celeba", "--method", "gd", "--removal_dist", "shapley", "--removal_seed", "2",
+                                 "--load", mdir, "--outdir", out, "--db", db, "--gd_steps", "2", "--n_samples", "12",
+                                 "--batch_size", "6", "--num_inference_steps", "5", "--model_behavior", "global",
+                                 "--precompute_stage", "reuse"])
+    assert unlearn_main.main(u)
+    row = json.loads(open(db).readline())
+    kept = {i % 5 for i in row["remaining_idx"]}
+    assert 0 < len(kept) < 5 and all((i % 5) in kept for i in row["remaining_idx"])      # whole celebrity groups
+    assert len(row["cluster_count"]) == 20 and sum(row["cluster_count"]) == 12
+    assert abs(sum(row["cluster_proportions"]) - 1.0) < 1e-9 and 0.0 <= row["entropy"] <= np.log2(20) + 1e-9
+    assert "fid_value" not in row and row["trained_steps"] == 2
