@@ -79,7 +79,6 @@ struct DevArgs {
   int ldr;
   float* ws;
   int tiles_m, tiles_n, splitk, ktiles_per_split;
-  int stagger;   // patch kernels: s_sleep(127) count for the workgroups that take the second slot of each CU
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -1032,13 +1031,17 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   int nwg = gridDim.x, bid = blockIdx.x;
   int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
   int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
-  int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  // split-K over the 32-channel chunks (small maps: few tiles, long K): split s owns chunks [c_begin, c_end)
+  const int tiles = p.tiles_m * p.tiles_n;
+  const int split = t / tiles, trem = t - split * tiles;
+  int tile_m = trem / p.tiles_n, tile_n = trem - tile_m * p.tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
   // tensor is (H/2) x (W/2) and patch pixel (ih, iw) reads stored pixel (ih>>1, iw>>1)
   const int H = p.g.Ho, C = p.g.C, ups = p.g.upsample;
   const int img = row0 / (H * W), oh0 = NI == 1 ? (row0 - img * (H * W)) / W : 0;
-  const int nchunks = C / BK;
+  const int c_begin = split * p.ktiles_per_split;
+  const int c_end = min(C / BK, c_begin + p.ktiles_per_split);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
   const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
@@ -1084,30 +1087,24 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     abase[i] = ((m / (TR * W)) * (PR * PW) + ((m / W) % TR) * PW + (m % W)) * PLD + 4 * h;
   }
 
-  // The two workgroups that share a CU start together and, doing identical work, stay in lockstep: their prologues
-  // (exposed global latency) and epilogues (64 KB of stores each) coincide and the matrix pipe idles.  Delaying the
-  // workgroups of the second dispatch wave (256 .. 511: the second slot of every CU) by about half a tile's duration
-  // once keeps the pairs out of phase for the rest of the launch - every later workgroup inherits its slot's phase.
-  if (p.stagger > 0 && bid >= 256 && bid < 512)
-    for (int i = 0; i < p.stagger; ++i) __builtin_amdgcn_s_sleep(127);
-  // prologue: patch of chunk 0 and the weights of step 0
-  bl.prep(0, mb);
+  // prologue: patch of the first chunk and the weights of step 0
+  bl.prep(c_begin * BK, mb);
 #pragma unroll
   for (int q = 0; q < BL::NS; ++q) glds16(bl.src(q), BL::dma_dst(btile0, q));
 #pragma unroll
-  for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i], (pvalid >> i) & 1u));
+  for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + c_begin * BK, (pvalid >> i) & 1u));
   commit_patch();
   barrier_after_dma();
 
-  const int nsteps = nchunks * 9;
-  int chunk = 0, tap = 0;
+  const int nsteps = (c_end - c_begin) * 9;
+  int chunk = c_begin, tap = 0;
   for (int st = 0; st < nsteps; ++st) {
     const float* lb = btile0 + (st & 1) * B_TILE;
     float* nb = btile0 + ((st + 1) & 1) * B_TILE;
     int ntap = tap + 1, nchunk = chunk;
     if (ntap == 9) { ntap = 0; ++nchunk; }
     bl.prep(st + 1 < nsteps ? ntap * C + nchunk * BK : p.K, mb);     // past the end: zeros
-    const int cnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
+    const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
 #pragma unroll
     for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform: one float4 of the next chunk's patch per tap
       if (tap == i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + cnext * BK, (pvalid >> i) & 1u));
@@ -1151,23 +1148,28 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     chunk = nchunk;
   }
 
-  float* Cp = p.C;
-  const float* R = p.residual;
+  const bool direct = p.splitk == 1;          // partial sums of a split go to the workspace; splitk_reduce_kernel finishes
+  float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
+  const float* R = direct ? p.residual : nullptr;
+  const int ldc = direct ? p.ldc : p.N;
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     int n = col0 + wn * (BN / 2) + j * 32 + l31;
     if (n >= p.N) continue;
-    float bias = p.bias ? p.bias[n] : 0.f;
+    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
         int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m >= p.M) continue;
-        float v = acc[i][j][e] * p.alpha + bias;
-        if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
-        if (R) v += R[(long)m * p.ldr + n];
-        Cp[(long)m * p.ldc + n] = v;
+        float v = acc[i][j][e];
+        if (direct) {
+          v = v * p.alpha + bias;
+          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
+          if (R) v += R[(long)m * p.ldr + n];
+        }
+        Cp[(long)m * ldc + n] = v;
       }
     }
   }
@@ -1435,14 +1437,34 @@ static bool patch_conv_geom(const gad_gemm_args* a, bool dgrad = false) {
   return pick_vec(a) == 4 && modes && !a->A2 && g.KH == 3 && g.KW == 3 &&
          g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && g.Ho == (g.upsample ? 2 * g.H : g.H) &&
          g.Wo == (g.upsample ? 2 * g.W : g.W) &&
-         (((g.Wo == 64 || g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) || (g.Wo == 8 && g.Ho == 8 && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
+         (((g.Wo == 64 || g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) ||
+          ((g.Wo == 8 || g.Wo == 4) && g.Ho == g.Wo && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
          (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
 }
 static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch_conv_geom(a); }
-// fp32: only where the planner would have launched the 128x128 tile without split-K anyway
-static bool use_patch_conv_f32(const gad_gemm_args* a, const Plan& pl) {
+// fp32 patch kernel: its own plan - 128-pixel tiles, split-K over the 32-channel chunks when the tiles alone cannot fill
+// the 512 workgroup slots (small maps); launches too small even then stay on the generic kernel
+struct PatchPlan {
+  int splitk, chunks_per_split;
+  long blocks;
+};
+static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
   const char* on = getenv("GAD_PATCH_CONV_F32");
-  return !use_bf16(a) && (patch_conv_geom(a) || patch_conv_geom(a, true)) && pl.bm == 128 && pl.splitk == 1 && !(on && !atoi(on));
+  if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true)) || (on && !atoi(on))) return false;
+  if (a->N < 64) return false;               // conv_out (3 output channels): a 128-wide tile would be 98 % padding
+  const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, 128);
+  const int nchunks = a->g.C / BK;
+  long sk = 1;
+  if (tiles < 384) {
+    sk = gad_ceil_div(512, tiles);
+    if (sk > nchunks / 2) sk = nchunks / 2;      // >= 2 chunks (18 K steps) per workgroup
+    if (sk < 1) sk = 1;
+  }
+  const int per = (int)gad_ceil_div(nchunks, sk);
+  pp->chunks_per_split = per;
+  pp->splitk = (int)gad_ceil_div(nchunks, per);
+  pp->blocks = tiles * pp->splitk;
+  return pp->blocks >= 192;
 }
 
 // 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible)
@@ -1471,8 +1493,8 @@ extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
   if (use_bf16(a)) return 1;
-  Plan pl = make_plan(a);
-  return use_patch_conv_f32(a, pl) ? 2 : 0;
+  PatchPlan pp;
+  return use_patch_conv_f32(a, &pp) ? 2 : 0;
 }
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
@@ -1486,6 +1508,10 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
 
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   if (int sp = wgrad_patch_splits(a)) return sp > 1 ? (int64_t)sp * a->M * a->N * (int64_t)sizeof(float) : 0;
+  {
+    PatchPlan pp;
+    if (use_patch_conv_f32(a, &pp)) return pp.splitk > 1 ? (int64_t)pp.splitk * a->M * a->N * (int64_t)sizeof(float) : 0;
+  }
   Plan pl = make_plan(a);
   if (pl.splitk == 1) return 0;
   long batch = a->batch > 0 ? a->batch : 1;
@@ -1561,7 +1587,6 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
-  d.stagger = 0;
   d.A2 = a->A2; d.a_split = a->a_split; d.ldx2 = a->ldx2;
   d.M = a->M; d.N = a->N; d.K = a->K;
   d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
@@ -1615,35 +1640,41 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     if (a->g.Wo == 64) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<64, 1>), grid, block, 0, st, d);
     else if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32, 1>), grid, block, 0, st, d);
     else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16, 1>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<8, 2>), grid, block, 0, st, d);
+    else if (a->g.Wo == 8) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<8, 2>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<4, 8>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
     return 0;
   }
-  d.stagger = 0;
-  if (use_patch_conv_f32(a, pl)) {
-    dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
-    {   // half of a tile's duration when two workgroups share the SIMDs: K steps x ~3.6 us / 2, in 4-us sleeps
-      const char* sg = getenv("GAD_STAGGER");
-      const int nsteps = a->K / BK;
-      int auto_sg = pl.nblocks > 512 ? (int)(nsteps * 0.45) : 0;
-      d.stagger = sg ? atoi(sg) * (pl.nblocks > 512 ? 1 : 0) : auto_sg;
-      if (sg && atoi(sg) < 0) d.stagger = auto_sg;
+  PatchPlan pp;
+  if (use_patch_conv_f32(a, &pp)) {
+    d.tiles_m = (int)gad_ceil_div(a->M, 128);
+    d.tiles_n = (int)gad_ceil_div(a->N, 128);
+    d.splitk = pp.splitk;
+    d.ktiles_per_split = pp.chunks_per_split;
+    if (pp.splitk > 1) {
+      int64_t need = (int64_t)pp.splitk * a->M * a->N * (int64_t)sizeof(float);
+      GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: patch-conv split-K workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
     }
+    dim3 grid((unsigned)pp.blocks), block(NTHREADS);
     const bool dg = am == GAD_A_CONVT;
-    if (a->g.Wo == 64) {
-      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<64, 1, true>), grid, block, 0, st, d);
-      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<64, 1, false>), grid, block, 0, st, d);
-    } else if (a->g.Wo == 32) {
-      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, true>), grid, block, 0, st, d);
-      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<32, 1, false>), grid, block, 0, st, d);
-    } else if (a->g.Wo == 16) {
-      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1, true>), grid, block, 0, st, d);
-      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<16, 1, false>), grid, block, 0, st, d);
-    } else {
-      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2, true>), grid, block, 0, st, d);
-      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<8, 2, false>), grid, block, 0, st, d);
-    }
+#define GAD_PATCH(W_, NI_)                                                                              \
+    do {                                                                                                \
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, true>), grid, block, 0, st, d);     \
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, false>), grid, block, 0, st, d);       \
+    } while (0)
+    if (a->g.Wo == 64) GAD_PATCH(64, 1);
+    else if (a->g.Wo == 32) GAD_PATCH(32, 1);
+    else if (a->g.Wo == 16) GAD_PATCH(16, 1);
+    else if (a->g.Wo == 8) GAD_PATCH(8, 2);
+    else GAD_PATCH(4, 8);
+#undef GAD_PATCH
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch f32)");
+    if (pp.splitk > 1) {
+      long total = (long)a->M * a->N;
+      int rblocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
+      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, st, d, 1);
+      GAD_LAUNCH_CHECK("gad_gemm(patch splitk reduce)");
+    }
     return 0;
   }
   if (a->A2) {

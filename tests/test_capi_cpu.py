@@ -100,6 +100,8 @@ def test_kernel_family_selection_is_a_pure_host_decision():
     assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, big, 128, 128, 32, 32, 128, k=1, pad=0)) == 0        # 1x1
     assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, big, 128, 9 * 100, 32, 32, 100)) == 0               # C % 32 != 0
     assert kid(_conv_args(_capi.A_CONV, _capi.B_KC, 2 * 32 * 32, 128, 9 * 128, 32, 32, 128)) == 0       # tiny M: split-K plan
+    small = _conv_args(_capi.A_CONV, _capi.B_KC, 1024 * 16, 256, 9 * 256, 4, 4, 256)                     # 4x4 maps, B = 1024
+    assert kid(small) == 2 and lib.gad_gemm_workspace_bytes(ctypes.byref(small)) == 2 * 1024 * 16 * 256 * 4   # 2 chunk splits
     up = _conv_args(_capi.A_CONV, _capi.B_KC, big, 256, 9 * 256, 16, 16, 256, Ho=32, Wo=32, ups=1)
     assert kid(up) == 2                                                      # nearest-2x fused into the patch fetch
     dg = _conv_args(_capi.A_CONVT, _capi.B_WDGRAD, big, 128, 9 * 128, 32, 32, 128)
