@@ -5,6 +5,7 @@ fixtures).  Run:  python tests/golden/make_golden.py
 What is imported from /root/reference (read-only, unmodified):
   src/attributions/methods/datashapley.py   data_shapley, kernel_shap
   src/attributions/methods/databanzhaf.py   data_banzhaf
+  src/attributions/methods/datamodel.py     datamodel
   src/datasets.py                           remove_data_by_{shapley,datamodel,uniform,loo}, remove_data_for_aoi
   src/ddpm_config.py                        DDPMConfig / PromptConfig / Lora* registries
 `src/datasets.py` and `src/ddpm_config.py` import torchvision / lightning-free
@@ -14,7 +15,7 @@ registered for the *unrelated* imports only - none of the functions recorded
 here touches them (they are pure numpy).
 
 Outputs (data only - inputs + expected outputs):
-  tests/golden/samplers.json, shapley.npz, configs.json
+  tests/golden/samplers.json, shapley.npz, configs.json, datamodel.npz
 """
 import json
 import os
@@ -146,7 +147,16 @@ def main():
                 reg[f"{cls_name}.{k}"] = v
     with open(os.path.join(OUT, "configs.json"), "w") as f:
         json.dump(reg, f, indent=1, sort_keys=True, default=str)
-    print("wrote", len(cases), "sampler cases;", len(blobs), "solver arrays;", len(reg), "config entries")
+
+    # ---------------- datamodel (bootstrap RidgeCV, global numpy RNG) -------
+    from src.attributions.methods.datamodel import datamodel
+    rng = np.random.RandomState(7)
+    Xd = (rng.rand(120, 20) > 0.5).astype(np.float64)
+    yd = Xd @ rng.randn(20) + 0.1 * rng.randn(120)
+    np.random.seed(123)
+    coef = datamodel(Xd, yd, 4)
+    np.savez_compressed(os.path.join(OUT, "datamodel.npz"), X=Xd, y=yd, seed=np.array(123), coef=coef)
+    print("wrote", len(cases), "sampler cases;", len(blobs), "solver arrays;", len(reg), "config entries; datamodel", coef.shape)
 
 
 if __name__ == "__main__":

@@ -212,3 +212,14 @@ def test_real_data_readers(tmp_path, monkeypatch):
     assert L.device_tensor("cpu", [5, 0]).flatten(1).mean(1).tolist() == [5.0, 0.0] and L.flip is False
     remaining, removed = ds.remove_data_by_shapley(L, seed=1, by_class=True)
     assert len(remaining) + len(removed) == 6
+
+
+def test_datamodel_matches_reference(golden_dir):
+    """Bootstrap RidgeCV datamodel (reference src/attributions/methods/datamodel.py:8-36) with the global numpy RNG
+    seeded as in the fixture run of the reference function."""
+    from src.attributions.methods.datamodel import datamodel
+    z = np.load(os.path.join(golden_dir, "datamodel.npz"))
+    np.random.seed(int(z["seed"]))
+    got = datamodel(z["X"], z["y"], 4)
+    assert got.shape == z["coef"].shape == (4, 20)
+    assert np.allclose(got, z["coef"], rtol=1e-9, atol=1e-12)
