@@ -1,6 +1,9 @@
 """Score-tail arithmetic against independent recomputations with the same
 libraries the reference calls (scipy.stats.entropy, scipy sqrtm, scipy ward/fcluster, brute-force torch)."""
+import os
+
 import numpy as np
+import pytest
 import torch
 from scipy.stats import entropy
 
@@ -77,3 +80,28 @@ def test_frechet_eigh_route_matches_sqrtm_route():
     np.testing.assert_allclose(t1[1].numpy(), s1, rtol=1e-10, atol=1e-12)
     got = frechet_distance_torch(t1[0], t1[1], t2[0], t2[1])
     assert abs(got - want) < 1e-7 * max(1.0, abs(want))
+
+
+def test_precision_recall_and_inception_score_match_reference_functions():
+    """tests/golden/scores.npz holds what the reference's own ManifoldBuilder / calc_pr / eval_is returned on CPU
+    (tests/golden/make_scores_golden.py).  The reference takes its distances in native fp16 (torch.cdist on half
+    tensors); here they are accumulated in fp32 and rounded to fp16 once, so radii may differ by one fp16 ulp."""
+    import torch
+    from src.attributions.global_scores.inception_score import inception_score_from_probs
+    from src.attributions.global_scores.precision_recall import calc_pr, make_manifold
+    import sys
+    sys.path.insert(0, os.path.join(os.path.dirname(__file__), "golden"))
+    from make_scores_golden import tiny_classifier
+    z = np.load(os.path.join(os.path.dirname(__file__), "golden", "scores.npz"))
+    m_ref = make_manifold(torch.from_numpy(z["pr_ref"]), 3, 128, 100, "cpu")
+    m_gen = make_manifold(torch.from_numpy(z["pr_gen"]), 3, 128, 100, "cpu")
+    for got, want in ((m_ref.kth, z["kth_ref"]), (m_gen.kth, z["kth_gen"])):
+        rel = np.abs(got.float().numpy() - want) / want
+        assert rel.max() < 2.0 ** -9                                  # <= 2 fp16 ulps
+        assert (rel == 0).mean() > 0.8
+    p, r = calc_pr(m_gen, m_ref, 128, 100, "cpu")
+    assert abs(p - float(z["precision"])) <= 2 / 200 + 1e-9 and abs(r - float(z["recall"])) <= 2 / 300 + 1e-9
+    with torch.no_grad():
+        probs = torch.softmax(tiny_classifier()(torch.from_numpy(z["is_images"])), dim=1).numpy()
+    assert inception_score_from_probs(probs, splits=1) == pytest.approx(float(z["is_splits1"]), rel=1e-6)
+    assert inception_score_from_probs(probs, splits=4) == pytest.approx(float(z["is_splits4"]), rel=1e-6)
