@@ -487,6 +487,37 @@ struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
 };
 
 // ------------------------------------------------------------------------------------
+// Epilogue shared by every contraction kernel: the 2x2-wave block's accumulators (C/D map: col = lane & 31,
+// row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) go to C with alpha, bias[n], rowadd[m / rows_per_group][n] and
+// residual[m][n] fused - or, for a split of a split-K launch (direct = false), raw to the workspace slab.
+// ------------------------------------------------------------------------------------
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc)[TM][TN], int row0, int col0, int wm, int wn,
+                                            int h, int l31, float* C, int ldc, const float* R, bool direct) {
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    if (n >= p.N) continue;
+    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        if (m >= p.M) continue;
+        float v = acc[i][j][e];
+        if (direct) {
+          v = v * p.alpha + bias;
+          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
+          if (R) v += R[(long)m * p.ldr + n];
+        }
+        C[(long)m * ldc + n] = v;
+      }
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------
 // Fragment reads.  K step of 32 = 4 groups of 8; in group g, MFMA step j (0..3) feeds
 // lane half h with k = 8g + 4h + j  (so a KC tile is read as one b128 per group).
 // ------------------------------------------------------------------------------------
@@ -637,27 +668,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
   const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = col0 + wn * (BN / 2) + j * 32 + l31;
-    if (n >= p.N) continue;
-    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e];
-        if (direct) {
-          v = v * p.alpha + bias;
-          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
-          if (R) v += R[(long)m * p.ldr + n];
-        }
-        C[(long)m * ldc + n] = v;
-      }
-    }
-  }
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct);
 }
 
 // ------------------------------------------------------------------------------------
@@ -817,27 +828,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
   float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
   const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = col0 + wn * (BN / 2) + j * 32 + l31;
-    if (n >= p.N) continue;
-    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e];
-        if (direct) {
-          v = v * p.alpha + bias;
-          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
-          if (R) v += R[(long)m * p.ldr + n];
-        }
-        C[(long)m * ldc + n] = v;
-      }
-    }
-  }
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct);
 }
 
 // ------------------------------------------------------------------------------------
@@ -980,26 +971,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     chunk = nchunk;
   }
 
-  float* Cp = p.C;
-  const float* R = p.residual;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = col0 + wn * (BN / 2) + j * 32 + l31;
-    if (n >= p.N) continue;
-    float bias = p.bias ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e] * p.alpha + bias;
-        if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
-        if (R) v += R[(long)m * p.ldr + n];
-        Cp[(long)m * p.ldc + n] = v;
-      }
-    }
-  }
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, p.C, p.ldc, p.residual, true);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1152,27 +1124,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
   const float* R = direct ? p.residual : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-#pragma unroll
-  for (int j = 0; j < TN; ++j) {
-    int n = col0 + wn * (BN / 2) + j * 32 + l31;
-    if (n >= p.N) continue;
-    float bias = (direct && p.bias) ? p.bias[n] : 0.f;
-#pragma unroll
-    for (int i = 0; i < TM; ++i) {
-#pragma unroll
-      for (int e = 0; e < 16; ++e) {
-        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
-        if (m >= p.M) continue;
-        float v = acc[i][j][e];
-        if (direct) {
-          v = v * p.alpha + bias;
-          if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
-          if (R) v += R[(long)m * p.ldr + n];
-        }
-        Cp[(long)m * ldc + n] = v;
-      }
-    }
-  }
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, Cp, ldc, R, direct);
 }
 
 // ------------------------------------------------------------------------------------
