@@ -486,6 +486,14 @@ struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
   __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p, col0, p.N, kend); }
 };
 
+// Workgroup id -> work item, XCD-aware and bijective: hardware deals consecutive workgroup ids round-robin to the 8 XCDs
+// (each with its own L2); this hands every XCD a CONTIGUOUS range of work items, so tiles that share an operand panel
+// (neighbouring tile_n of one tile_m, the halo rows of neighbouring row tiles) meet in one L2.
+__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
+  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
+  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+}
+
 // ------------------------------------------------------------------------------------
 // Epilogue shared by every contraction kernel: the 2x2-wave block's accumulators (C/D map: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) go to C with alpha, bias[n], rowadd[m / rows_per_group][n] and
@@ -541,9 +549,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
 
   // ---- block -> (batch z, split, tile_m, tile_n), XCD-aware (bijective) ----
-  int nwg = gridDim.x, bid = blockIdx.x;
-  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
   int tiles = p.tiles_m * p.tiles_n;
   int zs = t / tiles, rem = t - zs * tiles;
   int tile_m = rem / p.tiles_n, tile_n = rem - tile_m * p.tiles_n;
@@ -738,9 +744,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
   constexpr int B_TILE = BT::ELEMS;
   __shared__ __attribute__((aligned(16))) unsigned short lds[2 * (A_TILE + B_TILE)];
 
-  int nwg = gridDim.x, bid = blockIdx.x;
-  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  int t = (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
   int tiles = p.tiles_m * p.tiles_n;
   int zs = t / tiles, rem = t - zs * tiles;
   int tile_m = rem / p.tiles_n, tile_n = rem - tile_m * p.tiles_n;
@@ -854,9 +858,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
   unsigned short* const patch0 = lds;
   unsigned short* const btile0 = lds + 2 * P_TILE;
 
-  int nwg = gridDim.x, bid = blockIdx.x;
-  int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
   int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
   const int row0 = tile_m * BM, col0 = tile_n * BN;
   // H x W: the conv's input grid as the taps see it (= output grid); with the fused nearest-2x upsample the stored
@@ -1000,9 +1002,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   float* const patch = lds;
   float* const btile0 = lds + NPIX * PLD;
 
-  int nwg = gridDim.x, bid = blockIdx.x;
-  int xcd = bid & 7, qq = nwg >> 3, rr = nwg & 7;
-  int t = (xcd < rr ? xcd * (qq + 1) : rr * (qq + 1) + (xcd - rr) * qq) + (bid >> 3);
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
   // split-K over the 32-channel chunks (small maps: few tiles, long K): split s owns chunks [c_begin, c_end)
   const int tiles = p.tiles_m * p.tiles_n;
   const int split = t / tiles, trem = t - split * tiles;
