@@ -141,10 +141,31 @@ class Attention(nn.Module):
         self.to_v = Linear(channels, inner)
         self.to_out = nn.ModuleList([Linear(inner, channels), nn.Dropout(0.0)])
 
+    def _fused_qkv(self):
+        """[3C, C] weight and [3C] bias of the three projections, concatenated once and reused while the parameters are
+        unchanged (sampling: thousands of forwards on fixed EMA weights)."""
+        ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_q.bias, self.to_k.bias, self.to_v.bias)
+        key = tuple((p.data_ptr(), p._version) for p in ps)
+        if getattr(self, "_qkv_key", None) != key:
+            self._qkv_w = torch.cat([p.detach() for p in ps[:3]], 0).contiguous()
+            self._qkv_b = torch.cat([p.detach() for p in ps[3:]], 0).contiguous()
+            self._qkv_key = key
+        return self._qkv_w, self._qkv_b
+
     def forward(self, x, scale: float = 1.0):
         b, hh, ww, c = x.shape
         res = x.view(b, hh * ww, c)
         h = self.group_norm(x).view(b, hh * ww, c)                   # :1297-1298 (NHWC: no transposes needed)
+        lora = any(l.lora_layer is not None for l in (self.to_q, self.to_k, self.to_v))
+        if (not torch.is_grad_enabled() and not lora and self.to_q.weight.shape[0] == c
+                and not torch.cuda.is_current_stream_capturing()):
+            # sampling: one [3C, C] projection instead of three (h is read once), q/k/v consumed in place.  Not inside a
+            # hipGraph capture: a replayed graph would keep reading the cached copy after the parameters changed.
+            w, bias = self._fused_qkv()
+            qkv = ops.linear_fwd_raw(h.view(b * hh * ww, c), w, bias)
+            o = ops.attention_core_qkv_raw(qkv, b, hh * ww, c, self.heads)
+            o = self.to_out[0](o, residual=res, scale=scale)
+            return o.view(b, hh, ww, c)
         q, k, v = self.to_q(h, scale=scale), self.to_k(h, scale=scale), self.to_v(h, scale=scale)   # :1301-1309
         o = ops.attention_core(q, k, v, self.heads)                   # :1314-1325
         o = self.to_out[0](o, residual=res, scale=scale)              # :1329 + residual :1336-1337

@@ -641,6 +641,22 @@ def attention_core(q, k, v, heads):
     return AttentionCoreFn.apply(q, k, v, heads)
 
 
+def attention_core_qkv_raw(qkv, Bn, T, Cq, heads):
+    """Inference form of AttentionCoreFn on the output of ONE fused projection: qkv is [Bn*T, 3*Cq] (q | k | v along
+    the columns); the two batched contractions read q, k, v in place through their row stride 3*Cq.  Same products in
+    the same K order as the three-projection path, so the result is bit-identical to it.  No autograd."""
+    d = Cq // heads
+    scale = 1.0 / math.sqrt(d)
+    ld = 3 * Cq
+    q, k, v = qkv[:, 0:Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:3 * Cq]        # views: data_ptr = column offset
+    S = torch.empty((Bn, heads, T, T), device=qkv.device, dtype=torch.float32)
+    _attn_gemm(q, k, S, A_KC, B_KC, T, T, d, ld, ld, T, Bn, heads, (T * ld, d), (T * ld, d), (heads * T * T, T * T))
+    check(_capi.load().gad_softmax_fwd(S.data_ptr(), S.data_ptr(), Bn * heads * T, T, scale, _stream()), "gad_softmax_fwd")
+    o = torch.empty((Bn, T, Cq), device=qkv.device, dtype=torch.float32)
+    _attn_gemm(S, v, o, A_KC, B_MC, T, d, T, T, ld, Cq, Bn, heads, (heads * T * T, T * T), (T * ld, d), (T * Cq, d))
+    return o
+
+
 # ----------------------------------------------------------------------------------
 # scheduler / loss / optimizer kernels (no autograd)
 # ----------------------------------------------------------------------------------

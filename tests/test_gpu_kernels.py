@@ -550,3 +550,22 @@ def test_conv_patch_kernel_small_maps(ops, prec):
         want = F.conv2d(_bf16_round(x), _bf16_round(w), b.double(), padding=1) + res.double()
         close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-6 * math.sqrt(Cin * 9))
     assert (got - gen).abs().max().item() < 3e-5
+
+
+def test_attention_fused_qkv_inference_path_is_bit_identical(ops):
+    """no_grad forward of the attention block (one [3C, C] projection, q/k/v read in place) vs the grad-mode forward
+    (three projections); the cached fused weight follows in-place parameter updates."""
+    import gad
+    from gad.nn import Attention
+    torch.manual_seed(0)
+    for C, heads, d, H in ((256, 1, 256, 16), (224, 7, 32, 8)):
+        att = Attention(C, heads, d, 1e-6, 32).to(dev)
+        x = nhwc(rnd(3, C, H, H, seed=C))
+        with torch.no_grad():
+            a = att(x)
+        b = att(x).detach()
+        assert torch.equal(a, b)
+        with torch.no_grad():
+            att.to_k.weight.mul_(1.5)                      # in-place update (optimizer / EMA copy_to): cache must refresh
+            a2 = att(x)
+        assert torch.equal(a2, att(x).detach()) and not torch.equal(a2, a)
