@@ -705,7 +705,13 @@ def sumsq_raw(g, out=None):
     return out
 
 
+# Raw kernels update parameters through device pointers, which torch's per-tensor version counters do not see.  Anything
+# that caches a function of the weights (the fused q|k|v projection of the sampling path) keys on this epoch as well.
+WEIGHT_EPOCH = [0]
+
+
 def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weight_decay, adamw, step, ema_decay):
+    WEIGHT_EPOCH[0] += 1
     a = AdamArgs()
     a.p, a.g, a.m, a.v, a.ema = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema)
     a.n = p.numel()
@@ -717,6 +723,7 @@ def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weigh
 
 
 def ema_update_raw(ema, p, decay: float):
+    WEIGHT_EPOCH[0] += 1
     check(_capi.load().gad_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), decay, _stream()), "gad_ema_update")
 
 

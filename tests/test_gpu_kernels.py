@@ -569,3 +569,16 @@ def test_attention_fused_qkv_inference_path_is_bit_identical(ops):
             att.to_k.weight.mul_(1.5)                      # in-place update (optimizer / EMA copy_to): cache must refresh
             a2 = att(x)
         assert torch.equal(a2, att(x).detach()) and not torch.equal(a2, a)
+    # a raw optimizer kernel writes the parameters through device pointers (no torch version bump): the cache must still refresh
+    att = Attention(256, 1, 256, 1e-6, 32).to(dev)
+    flat, gflat = gad.flatten_params(list(att.parameters()))
+    x = nhwc(rnd(2, 256, 8, 8, seed=9))
+    with torch.no_grad():
+        before = att(x)
+    gflat.fill_(1.0)
+    m, v = torch.zeros_like(flat), torch.zeros_like(flat)
+    ops.clip_adam_ema_raw(flat, gflat, m, v, None, None, max_norm=0.0, lr=1e-2, betas=(0.9, 0.999), eps=1e-8,
+                          weight_decay=0.0, adamw=False, step=1, ema_decay=0.0)
+    with torch.no_grad():
+        after = att(x)
+    assert not torch.equal(before, after) and torch.equal(after, att(x).detach())
