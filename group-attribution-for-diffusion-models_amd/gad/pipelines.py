@@ -29,9 +29,19 @@ class DDPMPipeline:
         self.device = torch.device(device)
         return self
 
-    def _run_steps(self, x, num_inference_steps):
+    def _run_steps(self, x, num_inference_steps, generator=None):
         """x: NHWC device tensor, updated in place through all timesteps."""
         sch = self.scheduler
+        if not isinstance(sch, DDIMScheduler):
+            # any other scheduler with the diffusers step() protocol (DDPMScheduler: ancestral sampling).  Off the
+            # reference's path (its samplers are DDIM); the step sees NCHW views so that its noise draws keep diffusers' order
+            tdev = torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
+            for t in sch.timesteps.tolist():
+                tdev.fill_(t)
+                eps = self.unet.forward_nhwc(x, tdev)
+                nxt = sch.step(eps.permute(0, 3, 1, 2), t, x.permute(0, 3, 1, 2), generator=generator).prev_sample
+                x.copy_(nxt.permute(0, 2, 3, 1))
+            return x
         clip = float(sch.config.clip_sample_range) if sch.config.clip_sample else 0.0
         B = x.shape[0]
         tdev = torch.empty(B, device=x.device, dtype=torch.int64)
@@ -81,7 +91,7 @@ class DDPMPipeline:
             noise = torch.randn(shape, generator=generator, dtype=torch.float32, device=self.device)
         self.scheduler.set_timesteps(num_inference_steps)
         x = ops.nchw_to_nhwc_raw(noise.contiguous())
-        x = self._run_steps(x, num_inference_steps)
+        x = self._run_steps(x, num_inference_steps, generator)
         img = ops.to_image01_raw(x)                               # (x/2+0.5).clamp(0,1); already NHWC
         if output_type == "tensor":
             return SimpleNamespace(images=img)

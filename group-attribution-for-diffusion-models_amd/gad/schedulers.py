@@ -60,6 +60,43 @@ class DDPMScheduler(_Base):
         self._tables(self.config)
         self.timesteps = torch.from_numpy(np.arange(0, num_train_timesteps)[::-1].copy())
 
+    def set_timesteps(self, num_inference_steps, device=None):
+        if num_inference_steps > self.config.num_train_timesteps:
+            raise ValueError("num_inference_steps > num_train_timesteps")
+        self.num_inference_steps = num_inference_steps
+        ratio = self.config.num_train_timesteps // num_inference_steps
+        ts = (np.arange(0, num_inference_steps) * ratio).round()[::-1].copy().astype(np.int64) + self.config.steps_offset
+        self.timesteps = torch.from_numpy(ts)
+
+    def step(self, model_output, timestep, sample, generator=None, return_dict=True):
+        """Ancestral DDPM update (diffusers DDPMScheduler.step, epsilon prediction, variance_type fixed_small / fixed_large):
+        x0 = (x - sqrt(1-abar_t) eps) / sqrt(abar_t), clipped; mean = c0 x0 + c1 x; x_prev = mean + sigma z for t > 0.
+        Off the reference's hot path - its samplers are DDIM (src/diffusion_utils.py:311,406) and this scheduler only
+        supplies add_noise there - so it is plain torch on the tensors' device."""
+        c = self.config
+        if c.prediction_type != "epsilon" or c.thresholding or c.variance_type not in ("fixed_small", "fixed_large"):
+            raise NotImplementedError("DDPMScheduler.step: epsilon prediction with fixed variance only")
+        t = int(timestep)
+        n = self.num_inference_steps or c.num_train_timesteps
+        prev_t = t - c.num_train_timesteps // n
+        ac = self.alphas_cumprod
+        a_t = ac[t].item()
+        a_p = ac[prev_t].item() if prev_t >= 0 else 1.0
+        cur_alpha = a_t / a_p
+        cur_beta = 1.0 - cur_alpha
+        x0 = (sample - (1.0 - a_t) ** 0.5 * model_output) / a_t ** 0.5
+        if c.clip_sample:
+            x0 = x0.clamp(-c.clip_sample_range, c.clip_sample_range)
+        mean = (a_p ** 0.5 * cur_beta / (1.0 - a_t)) * x0 + (cur_alpha ** 0.5 * (1.0 - a_p) / (1.0 - a_t)) * sample
+        if t > 0:
+            var = max((1.0 - a_p) / (1.0 - a_t) * cur_beta, 1e-20) if c.variance_type == "fixed_small" else cur_beta
+            if generator is not None and generator.device.type == "cpu" and sample.is_cuda:
+                z = torch.randn(sample.shape, generator=generator, dtype=sample.dtype).to(sample.device)
+            else:
+                z = torch.randn(sample.shape, generator=generator, dtype=sample.dtype, device=sample.device)
+            mean = mean + var ** 0.5 * z
+        return SimpleNamespace(prev_sample=mean)
+
 
 def min_snr_weights(alphas_cumprod, timesteps, snr_gamma):
     """compute_snr + the epsilon-prediction weights of train_text_to_image_lora.py:1276-1290:

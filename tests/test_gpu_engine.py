@@ -159,3 +159,16 @@ def test_celeba_latent_mode_entry_points(tmp_path, monkeypatch):
     assert len(row["cluster_count"]) == 20 and sum(row["cluster_count"]) == 12
     assert abs(sum(row["cluster_proportions"]) - 1.0) < 1e-9 and 0.0 <= row["entropy"] <= np.log2(20) + 1e-9
     assert "fid_value" not in row and row["trained_steps"] == 2
+
+
+def test_ddpm_pipeline_with_the_ancestral_scheduler():
+    """DDPMPipeline(unet, DDPMScheduler()) - the pipeline object main.py builds (:550-552); the reference only samples
+    through DDIM, this keeps the object usable: images in [0,1], reproducible with a CPU generator."""
+    import gad
+    ucfg, scfg = _cfg()
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**ucfg).to(dev).eval()
+    pipe = gad.DDPMPipeline(net, gad.DDPMScheduler(**scfg))
+    a = pipe(batch_size=2, num_inference_steps=6, output_type="numpy", generator=torch.Generator().manual_seed(3)).images
+    b = pipe(batch_size=2, num_inference_steps=6, output_type="numpy", generator=torch.Generator().manual_seed(3)).images
+    assert a.shape == (2, 32, 32, 3) and np.array_equal(a, b) and 0.0 <= a.min() and a.max() <= 1.0 and np.isfinite(a).all()

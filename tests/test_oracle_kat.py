@@ -100,3 +100,30 @@ def test_pipeline_noise_is_cpu_generator_exact_and_deterministic():
     a = pipe(batch_size=2, generator=torch.Generator().manual_seed(7), num_inference_steps=2).images
     b = pipe(batch_size=2, generator=torch.Generator().manual_seed(7), num_inference_steps=2).images
     assert a.shape == (2, 32, 32, 3) and a.min() >= 0 and a.max() <= 1 and np.array_equal(a, b)
+
+
+def test_ddpm_ancestral_step_closed_form():
+    """DDPMScheduler.step (off the reference's hot path; kept so DDPMPipeline(unet, DDPMScheduler()) works): with eps = the
+    true noise the predicted x0 is exact, the mean follows the posterior q(x_{t-1} | x_t, x_0), the added noise has
+    variance beta_tilde_t, and t = 0 adds none."""
+    import torch
+    import gad
+    sch = gad.DDPMScheduler()
+    torch.manual_seed(0)
+    x0, eps = torch.rand(2, 3, 4, 4) * 1.6 - 0.8, torch.randn(2, 3, 4, 4)
+    for t in (999, 500, 1, 0):
+        a_t = sch.alphas_cumprod[t].double().item()
+        a_p = sch.alphas_cumprod[t - 1].double().item() if t > 0 else 1.0
+        beta = 1 - a_t / a_p
+        xt = a_t ** 0.5 * x0.double() + (1 - a_t) ** 0.5 * eps.double()
+        g = torch.Generator().manual_seed(5)
+        out = sch.step(eps, t, xt.float(), generator=g).prev_sample.double()
+        mean = (a_p ** 0.5 * beta / (1 - a_t)) * x0.double() + ((a_t / a_p) ** 0.5 * (1 - a_p) / (1 - a_t)) * xt
+        if t == 0:
+            assert torch.allclose(out, x0.double(), atol=1e-5)
+        else:
+            z = torch.randn(xt.shape, generator=torch.Generator().manual_seed(5)).double()
+            var = (1 - a_p) / (1 - a_t) * beta
+            assert torch.allclose(out, mean + var ** 0.5 * z, atol=2e-4), t
+    sch.set_timesteps(10)
+    assert sch.timesteps.tolist() == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
