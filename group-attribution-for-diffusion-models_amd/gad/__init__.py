@@ -6,7 +6,7 @@ diffusers for the objects on the hot path."""
 from . import _capi, ops  # noqa: F401
 from .ops import operand_precision, set_operand_precision  # noqa: F401
 from .nn import LoRALinearLayer, UNet2DModel  # noqa: F401
-from .pipelines import DDIMPipeline, DDPMPipeline, StableDiffusionLatentPipeline, sd_simple_loss  # noqa: F401
+from .pipelines import DDIMPipeline, DDPMPipeline, LDMPipeline, StableDiffusionLatentPipeline, sd_simple_loss  # noqa: F401
 from .schedulers import DDIMScheduler, DDPMScheduler  # noqa: F401
 from .training import EMAModel, FusedTrainer, flatten_params, lr_lambda  # noqa: F401
 from . import coalition  # noqa: F401,E402

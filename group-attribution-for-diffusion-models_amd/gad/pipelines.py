@@ -29,6 +29,9 @@ class DDPMPipeline:
         self.device = torch.device(device)
         return self
 
+    def _decode(self, x_nhwc):
+        return x_nhwc
+
     def _run_steps(self, x, num_inference_steps, generator=None):
         """x: NHWC device tensor, updated in place through all timesteps."""
         sch = self.scheduler
@@ -92,6 +95,7 @@ class DDPMPipeline:
         self.scheduler.set_timesteps(num_inference_steps)
         x = ops.nchw_to_nhwc_raw(noise.contiguous())
         x = self._run_steps(x, num_inference_steps, generator)
+        x = self._decode(x)
         img = ops.to_image01_raw(x)                               # (x/2+0.5).clamp(0,1); already NHWC
         if output_type == "tensor":
             return SimpleNamespace(images=img)
@@ -100,6 +104,25 @@ class DDPMPipeline:
             from PIL import Image
             images = [Image.fromarray((im * 255).round().astype("uint8").squeeze()) for im in images]
         return SimpleNamespace(images=images)
+
+
+class LDMPipeline(DDPMPipeline):
+    """diffusers.LDMPipeline as the reference drives it for CelebA-HQ (src/diffusion_utils.py:393-412, unlearn.py:753-765):
+    the same denoising loop on 3x64x64 latents, then `latents / vqvae.config.scaling_factor` through `vqvae.decode` and the
+    usual (x/2+0.5).clamp(0,1).  The VQ-VAE is any module with diffusers' decode protocol (hub-fetched in the reference,
+    `CompVis/ldm-celebahq-256`); with `vqvae=None` - what `--precompute_stage reuse` leaves the reference with
+    (main.py:531-533) - the pipeline returns the latents through the same post-processing."""
+
+    def __init__(self, unet, vqvae=None, scheduler=None):
+        super().__init__(unet, scheduler if scheduler is not None else DDIMScheduler())
+        self.vqvae = vqvae
+
+    def _decode(self, x_nhwc):
+        if self.vqvae is None:
+            return x_nhwc
+        lat = ops.nhwc_to_nchw_raw(x_nhwc) / float(getattr(self.vqvae.config, "scaling_factor", 1.0))
+        img = self.vqvae.decode(lat).sample
+        return ops.nchw_to_nhwc_raw(img.to(torch.float32).contiguous())
 
 
 class DDIMPipeline(DDPMPipeline):

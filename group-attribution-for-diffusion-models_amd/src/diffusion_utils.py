@@ -86,7 +86,9 @@ def build_pipeline(args, model, backend=None):
         if getattr(args, "precompute_stage", None) != "reuse":
             raise NotImplementedError("celeba samples in latent space: pass --precompute_stage reuse (no VQ-VAE weights here)")
         sc = {k: v for k, v in dataset_config("celeba")["scheduler_config"].items() if not k.startswith("_")}
-        pipeline = be.DDPMPipeline(unet=model, scheduler=be.DDIMScheduler(**sc)).to(args.device)
+        pipe_cls = getattr(be, "LDMPipeline", None)
+        pipeline = (pipe_cls(unet=model, vqvae=None, scheduler=be.DDIMScheduler(**sc)) if pipe_cls is not None
+                    else be.DDPMPipeline(unet=model, scheduler=be.DDIMScheduler(**sc))).to(args.device)
         return pipeline, None, None
     pipeline = be.DDPMPipeline(unet=model, scheduler=be.DDIMScheduler()).to(args.device)
     return pipeline, None, None

@@ -172,3 +172,31 @@ def test_ddpm_pipeline_with_the_ancestral_scheduler():
     a = pipe(batch_size=2, num_inference_steps=6, output_type="numpy", generator=torch.Generator().manual_seed(3)).images
     b = pipe(batch_size=2, num_inference_steps=6, output_type="numpy", generator=torch.Generator().manual_seed(3)).images
     assert a.shape == (2, 32, 32, 3) and np.array_equal(a, b) and 0.0 <= a.min() and a.max() <= 1.0 and np.isfinite(a).all()
+
+
+def test_ldm_pipeline_decode_protocol():
+    """LDMPipeline(unet, vqvae, scheduler): latents / scaling_factor -> vqvae.decode(...).sample -> [0,1] images
+    (reference src/diffusion_utils.py:393-412); vqvae=None returns the post-processed latents."""
+    import gad
+    from types import SimpleNamespace
+    ucfg, _ = _cfg()
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**ucfg).to(dev).eval()
+
+    class ToyVQ(torch.nn.Module):                                  # decode protocol only: 2x nearest upsample of scaled latents
+        config = SimpleNamespace(scaling_factor=0.5)
+
+        def decode(self, z):
+            return SimpleNamespace(sample=torch.nn.functional.interpolate(z, scale_factor=2.0, mode="nearest"))
+
+    sch = gad.DDIMScheduler(clip_sample=False)
+    lat = gad.LDMPipeline(net, None, sch)(batch_size=2, num_inference_steps=3, output_type="numpy",
+                                           generator=torch.Generator().manual_seed(1)).images
+    img = gad.LDMPipeline(net, ToyVQ(), sch)(batch_size=2, num_inference_steps=3, output_type="numpy",
+                                            generator=torch.Generator().manual_seed(1)).images
+    assert lat.shape == (2, 32, 32, 3) and img.shape == (2, 64, 64, 3)
+    # decoded = clamp((latent / 0.5) / 2 + 0.5): recover the raw latents where the un-decoded image is not saturated
+    raw = lat * 2 - 1
+    want = np.clip(raw / 0.5 / 2 + 0.5, 0, 1)
+    inside = (lat > 1e-6) & (lat < 1 - 1e-6)
+    assert np.allclose(img[:, ::2, ::2][inside], want[inside], atol=1e-5)
