@@ -64,6 +64,7 @@ struct DevArgs {
   const float* A;
   const float* B;
   float* C;
+  const unsigned short* Bh;   // bf16 copy of B ([N][ldb], k contiguous): bf16 patch conv streams it by LDS-DMA
   const float* A2;   // two-source conv gather (virtual channel concat): channels >= a_split come from A2
   int a_split, ldx2;
   int M, N, K;
@@ -844,15 +845,19 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
 // and the per-step address arithmetic disappears.  Weights stream through a double-buffered [128][32+8] bf16 tile
 // per (chunk, tap) exactly as in gemm_bf16_kernel.  K order = (chunk, tap); fp32 accumulation; same epilogue.
 // ------------------------------------------------------------------------------------
-template <int W, int NI>
-__global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevArgs p) {
+// WB: the weights come as a bf16 copy (cast once per set of weights on the host side): their [128][32] tile is 64-B rows
+// filled by LDS-DMA - 16 rows per wave-instruction, two instructions per wave and step, no registers, no convert, no
+// ds_write - with the four 16-B chunks of a row XOR-swizzled by (row >> 2) & 3 on the source side, so that the 16 rows of a
+// ds_read_b128 phase cover the 64 banks once.
+template <int W, int NI, bool WB>
+__global__ __launch_bounds__(NTHREADS, 3) void conv3x3_patch_bf16_kernel(const DevArgs p) {   // 3 waves / SIMD: <= 168 registers
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
   // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
   // each with its own halo'd sub-patch.
   constexpr int TR = BM / (W * NI), PW = W + 2, PR = TR + 2, NPIX = NI * PR * PW;
   constexpr int PSLOTS = (NPIX * 8 + NTHREADS - 1) / NTHREADS;      // float4 slots per thread per patch
   constexpr int P_TILE = NPIX * LDK;                                 // bf16 elements
-  constexpr int B_TILE = BN * LDK;
+  constexpr int B_TILE = WB ? BN * BK : BN * LDK;
   using BL = BLoader<GAD_B_KC, BN, 4>;
   __shared__ __attribute__((aligned(16))) unsigned short lds[2 * P_TILE + 2 * B_TILE];
   unsigned short* const patch0 = lds;
@@ -907,6 +912,23 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
 #pragma unroll
     for (int i = 0; i < BL::NS; ++i) Bf16Tile<true, BN>::put(tb, i, rb[i]);
   };
+  // WB: DMA of the bf16 weight tile of the step starting at k0 (lane -> row lane/4 of 16, physical chunk lane&3)
+  auto dma_b = [&](int k0, unsigned short* tb) {
+#pragma unroll
+    for (int j = 0; j < 2; ++j) {
+      const int row = j * 64 + wave * 16 + (lane >> 2);
+      const int c = (lane & 3) ^ ((row >> 2) & 3);
+      const bool ok = col0 + row < p.N && k0 < p.K;
+      const unsigned short* src = ok ? p.Bh + (long)(col0 + row) * p.ldb + k0 + c * 8 : (const unsigned short*)g_zero_block;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                       (__attribute__((address_space(3))) void*)(tb + (j * 64 + wave * 16) * BK), 16, 0, 0);
+    }
+  };
+  auto frag_b = [&](const unsigned short* tb, int r0, int ks) -> bf16x8_t {
+    if (!WB) return Bf16Tile<true, BN>::frag(tb, r0, ks, lane);
+    const int row = r0 + l31;
+    return *reinterpret_cast<const bf16x8_t*>(tb + row * BK + (((2 * ks + h) ^ ((row >> 2) & 3)) << 3));
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -929,9 +951,13 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     fetch_slot(i, 0);
     commit_slot(i, patch0);
   }
-  fetch_b(0);
-  commit_b(btile0);
-  __syncthreads();
+  if (WB) dma_b(0, btile0);
+  else {
+    fetch_b(0);
+    commit_b(btile0);
+  }
+  if (WB) barrier_after_dma();
+  else __syncthreads();
 
   const int nsteps = nchunks * 9;
   int chunk = 0, tap = 0;
@@ -942,7 +968,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
     // next step's weights; at the first tap also the next chunk's patch (past the end: zeros / clamped chunk)
     int ntap = tap + 1, nchunk = chunk;
     if (ntap == 9) { ntap = 0; ++nchunk; }
-    fetch_b(st + 1 < nsteps ? ntap * C + nchunk * BK : p.K);
+    const int knext = st + 1 < nsteps ? ntap * C + nchunk * BK : p.K;
+    if (WB) dma_b(knext, nb);
+    else fetch_b(knext);
     unsigned short* const pnext = patch0 + ((chunk + 1) & 1) * P_TILE;
     const int cnext = chunk + 1 < nchunks ? chunk + 1 : chunk;
 #pragma unroll
@@ -959,16 +987,17 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_bf16_kernel(const DevA
 #pragma unroll
       for (int i = 0; i < TM; ++i) fa[i] = *reinterpret_cast<const bf16x8_t*>(pa + abase[i] + tshift + ks * 16);
 #pragma unroll
-      for (int j = 0; j < TN; ++j) fb[j] = Bf16Tile<true, BN>::frag(lb, wn * (BN / 2) + j * 32, ks, lane);
+      for (int j = 0; j < TN; ++j) fb[j] = frag_b(lb, wn * (BN / 2) + j * 32, ks);
 #pragma unroll
       for (int i = 0; i < TM; ++i)
 #pragma unroll
         for (int j = 0; j < TN; ++j)
           acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(fa[i], fb[j], acc[i][j], 0, 0, 0);
     }
-    commit_b(nb);
+    if (!WB) commit_b(nb);
     if (PSLOTS == 9 && tap == 8) commit_slot(8, pnext);   // a ninth slot (W = 64) has no next tap to ride on
-    __syncthreads();
+    if (WB) barrier_after_dma();
+  else __syncthreads();
     tap = ntap;
     chunk = nchunk;
   }
@@ -1540,6 +1569,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
   d.A2 = a->A2; d.a_split = a->a_split; d.ldx2 = a->ldx2;
+  d.Bh = nullptr;
   d.M = a->M; d.N = a->N; d.K = a->K;
   d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
   d.batch_inner = a->batch_inner > 0 ? a->batch_inner : 1;
@@ -1589,11 +1619,20 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     d.tiles_n = (int)gad_ceil_div(a->N, 128);
     d.splitk = 1;
     dim3 grid((unsigned)(d.tiles_m * d.tiles_n)), block(NTHREADS);
-    if (a->g.Wo == 64) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<64, 1>), grid, block, 0, st, d);
-    else if (a->g.Wo == 32) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<32, 1>), grid, block, 0, st, d);
-    else if (a->g.Wo == 16) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<16, 1>), grid, block, 0, st, d);
-    else if (a->g.Wo == 8) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<8, 2>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<4, 8>), grid, block, 0, st, d);
+    const bool wb = a->B_bf16 != nullptr;
+    if (wb) GAD_CHECK(gad_aligned16(a->B_bf16) && a->ldb % 8 == 0, "gad_gemm: B_bf16 must be 16-byte aligned with ldb %% 8 == 0");
+    d.Bh = (const unsigned short*)a->B_bf16;
+#define GAD_PATCH_BF16(W_, NI_)                                                                           \
+    do {                                                                                                  \
+      if (wb) hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<W_, NI_, true>), grid, block, 0, st, d);      \
+      else hipLaunchKernelGGL((conv3x3_patch_bf16_kernel<W_, NI_, false>), grid, block, 0, st, d);        \
+    } while (0)
+    if (a->g.Wo == 64) GAD_PATCH_BF16(64, 1);
+    else if (a->g.Wo == 32) GAD_PATCH_BF16(32, 1);
+    else if (a->g.Wo == 16) GAD_PATCH_BF16(16, 1);
+    else if (a->g.Wo == 8) GAD_PATCH_BF16(8, 2);
+    else GAD_PATCH_BF16(4, 8);
+#undef GAD_PATCH_BF16
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch)");
     return 0;
   }

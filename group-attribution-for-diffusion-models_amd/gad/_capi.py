@@ -34,7 +34,7 @@ class GemmArgs(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int32),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32),
-                ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32)]
+                ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p)]
 
 
 class GroupNormArgs(C.Structure):

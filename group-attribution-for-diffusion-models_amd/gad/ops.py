@@ -140,7 +140,7 @@ def set_operand_precision(name):
 
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -164,6 +164,8 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.operand_precision = OPERAND_PRECISION[0]
     if A2 is not None:
         a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]
+    if B_bf16 is not None:
+        a.B_bf16 = B_bf16.data_ptr()
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -246,8 +248,22 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
         _req(residual, "conv residual")
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
-             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1)
+             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
+             B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and not torch.is_grad_enabled()
+                                       and Cin % 32 == 0 and not torch.cuda.is_current_stream_capturing()) else None)
     return y
+
+
+def bf16_weight(w):
+    """bf16 (RNE) copy of a conv weight in its [Cout][KH][KW][Cin] storage, cached on the parameter until it changes
+    (torch version counter, or the epoch the raw optimizer kernels bump).  Inference only: the bf16-mode patch
+    convolution streams it by LDS-DMA instead of rounding the fp32 weights in every workgroup."""
+    key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+    cached = getattr(w, "_gad_bf16", None)
+    if cached is None or cached[0] != key:
+        cached = (key, weight_krsc(w).detach().to(torch.bfloat16).contiguous())
+        w._gad_bf16 = cached
+    return cached[1]
 
 
 def two_source_ok(c1: int, c2: int) -> bool:

@@ -94,6 +94,10 @@ typedef struct gad_gemm_args {
    * A2 == NULL: single source.  a_split must be a multiple of 32. */
   const float* A2;
   int32_t a_split, ldx2;
+  /* optional bf16 copy of B (same [N][ldb] layout, k contiguous, RNE-rounded; 16-B aligned, ldb % 8 == 0): with
+   * operand_precision = 1 the LDS-patch convolution streams it by LDS-DMA instead of converting the fp32 weights in every
+   * workgroup.  Ignored by every other kernel. */
+  const void* B_bf16;
 } gad_gemm_args;
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);

@@ -27,7 +27,7 @@ def test_every_declared_symbol_is_exported_and_bound():
 def test_struct_layout_matches_header():
     # sizes computed from the C declaration (LP64): guards against a field drifting between gad.h and _capi.py
     assert ctypes.sizeof(_capi.ConvGeom) == 12 * 4
-    assert ctypes.sizeof(_capi.GemmArgs) == 3 * 8 + 10 * 4 + 6 * 8 + 48 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 4 + 4   # ... hints, operand_precision, pad, A2, a_split, ldx2
+    assert ctypes.sizeof(_capi.GemmArgs) == 3 * 8 + 10 * 4 + 6 * 8 + 48 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 4 + 4 + 8   # ... hints, operand_precision, pad, A2, a_split, ldx2, B_bf16
     assert ctypes.sizeof(_capi.GroupNormArgs) == 9 * 8 + 4 * 4 + 4 + 4 + 8 + 8 + 8 + 4 + 4   # ... x2, C1, tail pad
     assert ctypes.sizeof(_capi.AdamArgs) == 5 * 8 + 8 + 8 + 4 + 5 * 4 + 4 + 4 + 4 + 4
 

@@ -404,6 +404,18 @@ def test_conv_fwd_bf16_operands(ops, case, tile):
                                  residual=nhwc(res), tile_hint=tile)
     K = c["Cin"] * c["k"] ** 2
     close(got.permute(0, 3, 1, 2), want, rtol=1e-5, atol=2e-6 * math.sqrt(K))
+    # inference (no_grad): the weights come from a cached bf16 copy streamed by LDS-DMA - the same roundings and products
+    with torch.no_grad(), ops.operand_precision("bf16"):
+        wg = cl_weight(w)
+        got_ng = ops.conv2d_fwd_raw(nhwc(x), wg, b.to(dev), c["stride"], c["pad"], c["ups"], rowadd=temb.to(dev),
+                                    residual=nhwc(res), tile_hint=tile)
+        assert torch.equal(got_ng, got)
+        if c["k"] == 3 and c["Cin"] % 32 == 0:
+            assert wg._gad_bf16[1].dtype == torch.bfloat16
+            wg.mul_(2.0)                                       # in-place change -> the cached copy is rebuilt
+            got2 = ops.conv2d_fwd_raw(nhwc(x), wg, None, c["stride"], c["pad"], c["ups"], tile_hint=tile)
+            ref2 = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w * 2), None, c["stride"], c["pad"], c["ups"], tile_hint=tile)
+            assert torch.equal(got2, ref2)
     # and it is a different result from the fp32-operand kernel by about bf16 rounding, not more
     exact = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), c["stride"], c["pad"], c["ups"], rowadd=temb.to(dev),
                                residual=nhwc(res), tile_hint=tile)

@@ -39,11 +39,11 @@ def main():
             pad = (1, 1, 1, 1) if k == 3 else (0, 0, 0, 0)
             fl = 2.0 * B * H * H * Cout * Cin * k * k
             res = []
-            for prec in ("f32", "bf16"):
-                for tile in (1, 2):
-                    with ops.operand_precision(prec):
-                        ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b, 1, pad, False, tile_hint=tile))
-                    res.append(f"{prec} t{tile}: {fl/ms/1e9:6.0f} TF/s ({ms*1e3:6.0f} us)")
+            for prec, tile, ng in (("f32", 1, True), ("bf16", 1, False), ("bf16", 1, True), ("bf16", 2, True)):
+                with ops.operand_precision(prec), torch.set_grad_enabled(not ng):
+                    ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b, 1, pad, False, tile_hint=tile))
+                tag = f"{prec} t{tile}" + (" (bf16 weight copy)" if prec == "bf16" and ng and tile == 1 else "")
+                res.append(f"{tag}: {fl/ms/1e9:6.0f} TF/s ({ms*1e3:6.0f} us)")
             print(f"conv B={B} {Cin}->{Cout}@{H} k{k}: " + " | ".join(res), flush=True)
     if which in ("all", "unet"):
         from src.ddpm_config import DDPMConfig
