@@ -73,7 +73,8 @@ class FusedSampler:
     one U-Net launch: every reference batch b of `batch_size` images still draws its initial noise
     from ``torch.Generator().manual_seed(b)`` on the host (bit-identical noise), but `fuse` of them
     are stacked along N so the contraction kernels see M = fuse*batch_size*H*W rows.  The U-Net
-    has no cross-sample op (GroupNorm and attention are per sample), so results are unchanged."""
+    has no cross-sample op (GroupNorm and attention are per sample), so every sample sees the same arithmetic (up to
+    the fp32 summation order of the tile / split plan picked for the launch width)."""
 
     def __init__(self, unet: UNet2DModel, scheduler: DDIMScheduler, batch_size=32, fuse=32):
         self.unet, self.sch, self.bs, self.fuse = unet, scheduler, batch_size, fuse
