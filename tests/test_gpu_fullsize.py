@@ -174,3 +174,39 @@ def test_whole_model_is_kernel_family_invariant():
     assert (y0 - y1).abs().max().item() < 1e-4 * max(1.0, y1.abs().max().item())
     assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1
     assert (w0 - w1).abs().max().item() < 2e-6            # one Adam step of lr 1e-4: updates are +-1e-4, signs must agree
+
+
+def test_full_width_training_step_matches_cpu_oracle():
+    """The full CIFAR U-Net at the training batch (B=128: the LDS-patch forward / dgrad / wgrad kernels are the ones that
+    run) against the CPU oracle's training step on the same weights, batch, noise and timesteps: loss, gradient norm,
+    updated weights and EMA."""
+    import gad
+    from oracle import diffusers_ref as R
+    from src.ddpm_config import DDPMConfig
+    cfg = DDPMConfig.cifar100_config
+    torch.manual_seed(0)
+    ref = R.UNet2DModel(**cfg["unet_config"])
+    net = gad.UNet2DModel(**cfg["unet_config"])
+    net.load_state_dict(ref.state_dict())
+    net.to(dev)
+    opt = torch.optim.Adam(ref.parameters(), lr=1e-4)
+    ema_r, ema_g = R.EMAModel(ref.parameters()), gad.EMAModel(net.parameters())
+    for e in (ema_r, ema_g):
+        e.optimization_step = 5000
+    tr = gad.FusedTrainer(net, gad.DDPMScheduler(**cfg["scheduler_config"]), ema_g, lr=1e-4)
+    sch = R.DDPMScheduler(**cfg["scheduler_config"])
+    g = torch.Generator().manual_seed(1)
+    x, n = torch.rand(128, 3, 32, 32, generator=g) * 2 - 1, torch.randn(128, 3, 32, 32, generator=g)
+    t = R.antithetic_timesteps(torch.randint(0, 1000, (65,), generator=g), 1000, 128)
+    loss_r, gn_r = R.train_step(ref, opt, ema_r, sch, x, n, t)
+    loss_g = tr.step(x.to(dev), n.to(dev), t.to(dev))
+    assert abs(loss_g.item() - loss_r.item()) < 1e-4 * abs(loss_r.item())
+    assert abs(tr.grad_norm().item() - gn_r.item()) < 2e-3 * gn_r.item()
+    worst = 0.0
+    for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
+        worst = max(worst, (a.cpu() - b).abs().max().item())
+    assert worst < 2.5e-4, worst          # one Adam step moves every weight by ~lr = 1e-4; a sign flip of a ~0 gradient costs 2e-4
+    agree = [torch.isclose(a.cpu(), b, atol=2e-5).float().mean().item() for a, b in zip(net.state_dict().values(), ref.state_dict().values())]
+    assert min(agree) > 0.98
+    for a, b in zip(ema_g.shadow_params, ema_r.shadow_params):
+        assert torch.allclose(a.cpu(), b, atol=2e-6)
