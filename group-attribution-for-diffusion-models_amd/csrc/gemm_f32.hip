@@ -850,7 +850,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
 // ds_write - with the four 16-B chunks of a row XOR-swizzled by (row >> 2) & 3 on the source side, so that the 16 rows of a
 // ds_read_b128 phase cover the 64 banks once.
 template <int W, int NI, bool WB>
-__global__ __launch_bounds__(NTHREADS, 3) void conv3x3_patch_bf16_kernel(const DevArgs p) {   // 3 waves / SIMD: <= 168 registers
+__global__ __launch_bounds__(NTHREADS, (W == 64 || NI == 8) ? 2 : 3) void conv3x3_patch_bf16_kernel(const DevArgs p) {   // 3 waves / SIMD (<= 168 registers) where LDS allows 3 workgroups
   constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
   // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
   // each with its own halo'd sub-patch.
@@ -1161,7 +1161,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 //   dW[co][tap][ci] = sum_pixels dy[pix][co] * x[pix + tap shift][ci]
 // A workgroup owns 128 output channels x one 32-channel input chunk x ALL nine taps (a 128 x 288 slab of dW, 9
 // accumulator tiles per wave) and a range of pixels.  A K step is 32 consecutive pixels (one row at W = 32, two rows at
-// W = 16): the dy tile [32 px][128 co] and the halo'd x rows [(rows+2)(W+2) px][32 ci] arrive by LDS-DMA; the nine taps
+// W = 16, four at W = 8 - always inside one image): the dy tile [32 px][128 co] and the halo'd x rows [(rows+2)(W+2) px][32 ci] arrive by LDS-DMA; the nine taps
 // read their B fragments (lane = ci, the two lane halves = two adjacent pixels) from the same patch rows at shifted
 // pixel offsets, and one dy fragment (lane = co) feeds nine MFMAs.  Per 2.36 MFLOP the step stages 29 KB (the im2col
 // kernel: 32 KB per 1.05 MFLOP) and computes no im2col addresses.  Partial slabs of the pixel splits go to the
@@ -1456,7 +1456,7 @@ static int wgrad_patch_splits(const gad_gemm_args* a) {
   if (use_bf16(a) || pick_vec(a) != 4 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV) return 0;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return 0;
   if (g.Ho != (g.upsample ? 2 * g.H : g.H) || g.Wo != (g.upsample ? 2 * g.W : g.W)) return 0;
-  if (!(g.Wo == 32 || g.Wo == 16) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
+  if (!(g.Wo == 32 || g.Wo == 16 || g.Wo == 8) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
   if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
   if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
   const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, 128) * (g.C / BK);
@@ -1604,7 +1604,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     }
     dim3 grid((unsigned)(d.splitk * d.tiles_m * (a->g.C / BK))), block(NTHREADS);
     if (a->g.Wo == 32) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<32>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
+    else if (a->g.Wo == 16) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
+    else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<8>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(wgrad3x3 patch)");
     if (d.splitk > 1) {
       long total = (long)a->M * a->N;
