@@ -268,6 +268,9 @@ def main():
         # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU
         # (empirical_verification.ipynb:128,132) -> per-GPU ratio
         out["vs_baseline"] = value / world / 3.27 if a.precision == "f32" else None   # the published figure is fp32
+        if a.gd_steps != GD_STEPS or a.n_samples != N_SAMPLES:                          # a reduced workload is not the metric
+            out["config"]["workload"] += f" -- OVERRIDDEN: gd_steps={a.gd_steps}, n_samples={a.n_samples} (not the BASELINE workload)"
+            out["vs_baseline"] = None
         if not a.full_coalition:
             train_flop = 3 * UNET_GFLOP_PER_IMG * 1e9 * TRAIN_B
             samp_flop = UNET_GFLOP_PER_IMG * 1e9 * N_SAMPLES * DDIM_STEPS / GD_STEPS
