@@ -23,6 +23,14 @@
 //     scalar path (VEC = 1) into the same LDS image;
 //   * 1-D grid with an XCD-aware bijective remap so that tiles sharing an A panel sit
 //     on one XCD's L2; split-K through a caller-owned workspace + deterministic reduce.
+//
+// Kernel families in this file (gad_gemm picks one from the shapes; gad_gemm_kernel_id reports it):
+//   gemm_kernel                 the generic engine described above (all six operand-layout pairs)
+//   conv3x3_patch_f32_kernel    3x3 / stride 1 / pad 1 forward and data gradient with the input patch resident in LDS
+//   wgrad3x3_patch_f32_kernel   the matching weight gradient (128 x 288 slab of dW per workgroup)
+//   gemm_bf16_kernel            the generic engine with bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
+//   conv3x3_patch_bf16_kernel   the patch convolution with bf16 operands (optionally a bf16 weight copy by LDS-DMA)
+//   splitk_reduce_kernel        deterministic reduction + fused epilogue of any split launch
 #include <stdlib.h>
 
 #include "gad_common.h"
