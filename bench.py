@@ -28,12 +28,13 @@ for p in (os.path.join(ROOT, "group-attribution-for-diffusion-models_amd"), ROOT
         sys.path.insert(0, p)
 os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
 
-import torch  # noqa: E402
-
 GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128, 32, 32
 UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
 BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+
+
+torch = None       # imported in main(): the launcher parent of `--gpus N` must not import it
 
 
 def log(msg):
@@ -56,7 +57,27 @@ def parse():
                     help="skip the separate U-Net steps/s measurement (PMC passes: keeps the launch mix = the timed region's)")
     ap.add_argument("--gd-steps", type=int, default=GD_STEPS)
     ap.add_argument("--n-samples", type=int, default=N_SAMPLES)
+    ap.add_argument("--stub", action="store_true",
+                    help="CPU rehearsal of the launcher / process group / final all_gather with a stub engine over gloo "
+                         "(tests only: the line is marked \"stub\": true and is not a measurement)")
     return ap.parse_args()
+
+
+def launch_ranks(a) -> int:
+    """`python bench.py --gpus N` with no WORLD_SIZE in the environment: this process becomes the launcher.  It starts
+    N fresh children (one per GPU: RANK = LOCAL_RANK = r, WORLD_SIZE = N, MASTER_ADDR = 127.0.0.1) BEFORE anything
+    touches the GPU - it imports neither torch nor the package - waits for them and returns the worst exit code.
+    Rank 0's child prints the JSON line on the inherited stdout."""
+    import importlib.util
+    spec = importlib.util.spec_from_file_location(
+        "_gad_launch", os.path.join(ROOT, "group-attribution-for-diffusion-models_amd", "gad", "launch.py"))
+    launch = importlib.util.module_from_spec(spec)
+    spec.loader.exec_module(launch)                     # stdlib only: no torch, no HIP
+    log(f"launcher: starting {a.gpus} ranks (one per GPU)")
+    codes = launch.spawn_workers([sys.executable, os.path.abspath(__file__)] + sys.argv[1:], a.gpus)
+    if any(codes):
+        log(f"launcher: rank exit codes {codes}")
+    return max(abs(c) for c in codes)
 
 
 class SliceRunner:
@@ -101,12 +122,12 @@ class SliceRunner:
         ts = self.antithetic(self.n_t, image.shape[0], self.dev)
         return self.trainer.step(image, noise, ts)
 
-    @torch.no_grad()
     def sampler_step(self):
         ops, sch = self.ops, self.engine.sample_scheduler
         t = self.ts[self.ti]
         self.t.fill_(t)
-        eps = self.smodel.forward_nhwc(self.x, self.t)
+        with torch.no_grad():
+            eps = self.smodel.forward_nhwc(self.x, self.t)
         a_t, a_p = sch.step_coefficients(t)
         ops.ddim_step_raw(self.x, eps, a_t, a_p, 1.0, out=self.x)
         self.ti += 1
@@ -167,17 +188,75 @@ def cpu_baseline(engine):
             "train_s_per_image": t_train_img, "sampler_s_per_image": t_fwd_img}
 
 
+def stub_rank(a, rank, world):
+    """--stub: the N-rank path on CPU (gloo) with the engine's GPU work replaced by a deterministic function of the
+    seed: launcher, rendezvous, barrier-bracketed timing, run_sharded's final all_gather and the JSON contract are the
+    product's.  Not a measurement."""
+    import torch.distributed as dist
+    from gad.coalition import CoalitionRecord, run_sharded
+
+    class StubEngine:
+        n_groups, device = 20, torch.device("cpu")
+
+        def run_coalition(self, seed, verbose=False):
+            time.sleep(0.01)
+            return CoalitionRecord(seed, 100 - seed, seed, 10.0 + 0.5 * seed, 0.1, 0.01, 0.01, 1, [seed % 20])
+
+        def jsonl_row(self, rec):
+            return dict(removal_seed=rec.removal_seed, fid_value=rec.fid_value)
+
+    if world > 1:
+        dist.barrier()
+    t0 = time.time()
+    recs = run_sharded(StubEngine(), list(range(a.steps * world)), db_path=os.environ.get("GAD_STUB_DB"))
+    if world > 1:
+        dist.barrier()
+    dt = time.time() - t0
+    seen = [0]
+    if world > 1:
+        ids = [torch.zeros(1, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank]))
+        seen = sorted(int(i.item()) for i in ids)
+    if rank == 0:
+        print(json.dumps({"metric": "shapley_coalitions_per_hour", "value": len(recs) / (dt / 3600.0), "unit": "coalitions/hour",
+                          "n_gpus": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
+                          "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak",
+                          "vs_baseline": None, "dtype": "none", "data": "stub", "stub": True,
+                          "ranks_seen": seen, "records_gathered": sorted(r.removal_seed for r in recs),
+                          "config": {"workload": "STUB engine (CPU / gloo rehearsal of the N-rank path): not a measurement"}}),
+              flush=True)
+    if world > 1:
+        dist.destroy_process_group()
+
+
 def main():
     a = parse()
+    if "WORLD_SIZE" not in os.environ and a.gpus > 1:
+        sys.exit(launch_ranks(a))                                      # parent: never touches the GPU
     world = int(os.environ.get("WORLD_SIZE", "1"))
     rank = int(os.environ.get("RANK", "0"))
     local = int(os.environ.get("LOCAL_RANK", "0"))
+    if world != a.gpus:                                                # never silently benchmark a different N
+        print(f"bench.py: --gpus {a.gpus} but WORLD_SIZE={world}: launch N ranks with --gpus N (torch.distributed.run "
+              f"--nproc-per-node N, or plain `python bench.py --gpus N`)", file=sys.stderr)
+        sys.exit(2)
+    global torch
+    import torch
     import torch.distributed as dist
-    backend = os.environ.get("GAD_DIST_BACKEND", "nccl")          # "gloo" only to rehearse the N>1 path on one GPU
-    if os.environ.get("GAD_SHARE_GPU0"):
-        local = 0
+    backend = os.environ.get("GAD_DIST_BACKEND", "gloo" if a.stub else "nccl")   # "gloo" only to rehearse the N>1 path
     if world > 1:
         os.environ.setdefault("MASTER_ADDR", "127.0.0.1")
+    if a.stub:
+        if world > 1:
+            dist.init_process_group(backend)
+        return stub_rank(a, rank, world)
+    if os.environ.get("GAD_SHARE_GPU0"):
+        local = 0
+    elif local >= torch.cuda.device_count():
+        print(f"bench.py: rank {rank} wants cuda:{local} but only {torch.cuda.device_count()} GPUs are visible",
+              file=sys.stderr)
+        sys.exit(2)
+    if world > 1:
         torch.cuda.set_device(local)
         if backend == "nccl":
             dist.init_process_group("nccl", device_id=torch.device(f"cuda:{local}"))
@@ -243,6 +322,9 @@ def main():
         cdev = dev if backend == "nccl" else torch.device("cpu")
         packed = gather_records([r.pack(engine.n_groups) for r in recs], CoalitionRecord.NSCALAR + engine.n_groups, cdev)
         assert len(packed) == world * len(recs)
+        ids = [torch.zeros(1, device=cdev, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], device=cdev, dtype=torch.int64))     # device all_gather of the rank ids
+        ranks_seen = sorted(int(i.item()) for i in ids)
         tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
@@ -254,7 +336,8 @@ def main():
 
     if rank == 0:
         out = {
-            "metric": "shapley_coalitions_per_hour", "value": value, "unit": "coalitions/hour", "n_gpus": world,
+            "metric": "shapley_coalitions_per_hour", "value": value, "unit": "coalitions/hour",
+            "n_gpus": dist.get_world_size() if world > 1 else 1,
             "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
             "scaling": "weak", "vs_baseline": None,
             "dtype": "f32" if a.precision == "f32" else "bf16 operands, f32 accumulate/storage (NOT the reference default)",
@@ -265,6 +348,9 @@ def main():
                                        "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024")),
                        "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"},
         }
+        if world > 1:
+            out["rccl_ranks_seen"] = ranks_seen                       # from the collective, not from the flag
+            out["dist_backend"] = dist.get_backend()
         # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU
         # (empirical_verification.ipynb:128,132) -> per-GPU ratio
         out["vs_baseline"] = value / world / 3.27 if a.precision == "f32" else None   # the published figure is fp32

@@ -303,31 +303,160 @@ def gather_records(local: List[torch.Tensor], width: int, device, group=None) ->
     return sorted(out, key=lambda v: v[0].item())
 
 
-def run_sharded(engine: CoalitionEngine, seeds: Sequence[int], db_path: Optional[str] = None, verbose=False):
-    """Run `seeds` across the ranks of the default process group (or alone) and, on rank 0, append the
-    merged rows to the jsonl db in seed order.  Seeds already present in the db are skipped
-    (idempotent re-entry, setup_unlearn_commands.py:133-154)."""
+def _rank_shard(db_path: str, rank: int) -> str:
+    return f"{db_path}.rank{rank}"
+
+
+def _read_rows(path: str) -> List[dict]:
+    rows = []
+    if os.path.exists(path):
+        with open(path) as f:
+            for line in f:
+                line = line.strip()
+                if not line:
+                    continue
+                try:
+                    row = json.loads(line)
+                    int(row["removal_seed"])
+                except (ValueError, KeyError, TypeError):      # a torn last line of a killed writer: the seed is simply redone
+                    continue
+                rows.append(row)
+    return rows
+
+
+def _append_row(path: str, row: dict):
+    """One finished coalition = one durable line (the reference's `open(args.db, "a+")` per job, unlearn.py:960-968)."""
+    with open(path, "a+") as f:
+        f.write(json.dumps(row, default=str) + "\n")
+        f.flush()
+        os.fsync(f.fileno())
+
+
+def _shard_paths(db_path: str) -> List[str]:
+    import glob
+    return sorted(glob.glob(glob.escape(db_path) + ".rank*[0-9]"))
+
+
+def finished_seeds(db_path: Optional[str]) -> set:
+    """Seeds with a row in the db or in any rank's shard (shards of a run that died before its merge count)."""
+    done = set()
+    if db_path:
+        for path in [db_path] + _shard_paths(db_path):
+            done.update(int(r["removal_seed"]) for r in _read_rows(path))
+    return done
+
+
+def merge_shards(db_path: str, extra_rows: Sequence[dict] = ()) -> List[int]:
+    """Rank 0's consolidation: rows of `extra_rows` (records that arrived through the all_gather) and of every
+    rank shard that are not in the db yet are appended in seed order; then the shards are removed.  Returns the
+    seeds appended."""
+    have = {int(r["removal_seed"]) for r in _read_rows(db_path)}
+    new = {}
+    for path in _shard_paths(db_path):
+        for r in _read_rows(path):
+            new.setdefault(int(r["removal_seed"]), r)
+    for r in extra_rows:                                   # gathered records win: they are this run's data path
+        new[int(r["removal_seed"])] = r
+    seeds = sorted(s for s in new if s not in have)
+    for s in seeds:
+        _append_row(db_path, new[s])
+    for path in _shard_paths(db_path):
+        os.remove(path)
+    return seeds
+
+
+def _wait_for_ranks(db_path: Optional[str], tag: str, timeout_s: float) -> List[int]:
+    """Rendezvous ahead of the final collective that cannot hang on a dead rank: every rank posts a key in the
+    process group's store; a rank the launcher has declared dead (tombstone file `<db>.rank<r>.dead`, written by
+    gad.launch when a child exits non-zero) is not waited for.  Returns the ranks that did NOT arrive (empty = all
+    alive, the collective is safe)."""
+    import torch.distributed as dist
+    from datetime import timedelta
+
+    rank, world = dist.get_rank(), dist.get_world_size()
+    store = dist.distributed_c10d._get_default_store()
+    store.set(f"gad/{tag}/{rank}", "1")
+    missing = []
+    t0 = time.time()
+    for r in range(world):
+        key = f"gad/{tag}/{r}"
+        while True:
+            try:
+                store.wait([key], timedelta(seconds=0.5))
+                break
+            except Exception:                                  # not there yet (timeout) - dead, or still working?
+                dead = bool(db_path) and os.path.exists(f"{_rank_shard(db_path, r)}.dead")
+                if dead or time.time() - t0 > timeout_s:
+                    missing.append(r)
+                    break
+    return missing
+
+
+def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, verbose=False, retries: int = 1,
+                rendezvous_timeout_s: Optional[float] = None):
+    """The one-coalition-per-GPU scheduler that replaces the reference's SLURM job array
+    (text_to_image/experiments/setup_unlearn_commands.py:133-154,160-214; unlearn.job:15,17 `--requeue`,
+    `--open-mode=append`).
+
+    * rank r of the default process group (or a lone process) owns the seeds with ``seed % world == r`` that have no
+      row yet - neither in the db nor in any rank's shard (idempotent re-entry);
+    * every finished coalition is appended at once, flushed and fsynced, to this rank's shard ``<db>.rank<r>``: a
+      fault, OOM or kill on any rank loses at most the coalition that rank was running;
+    * a coalition that raises is recorded in ``<db>.failed`` (seed, rank, error, traceback) and retried `retries`
+      times after the rank's other seeds, with freshly built model / optimizer state (run_coalition builds them per
+      call); what still fails is left for the next entry (a requeued launch);
+    * the only data-path collective is one all_gather of the fixed-size records at the end, entered only when every
+      rank is known to have arrived (`_wait_for_ranks`); rank 0 then appends the rows to the db in seed order and
+      removes the shards.  If a rank is missing, the survivors skip the collective and rank 0 merges from the shards.
+    Returns the records every rank knows at the end (all of this run's when the gather ran, else its own)."""
+    import traceback
     import torch.distributed as dist
 
     dist_on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
-    done = set()
-    if db_path and os.path.exists(db_path):
-        with open(db_path) as f:
-            for line in f:
-                try:
-                    done.add(int(json.loads(line)["removal_seed"]))
-                except (ValueError, KeyError):
-                    pass
+    done = finished_seeds(db_path)
     mine = shard_seeds([s for s in seeds if s not in done], rank, world)
-    recs = [engine.run_coalition(s, verbose=verbose) for s in mine]
+    shard = _rank_shard(db_path, rank) if db_path else None
+    recs, failed = [], []
+    todo, attempt = list(mine), 0
+    while todo:
+        again = []
+        for s in todo:
+            try:
+                rec = engine.run_coalition(s, verbose=verbose)
+            except Exception as e:                               # this coalition only; the rank carries on
+                if db_path:
+                    _append_row(db_path + ".failed", dict(removal_seed=s, rank=rank, attempt=attempt, error=repr(e),
+                                                          traceback=traceback.format_exc()))
+                if verbose:
+                    print(f"[rank {rank}] coalition {s} failed (attempt {attempt}): {e!r}", flush=True)
+                again.append(s)
+                continue
+            recs.append(rec)
+            if shard:
+                _append_row(shard, engine.jsonl_row(rec))
+        attempt += 1
+        todo = again if attempt <= retries else []
+        failed = again
     width = CoalitionRecord.NSCALAR + engine.n_groups
     packed = [r.pack(engine.n_groups) for r in recs]
+    gathered = True
     if dist_on:
-        packed = gather_records(packed, width, engine.device if dist.get_backend() == "nccl" else "cpu")
+        timeout = rendezvous_timeout_s if rendezvous_timeout_s is not None else float(os.environ.get("GAD_SHARD_TIMEOUT", 24 * 3600))
+        _RDV[0] += 1
+        missing = _wait_for_ranks(db_path, f"sharded{_RDV[0]}", timeout)
+        if missing:
+            gathered = False
+            print(f"[rank {rank}] ranks {missing} did not reach the final all_gather: merging from the rank shards",
+                  flush=True)
+        else:
+            packed = gather_records(packed, width, engine.device if dist.get_backend() == "nccl" else "cpu")
     all_recs = [CoalitionRecord.unpack(v) for v in packed]
     if rank == 0 and db_path:
-        with open(db_path, "a+") as f:
-            for r in all_recs:
-                f.write(json.dumps(engine.jsonl_row(r)) + "\n")
+        merge_shards(db_path, [engine.jsonl_row(r) for r in all_recs] if (gathered and dist_on) else ())
+    if failed and verbose:
+        print(f"[rank {rank}] seeds still failing after {retries} retries: {failed}", flush=True)
     return all_recs
+
+
+_RDV = [0]

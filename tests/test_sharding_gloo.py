@@ -74,3 +74,77 @@ def test_two_rank_gloo_all_gather_and_merge(tmp_path):
     new = rows[1:]
     assert [r["removal_seed"] for r in new] == [0, 1, 3, 4, 5, 6]
     assert all(abs(r["fid_value"] - (10.0 + 0.5 * r["removal_seed"])) < 1e-12 for r in new)
+
+
+# ---- durability / failure handling of the scheduler (reference: per-job `open(db, "a+")` rows,
+# ---- unlearn.job `--requeue`, setup_unlearn_commands.py:133-154 re-entry) -------------------------------------
+import subprocess  # noqa: E402
+
+from gad import launch  # noqa: E402
+from gad.coalition import finished_seeds  # noqa: E402
+
+WORKER = os.path.join(os.path.dirname(os.path.abspath(__file__)), "_shard_worker.py")
+REPO = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+
+
+def _rows(path):
+    return [json.loads(l) for l in open(path)] if os.path.exists(path) else []
+
+
+@pytest.mark.timeout(120)
+def test_failed_coalition_is_recorded_and_retried(tmp_path):
+    db = str(tmp_path / "db.jsonl")
+    rc = subprocess.run([sys.executable, WORKER, db, "6", "raise_once:3"]).returncode
+    assert rc == 0
+    assert sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 2, 3, 4, 5]          # retried in a fresh cycle
+    fails = _rows(db + ".failed")
+    assert len(fails) == 1 and fails[0]["removal_seed"] == 3 and "synthetic failure" in fails[0]["error"]
+    assert not launch.os.path.exists(db + ".rank0")                                    # shard consolidated away
+
+
+@pytest.mark.timeout(120)
+def test_persistently_failing_coalition_does_not_lose_the_others(tmp_path):
+    db = str(tmp_path / "db.jsonl")
+    rc = subprocess.run([sys.executable, WORKER, db, "6", "raise_always:2"]).returncode
+    assert rc == 0
+    assert sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 3, 4, 5]
+    assert len(_rows(db + ".failed")) == 2                                              # first attempt + one retry
+    # re-entry runs only the missing seed
+    rc = subprocess.run([sys.executable, WORKER, db, "6", "ok"]).returncode
+    assert rc == 0 and sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 2, 3, 4, 5]
+
+
+@pytest.mark.timeout(180)
+def test_rank_dying_mid_run_keeps_finished_rows_and_requeue_completes(tmp_path):
+    """rank 1 is killed (os._exit) while running seed 5: its earlier seeds are already durable in its shard, rank 0
+    does not hang in the all_gather (tombstone), merges every shard, and a second entry finishes seed 5 and 7."""
+    db = str(tmp_path / "db.jsonl")
+    codes = launch.spawn_workers([sys.executable, WORKER, db, "8", "die:5"], 2, db_path=db)
+    assert codes[0] == 0 and codes[1] == 17
+    assert sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 2, 3, 4, 6]          # 1, 3 came from the dead rank's shard
+    assert finished_seeds(db) == {0, 1, 2, 3, 4, 6}
+    codes = launch.spawn_workers([sys.executable, WORKER, db, "8", "ok"], 2, db_path=db)   # the requeued entry
+    assert codes == [0, 0]
+    assert sorted(r["removal_seed"] for r in _rows(db)) == list(range(8))
+    assert len({r["removal_seed"] for r in _rows(db)}) == 8                            # no duplicates
+
+
+@pytest.mark.timeout(180)
+def test_bench_launcher_starts_n_ranks_before_any_gpu_call(tmp_path):
+    """`python bench.py --gpus 2` with no WORLD_SIZE: the parent spawns 2 ranks; n_gpus comes from the process group."""
+    env = {k: v for k, v in os.environ.items() if k not in ("WORLD_SIZE", "RANK", "LOCAL_RANK", "MASTER_PORT")}
+    env["GAD_STUB_DB"] = str(tmp_path / "stub.jsonl")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub", "--steps", "3", "--warmup", "0"],
+                       env=env, capture_output=True, text=True)
+    assert r.returncode == 0, r.stderr
+    line = json.loads([l for l in r.stdout.splitlines() if l.startswith("{")][-1])
+    assert line["n_gpus"] == 2 and line["ranks_seen"] == [0, 1] and line["stub"] is True
+    assert line["records_gathered"] == [0, 1, 2, 3, 4, 5]
+    assert sorted(x["removal_seed"] for x in _rows(env["GAD_STUB_DB"])) == [0, 1, 2, 3, 4, 5]
+
+
+def test_bench_refuses_a_world_size_that_is_not_gpus():
+    env = dict(os.environ, WORLD_SIZE="1", RANK="0", LOCAL_RANK="0")
+    r = subprocess.run([sys.executable, os.path.join(REPO, "bench.py"), "--gpus", "2", "--stub"], env=env,
+                       capture_output=True, text=True)
+    assert r.returncode == 2 and "WORLD_SIZE=1" in r.stderr
