@@ -60,7 +60,8 @@ __global__ void silu_bwd_kernel(const float* __restrict__ x, const float* __rest
   EW_LOOP_TAIL(n) dx[i] = silu_grad(x[i], dy[i]);
 }
 
-__global__ void ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eps, float* __restrict__ xp,
+// x / xp are NOT restrict-qualified: the samplers launch this in place (xp == x)
+__global__ void ddim_step_kernel(const float* x, const float* __restrict__ eps, float* xp,
                                  long n, float sa, float sb, float spa, float spb, float clip) {
   EW_LOOP_VEC(n) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i], e4 = reinterpret_cast<const f32x4*>(eps)[i], o;
@@ -79,8 +80,8 @@ __global__ void ddim_step_kernel(const float* __restrict__ x, const float* __res
   }
 }
 
-__global__ void cfg_ddim_step_kernel(const float* __restrict__ x, const float* __restrict__ eu, const float* __restrict__ ec,
-                                     float* __restrict__ xp, long n, float gd, float sa, float sb, float spa, float spb, float clip) {
+__global__ void cfg_ddim_step_kernel(const float* x, const float* __restrict__ eu, const float* __restrict__ ec,
+                                     float* xp, long n, float gd, float sa, float sb, float spa, float spb, float clip) {
   EW_LOOP_VEC(n) {
     f32x4 v = reinterpret_cast<const f32x4*>(x)[i], u = reinterpret_cast<const f32x4*>(eu)[i], c = reinterpret_cast<const f32x4*>(ec)[i], o;
 #pragma unroll
@@ -249,7 +250,8 @@ __global__ void final_sum_kernel(const float* __restrict__ part, float* __restri
 }
 
 // ---- row softmax, one wave per row ----
-__global__ void softmax_fwd_kernel(const float* __restrict__ s, float* __restrict__ p, long rows, int n, float scale) {
+// in-place launches (p == s, ds == dp) are part of the contract: no restrict on the aliased pairs
+__global__ void softmax_fwd_kernel(const float* s, float* p, long rows, int n, float scale) {
   long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
   int lane = threadIdx.x & 63;
@@ -264,7 +266,7 @@ __global__ void softmax_fwd_kernel(const float* __restrict__ s, float* __restric
   float inv = 1.f / sum;
   for (int i = lane; i < n; i += 64) pr[i] = expf(sr[i] * scale - mx) * inv;
 }
-__global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* __restrict__ dp, float* __restrict__ ds, long rows,
+__global__ void softmax_bwd_kernel(const float* __restrict__ p, const float* dp, float* ds, long rows,
                                    int n, float scale) {
   long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;

@@ -162,7 +162,7 @@ class CoalitionEngine:
                  unet_overrides: Optional[dict] = None, feature_dims=2048):
         from src.datasets import create_dataset
         from src.ddpm_config import DDPMConfig
-        from .scoring import FeatureNet
+        from .scoring import extractor_tag  # noqa: F401
 
         self.device = torch.device(device)
         self.dataset_name = dataset_name
@@ -188,7 +188,7 @@ class CoalitionEngine:
             base_state = {"unet": {k: v.clone() for k, v in m.state_dict().items()}, "unet_ema": ema.state_dict()}
         self.base_state = base_state
         from . import scoring
-        self.feature_net = FeatureNet(feature_dims).to(self.device)
+        self.feature_net = scoring.default_extractor(feature_dims, self.device)
         scoring._REF_STATS["net"] = self.feature_net          # one extractor for every score of this process
         self.opt_kwargs = dict(self.config["optimizer_config"]["kwargs"])
         self.adamw = self.config["optimizer_config"]["class_name"] == "AdamW"
@@ -239,6 +239,7 @@ class CoalitionEngine:
         total_steps_time = time.time() - t0
         # EMA weights are used for inference (unlearn.py:751-753); the fine-tuned ones are not kept
         model.flat[0].copy_(trainer.ema_flat)
+        ops.WEIGHT_EPOCH[0] += 1                                         # flat copy: no per-parameter version bump
         model.eval()
         t1 = time.time()
         if self.preview:                                                  # unlearn.py:761-765 (global RNG)
@@ -261,6 +262,7 @@ class CoalitionEngine:
         return rec
 
     def jsonl_row(self, rec: CoalitionRecord, extra: Optional[dict] = None) -> dict:
+        from .scoring import extractor_tag
         """Keys lds.py reads (lds.py:203-257): dataset, removal_dist, method, exp_name, removal_seed,
         remaining_idx, fid_value, gd_steps, total_steps_time, total_sampling_time."""
         remaining_idx, removed_idx = self.coalition(rec.removal_seed)
@@ -271,7 +273,8 @@ class CoalitionEngine:
                    total_steps_time=rec.total_steps_time, **{"is": rec.inception_score},
                    trained_steps=rec.trained_steps, remaining_idx=np.asarray(remaining_idx).tolist(),
                    removed_idx=np.asarray(removed_idx).tolist(), device=str(self.device),
-                   total_sampling_time=rec.total_sampling_time)
+                   total_sampling_time=rec.total_sampling_time,
+                   feature_extractor=extractor_tag(self.feature_net))   # stand-in rows must never pass for Inception rows
         if extra:
             row.update(extra)
         return row

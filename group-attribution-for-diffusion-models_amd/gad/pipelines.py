@@ -182,7 +182,10 @@ def sd_simple_loss(unet, scheduler, latents0, prompt_embeds, timesteps, n_noises
     total = 0.0
     with torch.no_grad():
         for _ in range(n_noises):
-            eps = torch.randn(z.shape, generator=generator, device=dev, dtype=torch.float32)
+            if generator is not None and generator.device.type == "cpu":      # host draw, then moved (randn_tensor semantics)
+                eps = torch.randn(z.shape, generator=generator, dtype=torch.float32).to(dev)
+            else:
+                eps = torch.randn(z.shape, generator=generator, device=dev, dtype=torch.float32)
             noisy = scheduler.add_noise(z, eps, timesteps.to(dev))
             pred = unet(noisy, timesteps.to(dev), ctx).sample
             loss, _ = ops.mse_fwd_bwd_raw(pred.contiguous(), eps)

@@ -9,6 +9,8 @@ Frechet distance - is restated exactly (fid_score.py:104-105 and
 pytorch_fid.calculate_frechet_distance)."""
 from __future__ import annotations
 
+import os
+
 import numpy as np
 import torch
 import torch.nn as nn
@@ -29,7 +31,7 @@ class FeatureNet(nn.Module):
         self.norms = nn.ModuleList([gnn.GroupNorm(32, co, 1e-5) for _, co, _ in chans])
         self.head = gnn.Linear(512, dims)
         torch.random.set_rng_state(rng)
-        self.dims = dims
+        self.dims, self.seed = dims, seed
 
     @torch.no_grad()
     def forward(self, images_nchw01):
@@ -41,28 +43,41 @@ class FeatureNet(nn.Module):
         return self.head(pooled)
 
 
-def feature_stats(features: np.ndarray):
-    """mu, sigma exactly as fid_score.compute_features_stats (:104-105): float64 mean and np.cov."""
-    f = np.asarray(features, dtype=np.float64)
-    return np.mean(f, axis=0), np.cov(f, rowvar=False)
+def extractor_tag(net) -> str:
+    """What produced the features behind a score row.  The reference's rows come from InceptionV3 / VGG16 / BLIP with
+    URL-fetched weights (fid_score.py:28, precision_recall.py:31, diversity_score.py:89); rows written under the seeded
+    stand-in must never be mistaken for them, so every row carries this tag as `feature_extractor`."""
+    return getattr(net, "tag", f"standin-seed{getattr(net, 'seed', '?')}-d{getattr(net, 'dims', '?')}")
 
 
-def frechet_distance(mu1, sigma1, mu2, sigma2, eps=1e-6):
-    """d^2 = |mu1-mu2|^2 + Tr(s1 + s2 - 2 sqrt(s1 s2))  (pytorch_fid.calculate_frechet_distance)."""
-    from scipy import linalg
+class ScriptedExtractor(nn.Module):
+    """A real extractor supplied as a TorchScript file ([B,3,H,W] in [0,1] -> [B,dims]; e.g. pytorch_fid's pool3 trunk
+    scripted where its weights exist): `GAD_FEATURE_NET_TS=/path/extractor.pt`.  Runs with stock torch ops - the score
+    tail is ~1 % of a coalition and off the hand-written path."""
 
-    mu1, mu2 = np.atleast_1d(mu1), np.atleast_1d(mu2)
-    sigma1, sigma2 = np.atleast_2d(sigma1), np.atleast_2d(sigma2)
-    diff = mu1 - mu2
-    covmean, _ = linalg.sqrtm(sigma1.dot(sigma2), disp=False)
-    if not np.isfinite(covmean).all():
-        offset = np.eye(sigma1.shape[0]) * eps
-        covmean = linalg.sqrtm((sigma1 + offset).dot(sigma2 + offset))
-    if np.iscomplexobj(covmean):
-        if not np.allclose(np.diagonal(covmean).imag, 0, atol=1e-3):
-            raise ValueError(f"Imaginary component {np.max(np.abs(covmean.imag))}")
-        covmean = covmean.real
-    return float(diff.dot(diff) + np.trace(sigma1) + np.trace(sigma2) - 2 * np.trace(covmean))
+    def __init__(self, path, device):
+        super().__init__()
+        import hashlib
+        self.mod = torch.jit.load(path, map_location=device).eval()
+        with open(path, "rb") as f:
+            self.tag = f"torchscript:{os.path.basename(path)}:{hashlib.sha256(f.read()).hexdigest()[:12]}"
+        with torch.no_grad():
+            self.dims = int(self.mod(torch.zeros(1, 3, 32, 32, device=device)).shape[1])
+
+    @torch.no_grad()
+    def forward(self, images_nchw01):
+        return self.mod(images_nchw01.float()).float()
+
+
+def default_extractor(dims, device, seed=1234):
+    path = os.environ.get("GAD_FEATURE_NET_TS")
+    if path and os.path.exists(path):
+        return ScriptedExtractor(path, device)
+    return FeatureNet(dims, seed=seed).to(device)
+
+
+from src.attributions.global_scores.fid_score import (calculate_frechet_distance as frechet_distance,  # noqa: E402,F401
+                                                      compute_features_stats as feature_stats)
 
 
 def feature_stats_torch(features: torch.Tensor):
@@ -102,7 +117,7 @@ def fid_against_dataset(images01, dataset, device, batch_size=512, feature_dims=
     mu/sigma play the role of the precomputed stats.pkl, :42-58; cached per dataset object)."""
     net = _REF_STATS.get("net")
     if net is None:
-        net = FeatureNet(feature_dims).to(device)
+        net = default_extractor(feature_dims, device)
         _REF_STATS["net"] = net
     key = id(dataset)
     if key not in _REF_STATS:
@@ -127,7 +142,7 @@ def global_scores_against_dataset(images01, dataset, device, batch_size=512, fea
     from src.attributions.global_scores.precision_recall import calc_pr, make_manifold
     net = _REF_STATS.get("net")
     if net is None:
-        net = FeatureNet(feature_dims).to(device)
+        net = default_extractor(feature_dims, device)
         _REF_STATS["net"] = net
     key = ("dev", id(dataset))
     if key not in _REF_STATS:
@@ -141,7 +156,8 @@ def global_scores_against_dataset(images01, dataset, device, batch_size=512, fea
     probs = torch.softmax(gen_f[:, :1000].double(), dim=1).cpu().numpy()
     is_value = inception_score_from_probs(probs)
     precision, recall = calc_pr(make_manifold(gen_f, nhood_size, 10000, 10000, device), m_ref, 10000, 10000, device)
-    return {"fid_value": fid, "is": is_value, "precision": precision, "recall": recall}
+    return {"fid_value": fid, "is": is_value, "precision": precision, "recall": recall,
+            "feature_extractor": extractor_tag(net)}
 
 
 def diversity_against_dataset(images01, dataset, device, num_cluster=20, batch_size=256, feature_dims=768, max_ref=2000):
@@ -167,4 +183,5 @@ def diversity_against_dataset(images01, dataset, device, num_cluster=20, batch_s
     f = compute_features_torch(net, images01.to(device), batch_size, device)
     emb_gen = torch.nn.functional.normalize(f.double(), dim=1).cpu().numpy()
     entropy, cluster_count, proportions, _, _ = diversity_from_embeddings(emb_ref, emb_gen, num_cluster)
-    return {"entropy": entropy, "cluster_count": cluster_count, "cluster_proportions": proportions}
+    return {"entropy": entropy, "cluster_count": cluster_count, "cluster_proportions": proportions,
+            "feature_extractor": extractor_tag(net)}

@@ -260,13 +260,16 @@ class UNet2DConditionModel(nn.Module):
                 params += list(layer.parameters())
         return params
 
-    def lora_state_dict(self):
+    def lora_state_dict(self, prefix: str = ""):
+        """Keys as diffusers-0.24 `unet.save_attn_procs` writes them (train_text_to_image_lora.py:1367,1493;
+        prune_lora.py:102,196): ``<attn_processors name>.to_{q,k,v,out}_lora.{down,up}.weight`` with NO `unet.` prefix
+        (that prefix belongs to pipeline-level `save_lora_weights` files; pass prefix="unet." for those)."""
         sd = {}
         for name, attn in self.attention_modules().items():
             for proj, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0])):
                 if lin.lora_layer is not None:
-                    sd[f"unet.{name}.{proj}_lora.down.weight"] = lin.lora_layer.down.weight.detach().cpu().contiguous()
-                    sd[f"unet.{name}.{proj}_lora.up.weight"] = lin.lora_layer.up.weight.detach().cpu().contiguous()
+                    sd[f"{prefix}{name}.{proj}_lora.down.weight"] = lin.lora_layer.down.weight.detach().cpu().contiguous()
+                    sd[f"{prefix}{name}.{proj}_lora.up.weight"] = lin.lora_layer.up.weight.detach().cpu().contiguous()
         return sd
 
     def save_attn_procs(self, save_directory, weight_name="pytorch_lora_weights.safetensors"):
@@ -274,19 +277,38 @@ class UNet2DConditionModel(nn.Module):
         os.makedirs(save_directory, exist_ok=True)
         save_file(self.lora_state_dict(), os.path.join(save_directory, weight_name))
 
-    def load_attn_procs(self, directory, weight_name="pytorch_lora_weights.safetensors"):
-        """Accepts per-projection ranks (the upstream loader's single-rank assumption is the bug the reference
-        patches with my_get_processor, src/utils.py:84-96)."""
-        from safetensors.torch import load_file
-        sd = load_file(os.path.join(directory, weight_name))
-        mods = self.attention_modules()
-        for name, attn in mods.items():
+    def load_lora_state_dict(self, sd: dict):
+        """Accepts the `unet.save_attn_procs` key form and the `unet.`-prefixed pipeline form, per-projection ranks
+        included (the upstream loader's single-rank assumption is the bug the reference patches with my_get_processor,
+        src/utils.py:84-96).  A non-empty file none of whose keys belong to this U-Net, or one with keys left over,
+        is an error - never a silent no-op that would train / score the bare base model."""
+        sd = {(k[len("unet."):] if k.startswith("unet.") else k): v for k, v in sd.items()}
+        used = set()
+        for name, attn in self.attention_modules().items():
             for proj, lin in (("to_q", attn.to_q), ("to_k", attn.to_k), ("to_v", attn.to_v), ("to_out", attn.to_out[0])):
-                kd = f"unet.{name}.{proj}_lora.down.weight"
-                if kd in sd:
-                    down, up = sd[kd], sd[f"unet.{name}.{proj}_lora.up.weight"]
+                kd, ku = f"{name}.{proj}_lora.down.weight", f"{name}.{proj}_lora.up.weight"
+                if kd in sd or ku in sd:
+                    if not (kd in sd and ku in sd):
+                        raise KeyError(f"LoRA file has only one of {kd} / {ku}")
+                    down, up = sd[kd], sd[ku]
+                    if down.shape[1] != lin.weight.shape[1] or up.shape[0] != lin.weight.shape[0] or down.shape[0] != up.shape[1]:
+                        raise ValueError(f"{name}.{proj}: LoRA shapes {tuple(down.shape)} / {tuple(up.shape)} do not fit a "
+                                         f"{tuple(lin.weight.shape)} projection")
                     layer = LoRALinearLayer(down.shape[1], up.shape[0], rank=down.shape[0]).to(lin.weight.device)
                     with torch.no_grad():
                         layer.down.weight.copy_(down)
                         layer.up.weight.copy_(up)
                     lin.set_lora_layer(layer)
+                    used.update((kd, ku))
+        left = sorted(set(sd) - used)
+        if sd and not used:
+            raise KeyError(f"none of the {len(sd)} keys of the LoRA file name an attention projection of this U-Net "
+                           f"(first key: {next(iter(sd))!r})")
+        if left:
+            raise KeyError(f"{len(left)} LoRA keys match no attention projection of this U-Net, e.g. {left[0]!r}")
+        ops.WEIGHT_EPOCH[0] += 1
+        return len(used) // 2
+
+    def load_attn_procs(self, directory, weight_name="pytorch_lora_weights.safetensors"):
+        from safetensors.torch import load_file
+        return self.load_lora_state_dict(load_file(os.path.join(directory, weight_name)))

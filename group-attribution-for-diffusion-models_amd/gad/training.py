@@ -174,6 +174,7 @@ class EMAModel:
     def copy_to(self, parameters):
         for s, p in zip(self.shadow_params, list(parameters)):
             p.data.copy_(s.to(p.device).data)
+        ops.WEIGHT_EPOCH[0] += 1          # p.data.copy_ bumps no version counter: weight-derived caches must refresh
 
     def store(self, parameters):
         self.temp_stored_params = [p.detach().cpu().clone() for p in parameters]
@@ -184,6 +185,7 @@ class EMAModel:
         for c, p in zip(self.temp_stored_params, parameters):
             p.data.copy_(c.data)
         self.temp_stored_params = None
+        ops.WEIGHT_EPOCH[0] += 1
 
     def to(self, device=None, dtype=None):
         self.shadow_params = [p.to(device=device, dtype=dtype) if p.is_floating_point() else p.to(device=device)

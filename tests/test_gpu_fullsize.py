@@ -202,6 +202,21 @@ def test_full_width_training_step_matches_cpu_oracle():
     loss_g = tr.step(x.to(dev), n.to(dev), t.to(dev))
     assert abs(loss_g.item() - loss_r.item()) < 1e-4 * abs(loss_r.item())
     assert abs(tr.grad_norm().item() - gn_r.item()) < 2e-3 * gn_r.item()
+    # per-parameter gradients at the width where the patch fwd / dgrad / wgrad kernels run (VERDICT r1 #2e): the oracle's
+    # .grad is already clipped (clip_grad_norm_ scales in place), the flat gradient buffer is not (the clip coefficient
+    # is applied inside the optimizer kernel) -> scale by the same coefficient.  Both sides are fp32 with different
+    # summation orders: relative L2 error per tensor < 2e-3, median < 3e-4, cosine > 0.99999.
+    coef = min(1.0, 1.0 / (tr.grad_norm().item() + 1e-6))
+    rels, names = [], []
+    for (name, p_ref), p_gpu in zip(ref.named_parameters(), net.parameters()):
+        gg = (p_gpu._gad_sink.detach().cpu().double() * coef).flatten()
+        gr = p_ref.grad.double().flatten()
+        rel = ((gg - gr).norm() / gr.norm().clamp_min(1e-30)).item()
+        cos = (gg @ gr / (gg.norm() * gr.norm()).clamp_min(1e-30)).item()
+        assert rel < 2e-3 and cos > 0.99999, (name, rel, cos)
+        rels.append(rel)
+        names.append(name)
+    assert sorted(rels)[len(rels) // 2] < 3e-4, sorted(zip(rels, names))[-5:]
     worst = 0.0
     for (k, a), b in zip(net.state_dict().items(), ref.state_dict().values()):
         worst = max(worst, (a.cpu() - b).abs().max().item())

@@ -167,7 +167,7 @@ def test_sd_lora_entry_point(tmp_path):
     mdir = tmp_path / "out" / "artbench_post_impressionism" / "retrain" / "models" / "artist_shapley" / "shapley_seed=0"
     sd = load_file(str(mdir / "pytorch_lora_weights.safetensors"))
     assert len(sd) == 32 * 4 * 2
-    k = "unet.mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_k_lora.down.weight"
+    k = "mid_block.attentions.0.transformer_blocks.0.attn2.processor.to_k_lora.down.weight"   # unet.save_attn_procs: no `unet.` prefix
     assert sd[k].shape == (8, 96) and sd[k.replace("down", "up")].abs().sum() > 0        # up started at 0: it trained
     t = pd.read_csv(mdir / "time.csv")
     assert list(t.columns) == ["step", "time", "gpu"] and len(t) == 4
@@ -231,6 +231,31 @@ def test_guided_latent_sampling_matches_oracle_loop():
                               got[:1], cond[:1].to(dev), torch.tensor([751, 501, 251, 1]), n_noises=2,
                               generator=torch.Generator(device=dev).manual_seed(0))
     assert loss > 0 and loss == loss
+
+
+def test_sd_simple_loss_matches_oracle_loop():
+    """compute_model_behaviors.py:391-417 restated with the oracle U-Net and scheduler on the host: the batch is the
+    sampler's whole timestep list, one fresh noise per repeat from `noise_generator`, F.mse_loss(mean) averaged over
+    n_noises.  Same CPU generator on both sides (host draw, then moved).  Tolerance 1e-4 relative (fp32 U-Net)."""
+    import gad
+    from oracle import diffusers_ref as R
+    ref, net = _pair(lora_rank=8)
+    kw = dict(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+    z0, cond = rnd(1, 4, 16, 16, seed=21), rnd(1, 77, 96, seed=22)
+    ts = torch.tensor([901, 801, 701, 601, 501, 401, 301, 201, 101, 1])
+    got = gad.sd_simple_loss(net, gad.DDPMScheduler(**kw), z0.to(dev), cond.to(dev), ts, n_noises=3,
+                             generator=torch.Generator().manual_seed(5))
+    sch = R.DDPMScheduler(**kw)
+    g = torch.Generator().manual_seed(5)
+    want = 0.0
+    with torch.no_grad():
+        for _ in range(3):
+            lat = z0.expand(len(ts), -1, -1, -1)
+            noise = torch.randn(lat.size(), generator=g)
+            preds = ref(sch.add_noise(lat, noise, ts), ts, cond.expand(len(ts), -1, -1)).sample
+            want += F.mse_loss(preds, noise, reduction="mean")
+    want = (want / 3).item()
+    assert got == pytest.approx(want, rel=1e-4), (got, want)
 
 
 def test_sd_model_behaviours_entry_point(tmp_path):

@@ -223,3 +223,43 @@ def test_datamodel_matches_reference(golden_dir):
     got = datamodel(z["X"], z["y"], 4)
     assert got.shape == z["coef"].shape == (4, 20)
     assert np.allclose(got, z["coef"], rtol=1e-9, atol=1e-12)
+
+
+def test_lora_file_keys_follow_unet_save_attn_procs(tmp_path):
+    """diffusers-0.24 `unet.save_attn_procs` (train_text_to_image_lora.py:1367,1493; prune_lora.py:102,196)
+    writes `<attn>.processor.to_q_lora.down.weight` with no `unet.` prefix; the loader takes that form and the
+    pipeline-level `unet.`-prefixed one, and never loads a foreign file as a silent no-op."""
+    import pytest
+    import torch
+    from safetensors.torch import load_file, save_file
+    import gad
+
+    cfg = dict(block_out_channels=(32, 64, 64, 64), attention_head_dim=2, cross_attention_dim=48, norm_num_groups=16)
+    torch.manual_seed(0)
+    net = gad.UNet2DConditionModel(**cfg)
+    names = list(net.attention_modules())
+    ranks = {f"{n[:-len('.processor')]}.{p}": 3 + (i % 4) for i, n in enumerate(names) for p in ("to_q", "to_k", "to_v", "to_out")}
+    net.inject_lora(rank=4, ranks=ranks)                                      # ragged ranks, as after prune_lora.py
+    for n, p in net.named_parameters():
+        if "lora_layer" in n:
+            torch.nn.init.normal_(p)
+    net.save_attn_procs(str(tmp_path), weight_name="w.safetensors")
+    sd = load_file(str(tmp_path / "w.safetensors"))
+    assert len(sd) == 2 * 4 * len(names) and not any(k.startswith("unet.") for k in sd)
+    assert "mid_block.attentions.0.transformer_blocks.0.attn1.processor.to_out_lora.up.weight" in sd
+    # reference-format file -> fresh model
+    other = gad.UNet2DConditionModel(**cfg)
+    assert other.load_attn_procs(str(tmp_path), weight_name="w.safetensors") == 4 * len(names)
+    for (ka, a), (kb, b) in zip(sorted(net.lora_state_dict().items()), sorted(other.lora_state_dict().items())):
+        assert ka == kb and torch.equal(a, b)
+    # pipeline-level (`unet.`-prefixed) form loads too
+    save_file({"unet." + k: v for k, v in sd.items()}, str(tmp_path / "p.safetensors"))
+    third = gad.UNet2DConditionModel(**cfg)
+    assert third.load_attn_procs(str(tmp_path), weight_name="p.safetensors") == 4 * len(names)
+    # foreign / partly foreign files are errors, not no-ops
+    save_file({"text_encoder.foo.weight": torch.zeros(2, 2)}, str(tmp_path / "bad.safetensors"))
+    with pytest.raises(KeyError, match="none of the"):
+        gad.UNet2DConditionModel(**cfg).load_attn_procs(str(tmp_path), weight_name="bad.safetensors")
+    save_file({**sd, "down_blocks.9.attn.processor.to_q_lora.down.weight": torch.zeros(2, 2)}, str(tmp_path / "bad2.safetensors"))
+    with pytest.raises(KeyError, match="match no attention projection"):
+        gad.UNet2DConditionModel(**cfg).load_attn_procs(str(tmp_path), weight_name="bad2.safetensors")

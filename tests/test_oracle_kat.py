@@ -127,3 +127,16 @@ def test_ddpm_ancestral_step_closed_form():
             assert torch.allclose(out, mean + var ** 0.5 * z, atol=2e-4), t
     sch.set_timesteps(10)
     assert sch.timesteps.tolist() == [900, 800, 700, 600, 500, 400, 300, 200, 100, 0]
+
+
+def test_product_antithetic_timesteps_is_bit_exact_with_the_oracle():
+    """gad.coalition.antithetic_timesteps itself (main.py:684-696), seeded generator, vs the oracle."""
+    import torch
+    from gad.coalition import antithetic_timesteps
+    from oracle import diffusers_ref as R
+    for B, N, seed in ((128, 1000, 0), (127, 1000, 1), (32, 50, 2), (1, 1000, 3), (2, 7, 4)):
+        got = antithetic_timesteps(N, B, "cpu", generator=torch.Generator().manual_seed(seed))
+        t1 = torch.randint(0, N, (B // 2 + 1,), generator=torch.Generator().manual_seed(seed)).long()
+        want = R.antithetic_timesteps(t1, N, B)
+        assert got.dtype == torch.int64 and torch.equal(got, want)
+        assert torch.equal(got[B // 2 + 1:], (N - 1 - got[:B // 2 + 1])[:B - (B // 2 + 1)])
