@@ -1,0 +1,569 @@
+// Fused (flash-style) attention for gfx950: softmax(scale * Q K^T) V and its gradients with the score matrix kept in
+// registers - S = [B, heads, Tq, Tk] never exists in HBM.
+//
+// Replaces F.scaled_dot_product_attention inside AttnProcessor2_0
+// (reference src/diffusers/models/attention_processor.py:1314-1325) for UNet2DModel's attention blocks (1 head of 256 on
+// CIFAR, heads of 32 on CelebA-HQ) and for the self / cross attentions of the Stable-Diffusion U-Net (head dims 40 / 80 /
+// 160, Tk = Tq or 77; text_to_image/train_text_to_image_lora.py:1268-1270).
+//
+// Exact-fp32 arithmetic on v_mfma_f32_16x16x4_f32 (16-wide tiles: head dim 40 pads to 48, not 64).  One workgroup = 4
+// waves = one block of queries (forward, dQ) or keys (dK/dV) of one (batch, head); it streams the other side through
+// double-buffered LDS tiles filled by LDS-DMA (global_load_lds_dwordx4; rows padded to D+4 floats, zeros beyond D / T).
+//
+// Orientation trick (cdna_hip_programming.md, "an accumulator tile as the next MFMA's operand"): the first product is
+// computed TRANSPOSED so that its 16x16 accumulator (col = lane & 15, row = 4 (lane >> 4) + reg) is, register by
+// register, already the B operand (B[k = lane >> 4][j = lane & 15]) of the product that contracts over its row index:
+//   forward   S^T[key][q] = K Q^T  ->  P^T          ->  O^T[dv][q]  += V^T[dv][key] P^T[key][q]
+//   dQ        S^T, dP^T[key][q] = V dO^T -> dS^T    ->  dQ^T[k][q]  += K^T[k][key] dS^T[key][q]
+//   dK / dV   S[q][key] = Q K^T, dP = dO V^T -> P,dS ->  dV^T[dv][key] += dO^T[dv][q] P[q][key];  dK^T += Q^T dS
+// so probabilities never touch LDS, and the softmax statistics of a query (running max, sum, LSE, delta) are per-lane
+// scalars wherever the query sits on the lane index.  Row maxima need two cross-lane exchanges (lanes l, l^16, l^32).
+//
+// Backward is two kernels (dQ by query block, dK/dV by key block), each recomputing S and dP: 7 products instead of
+// the minimal 5, but every output element is produced by exactly one workgroup in a fixed order - no float atomics, so
+// a training step stays bit-reproducible (tests/test_gpu_fullsize.py relies on that).
+#include "gad_common.h"
+
+namespace {
+
+typedef float f32x2 __attribute__((ext_vector_type(2)));
+
+constexpr int NT = 256;     // threads per workgroup (4 waves)
+constexpr int KV = 32;      // streamed rows per LDS tile
+
+__device__ __attribute__((aligned(64))) float g_attn_zero[16];
+
+__device__ __forceinline__ void glds16(const float* src, float* dst_wave_uniform) {
+  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                   (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, 0);
+}
+// publish LDS-DMA'd tiles: the DMA is a VMEM operation -> explicit vmcnt(0) before the barrier
+__device__ __forceinline__ void barrier_after_dma() {
+  __builtin_amdgcn_s_waitcnt(0x0F70);
+  __syncthreads();
+}
+
+template <int D>
+struct Cfg {
+  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+  static constexpr int DP = (D + 15) / 16 * 16;    // head dim padded to whole 16-wide output tiles
+  static constexpr int S = DP + 4;                 // LDS row stride (floats): == 4 (mod 8) -> column reads conflict-free
+  static constexpr int G16 = D / 16;               // 16-k groups read as one float4 per lane
+  static constexpr bool TAIL8 = (D % 16) == 8;     // + one 8-k group read as float2 per lane
+  static constexpr int KS = D / 4;                 // MFMA 16x16x4 steps over the head dim
+  static constexpr int NDV = DP / 16;              // 16-wide tiles over the head dim
+  static constexpr int TILE = (KV * S * 4 + 1023) / 1024 * 256;   // floats per LDS tile (whole 1 KiB DMA pieces)
+  static constexpr int NPIECE = TILE / 256;
+};
+
+struct AttnDev {
+  const float* q; const float* k; const float* v; float* o; float* lse;
+  const float* d_o; const float* delta; float* dq; float* dk; float* dv;
+  int B, heads, Tq, Tk;
+  int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;       // row strides (floats)
+  long sq, sk, sv, so, sdo, sdq, sdk, sdv;              // batch strides (floats)
+  float scale;                                           // 1/sqrt(d)
+};
+
+// Fill a [KV][S] row-major tile with rows row0 .. row0+KV-1 of `base` (row stride ld, D valid columns, T valid rows);
+// everything else (pad columns, rows past T, the tail of the last 1 KiB piece) reads the zero block.
+template <int D>
+__device__ __forceinline__ void stage_tile(float* tile, const float* base, int ld, int row0, int T) {
+  using C = Cfg<D>;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+  for (int i = 0; i < (C::NPIECE + 3) / 4; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < C::NPIECE) {
+      const int f = (piece * 64 + lane) * 4;
+      const int row = f / C::S, col = f - row * C::S;
+      const bool ok = row < KV && row0 + row < T && col < D;
+      const float* src = ok ? base + (long)(row0 + row) * ld + col : (const float*)g_attn_zero;
+      glds16(src, tile + piece * 256);
+    }
+  }
+}
+
+// "row fragment": lanes along the tile's ROWS (lane l: row r0 + (l & 15), k slot g = l >> 4).  Step s = 4 grp + j uses
+// k = 16 grp + 4 g + j (float4 per group), the 8-wide tail k = 16 G16 + 2 g + j (float2).  The SAME k assignment is
+// used for both operands of a product, which is all a contraction needs.
+template <int D>
+__device__ __forceinline__ void row_frag_lds(const float* tile, int r0, float (&f)[Cfg<D>::KS]) {
+  using C = Cfg<D>;
+  const int lane = threadIdx.x & 63, r = r0 + (lane & 15), g = lane >> 4;
+  const float* p = tile + r * C::S;
+#pragma unroll
+  for (int grp = 0; grp < C::G16; ++grp) {
+    const f32x4 v = *reinterpret_cast<const f32x4*>(p + 16 * grp + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[4 * grp + j] = v[j];
+  }
+  if (C::TAIL8) {
+    const f32x2 v = *reinterpret_cast<const f32x2*>(p + 16 * C::G16 + 2 * g);
+    f[4 * C::G16] = v[0];
+    f[4 * C::G16 + 1] = v[1];
+  }
+}
+// the same fragment straight from global memory (loop-invariant operands: one load per workgroup lifetime)
+template <int D>
+__device__ __forceinline__ void row_frag_global(const float* base, int ld, int row, bool ok, float mul, float (&f)[Cfg<D>::KS]) {
+  using C = Cfg<D>;
+  const int g = (threadIdx.x & 63) >> 4;
+  const float* p = base + (long)(ok ? row : 0) * ld;
+#pragma unroll
+  for (int grp = 0; grp < C::G16; ++grp) {
+    f32x4 v = *reinterpret_cast<const f32x4*>(p + 16 * grp + 4 * g);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) f[4 * grp + j] = ok ? v[j] * mul : 0.f;
+  }
+  if (C::TAIL8) {
+    f32x2 v = *reinterpret_cast<const f32x2*>(p + 16 * C::G16 + 2 * g);
+    f[4 * C::G16] = ok ? v[0] * mul : 0.f;
+    f[4 * C::G16 + 1] = ok ? v[1] * mul : 0.f;
+  }
+}
+
+__device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x4f32(a, b, c, 0, 0, 0); }
+__device__ __forceinline__ float ex2(float x) { return __builtin_amdgcn_exp2f(x); }
+__device__ __forceinline__ float xmax16_32(float v) {        // max over the 4 lanes {l, l^16, l^32, l^48}
+  v = fmaxf(v, __shfl_xor(v, 16, 64));
+  return fmaxf(v, __shfl_xor(v, 32, 64));
+}
+__device__ __forceinline__ float xsum16_32(float v) {
+  v += __shfl_xor(v, 16, 64);
+  return v + __shfl_xor(v, 32, 64);
+}
+
+constexpr float LOG2E = 1.4426950408889634f;
+constexpr float NEG_BIG = -1.0e30f;
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward: workgroup = 64 NQ queries of one (b, h); wave w owns queries [q0 + 16 NQ w, + 16 NQ)
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int NQ>
+__global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
+  using C = Cfg<D>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][K tile | V tile]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * D;
+  const float* K = p.k + b * p.sk + h * D;
+  const float* V = p.v + b * p.sv + h * D;
+  const int qw = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+
+  float qf[NQ][C::KS];
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) {
+    const int row = qw + 16 * t + c;
+    row_frag_global<D>(Q, p.ldq, row, row < p.Tq, p.scale * LOG2E, qf[t]);     // scores in the exp2 domain
+  }
+  f32x4 o[C::NDV][NQ];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i)
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) o[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) { m[t] = NEG_BIG; l[t] = 0.f; }
+
+  const int ntiles = (p.Tk + KV - 1) / KV;
+  stage_tile<D>(lds, K, p.ldk, 0, p.Tk);
+  stage_tile<D>(lds + C::TILE, V, p.ldv, 0, p.Tk);
+  barrier_after_dma();
+
+  for (int it = 0; it < ntiles; ++it) {
+    const float* kt_ = lds + (it & 1) * (2 * C::TILE);
+    const float* vt_ = kt_ + C::TILE;
+    if (it + 1 < ntiles) {            // the other buffer was last read before the barrier that ended iteration it-1
+      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+      stage_tile<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk);
+      stage_tile<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk);
+    }
+    // S^T[key][q] (exp2 domain), two key tiles of 16
+    f32x4 s[2][NQ];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float kf[C::KS];
+      row_frag_lds<D>(kt_, 16 * kt, kf);
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) s[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) s[kt][t] = mfma16(kf[st], qf[t][st], s[kt][t]);
+    }
+    if ((it + 1) * KV > p.Tk) {       // ragged last tile (Tk = 77): keys past the end do not take part
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (it * KV + 16 * kt + 4 * g + e >= p.Tk)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) s[kt][t][e] = -__builtin_inff();
+    }
+    // online softmax; query = lane & 15 -> running max / sum / rescale factor are per-lane scalars
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      float mx = fmaxf(fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3])),
+                       fmaxf(fmaxf(s[1][t][0], s[1][t][1]), fmaxf(s[1][t][2], s[1][t][3])));
+      mx = xmax16_32(mx);
+      const float mn = fmaxf(m[t], mx);
+      const float alpha = ex2(m[t] - mn);
+      m[t] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = ex2(s[kt][t][e] - mn);
+          s[kt][t][e] = pe;
+          ps += pe;
+        }
+      l[t] = l[t] * alpha + ps;       // per-lane partial sum (its 8 keys); the 4 partials of a query meet in the epilogue
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) o[i][t] *= alpha;
+    }
+    // O^T[dv][q] += V^T[dv][key] P^T[key][q]: B operand = the probability registers as they stand
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* vrow = vt_ + (16 * kt + 4 * g + e) * C::S + c;
+#pragma unroll
+        for (int i = 0; i < C::NDV; ++i) {
+          const float a = vrow[16 * i];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) o[i][t] = mfma16(a, s[kt][t][e], o[i][t]);
+        }
+      }
+    barrier_after_dma();              // next tiles landed; every wave is done with this buffer
+  }
+
+  float* O = p.o + b * p.so + h * D;
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) {
+    const float lt = xsum16_32(l[t]);
+    const float inv = 1.f / lt;
+    const int row = qw + 16 * t + c;
+    if (row < p.Tq) {
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        const int dv = 16 * i + 4 * g;
+        if (dv < D) *reinterpret_cast<f32x4*>(O + (long)row * p.ldo + dv) = o[i][t] * inv;
+      }
+      if (g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m[t] + __builtin_amdgcn_logf(lt);   // v_log_f32 = log2
+    }
+  }
+}
+
+// delta[b, h, q] = sum_dv dO[b, q, h, dv] * O[b, q, h, dv]
+template <int D>
+__global__ void attn_delta_kernel(const AttnDev p, float* delta) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.B * p.Tq * p.heads;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.heads);
+  const long bq = idx / p.heads;
+  const int q = (int)(bq % p.Tq), b = (int)(bq / p.Tq);
+  const float* o = p.o + b * p.so + (long)q * p.ldo + h * D;
+  const float* g = p.d_o + b * p.sdo + (long)q * p.lddo + h * D;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const f32x4 a = *reinterpret_cast<const f32x4*>(o + i), d = *reinterpret_cast<const f32x4*>(g + i);
+    acc += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+  }
+  delta[((long)b * p.heads + h) * p.Tq + q] = acc;
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dQ: workgroup = 64 queries of one (b, h), wave w owns 16; streams K / V tiles
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
+  using C = Cfg<D>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* K = p.k + b * p.sk + h * D;
+  const float* V = p.v + b * p.sv + h * D;
+  const int row = blockIdx.x * 64 + wave * 16 + c;
+  const bool rok = row < p.Tq;
+
+  float qf[C::KS], dof[C::KS];
+  row_frag_global<D>(p.q + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
+  row_frag_global<D>(p.d_o + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
+  const float L2 = rok ? p.lse[(long)bh * p.Tq + row] : 0.f;
+  const float dl = rok ? p.delta[(long)bh * p.Tq + row] : 0.f;
+  f32x4 dq[C::NDV];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  const int ntiles = (p.Tk + KV - 1) / KV;
+  stage_tile<D>(lds, K, p.ldk, 0, p.Tk);
+  stage_tile<D>(lds + C::TILE, V, p.ldv, 0, p.Tk);
+  barrier_after_dma();
+  for (int it = 0; it < ntiles; ++it) {
+    const float* kt_ = lds + (it & 1) * (2 * C::TILE);
+    const float* vt_ = kt_ + C::TILE;
+    if (it + 1 < ntiles) {
+      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+      stage_tile<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk);
+      stage_tile<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk);
+    }
+    f32x4 ds[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float kf[C::KS];
+        row_frag_lds<D>(kt_, 16 * kt, kf);
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) s = mfma16(kf[st], qf[st], s);              // S^T[key][q]
+      }
+      {
+        float vf[C::KS];
+        row_frag_lds<D>(vt_, 16 * kt, vf);
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) dp = mfma16(vf[st], dof[st], dp);           // dP^T[key][q] = V dO^T
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
+        const float pe = kok ? ex2(s[e] - L2) : 0.f;
+        ds[kt][e] = pe * (dp[e] - dl);
+      }
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* krow = kt_ + (16 * kt + 4 * g + e) * C::S + c;
+#pragma unroll
+        for (int i = 0; i < C::NDV; ++i) dq[i] = mfma16(krow[16 * i], ds[kt][e], dq[i]);   // dQ^T[k][q] += K^T dS^T
+      }
+    barrier_after_dma();
+  }
+  if (rok) {
+    float* DQ = p.dq + b * p.sdq + h * D + (long)row * p.lddq;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const int kk = 16 * i + 4 * g;
+      if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[i] * p.scale;
+    }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// dK / dV: workgroup = 64 keys of one (b, h), wave w owns 16; streams Q / dO tiles (+ LSE, delta of their rows)
+// ------------------------------------------------------------------------------------------------------------------
+template <int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
+  using C = Cfg<D>;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * D;
+  const float* DO = p.d_o + b * p.sdo + h * D;
+  const int key = blockIdx.x * 64 + wave * 16 + c;
+  const bool kok = key < p.Tk;
+
+  float kf[C::KS], vf[C::KS];
+  row_frag_global<D>(p.k + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
+  row_frag_global<D>(p.v + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
+  f32x4 dk[C::NDV], dv[C::NDV];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float* lse = p.lse + (long)bh * p.Tq;
+  const float* dlt = p.delta + (long)bh * p.Tq;
+
+  const int ntiles = (p.Tq + KV - 1) / KV;
+  stage_tile<D>(lds, Q, p.ldq, 0, p.Tq);
+  stage_tile<D>(lds + C::TILE, DO, p.lddo, 0, p.Tq);
+  barrier_after_dma();
+  for (int it = 0; it < ntiles; ++it) {
+    const float* qt_ = lds + (it & 1) * (2 * C::TILE);
+    const float* dot_ = qt_ + C::TILE;
+    if (it + 1 < ntiles) {
+      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+      stage_tile<D>(nb, Q, p.ldq, (it + 1) * KV, p.Tq);
+      stage_tile<D>(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq);
+    }
+    f32x4 pr[2], ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      {
+        float qf[C::KS];
+        row_frag_lds<D>(qt_, 16 * t, qf);
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) s = mfma16(qf[st], kf[st], s);              // S[q][key]
+      }
+      {
+        float gf[C::KS];
+        row_frag_lds<D>(dot_, 16 * t, gf);
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) dp = mfma16(gf[st], vf[st], dp);            // dP[q][key] = dO V^T
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {       // the query of register e is row 4 g + e of the tile
+        const int qrow = it * KV + 16 * t + 4 * g + e;
+        const bool qok = qrow < p.Tq;
+        const float L2 = qok ? lse[qrow] : 0.f, dl = qok ? dlt[qrow] : 0.f;
+        const float pe = qok ? ex2(s[e] - L2) : 0.f;
+        pr[t][e] = pe;
+        ds[t][e] = pe * (dp[e] - dl);
+      }
+    }
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* grow = dot_ + (16 * t + 4 * g + e) * C::S + c;
+        const float* qrow = qt_ + (16 * t + 4 * g + e) * C::S + c;
+#pragma unroll
+        for (int i = 0; i < C::NDV; ++i) {
+          dv[i] = mfma16(grow[16 * i], pr[t][e], dv[i]);      // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+          dk[i] = mfma16(qrow[16 * i], ds[t][e], dk[i]);      // dK^T[k][key]  += Q^T[k][q]  dS[q][key]
+        }
+      }
+    barrier_after_dma();
+  }
+  if (kok) {
+    float* DK = p.dk + b * p.sdk + h * D + (long)key * p.lddk;
+    float* DV = p.dv + b * p.sdv + h * D + (long)key * p.lddv;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const int kk = 16 * i + 4 * g;
+      if (kk < D) {
+        *reinterpret_cast<f32x4*>(DK + kk) = dk[i] * p.scale;
+        *reinterpret_cast<f32x4*>(DV + kk) = dv[i];
+      }
+    }
+  }
+}
+
+template <typename F>
+static int set_lds(F kernel, int bytes, const char* what) {
+  if (bytes > 64 * 1024) {
+    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+    if (e != hipSuccess) {
+      gad_set_error("%s: cannot reserve %d bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+      return 1;
+    }
+  }
+  return 0;
+}
+
+}  // namespace
+extern "C" int gad_attention_supported(int32_t d) {
+  switch (d) {
+    case 16: case 32: case 40: case 64: case 80: case 96: case 128: case 160: case 192: case 224: case 256: return 1;
+    default: return 0;
+  }
+}
+namespace {
+
+static int check_common(const gad_attention_args* a, const char* who) {
+  GAD_CHECK(a && a->q && a->k && a->v && a->o, "%s: null pointer", who);
+  GAD_CHECK(a->B > 0 && a->heads > 0 && a->Tq > 0 && a->Tk > 0, "%s: bad shape B=%d heads=%d Tq=%d Tk=%d", who, a->B, a->heads, a->Tq, a->Tk);
+  GAD_CHECK(gad_attention_supported(a->d), "%s: head dim %d has no instance (16, 32, 40, 64, 80, 96, 128, 160, 192, 224, 256)", who, a->d);
+  const int w = a->heads * a->d;
+  GAD_CHECK(a->ldq >= w && a->ldk >= w && a->ldv >= w && a->ldo >= w, "%s: a row stride is smaller than heads*d = %d", who, w);
+  GAD_CHECK(a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0, "%s: row strides must be multiples of 4 floats", who);
+  GAD_CHECK(a->stride_q % 4 == 0 && a->stride_k % 4 == 0 && a->stride_v % 4 == 0 && a->stride_o % 4 == 0, "%s: batch strides must be multiples of 4 floats", who);
+  GAD_CHECK(gad_aligned16(a->q) && gad_aligned16(a->k) && gad_aligned16(a->v) && gad_aligned16(a->o), "%s: q/k/v/o must be 16-byte aligned", who);
+  GAD_CHECK((long)a->B * a->heads < 65536, "%s: B*heads = %ld exceeds the grid's y range", who, (long)a->B * a->heads);
+  GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "%s: operand_precision must be 0 or 1", who);
+  return 0;
+}
+
+static AttnDev make_dev(const gad_attention_args* a) {
+  AttnDev d;
+  memset(&d, 0, sizeof(d));
+  d.q = a->q; d.k = a->k; d.v = a->v; d.o = a->o; d.lse = a->lse;
+  d.d_o = a->d_o; d.delta = a->delta; d.dq = a->dq; d.dk = a->dk; d.dv = a->dv;
+  d.B = a->B; d.heads = a->heads; d.Tq = a->Tq; d.Tk = a->Tk;
+  d.ldq = a->ldq; d.ldk = a->ldk; d.ldv = a->ldv; d.ldo = a->ldo;
+  d.lddo = a->ld_do; d.lddq = a->ld_dq; d.lddk = a->ld_dk; d.lddv = a->ld_dv;
+  d.sq = a->stride_q; d.sk = a->stride_k; d.sv = a->stride_v; d.so = a->stride_o;
+  d.sdo = a->stride_do; d.sdq = a->stride_dq; d.sdk = a->stride_dk; d.sdv = a->stride_dv;
+  d.scale = a->scale;
+  return d;
+}
+
+template <int D, int NQ>
+static int launch_fwd(const AttnDev& d, hipStream_t st) {
+  const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
+  if (set_lds(attn_fwd_f32_kernel<D, NQ>, bytes, "gad_attention_fwd")) return 1;
+  dim3 grid((unsigned)gad_ceil_div(d.Tq, 64 * NQ), (unsigned)(d.B * d.heads));
+  hipLaunchKernelGGL((attn_fwd_f32_kernel<D, NQ>), grid, dim3(NT), bytes, st, d);
+  return 0;
+}
+
+template <int D>
+static int launch_bwd(const AttnDev& d, float* delta, hipStream_t st) {
+  const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
+  if (set_lds(attn_bwd_dq_f32_kernel<D>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_f32_kernel<D>, bytes, "gad_attention_bwd")) return 1;
+  const long total = (long)d.B * d.Tq * d.heads;
+  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
+  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tq, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  return 0;
+}
+
+}  // namespace
+
+extern "C" int gad_attention_fwd(const gad_attention_args* a, void* stream) {
+  if (check_common(a, "gad_attention_fwd")) return 1;
+  AttnDev d = make_dev(a);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  // queries per workgroup: 128 while the (b, h, block) grid still fills the chip twice over, else 64
+  const bool wide = gad_ceil_div(a->Tq, 128) * a->B * a->heads >= 512;
+  switch (a->d) {
+    case 16: rc = wide ? launch_fwd<16, 2>(d, st) : launch_fwd<16, 1>(d, st); break;
+    case 32: rc = wide ? launch_fwd<32, 2>(d, st) : launch_fwd<32, 1>(d, st); break;
+    case 40: rc = wide ? launch_fwd<40, 2>(d, st) : launch_fwd<40, 1>(d, st); break;
+    case 64: rc = wide ? launch_fwd<64, 2>(d, st) : launch_fwd<64, 1>(d, st); break;
+    case 80: rc = wide ? launch_fwd<80, 2>(d, st) : launch_fwd<80, 1>(d, st); break;
+    case 96: rc = launch_fwd<96, 1>(d, st); break;
+    case 128: rc = launch_fwd<128, 1>(d, st); break;
+    case 160: rc = launch_fwd<160, 1>(d, st); break;
+    case 192: rc = launch_fwd<192, 1>(d, st); break;
+    case 224: rc = launch_fwd<224, 1>(d, st); break;
+    default: rc = launch_fwd<256, 1>(d, st); break;
+  }
+  if (rc) return rc;
+  GAD_LAUNCH_CHECK("gad_attention_fwd");
+  return 0;
+}
+
+extern "C" int gad_attention_bwd(const gad_attention_args* a, void* stream) {
+  if (check_common(a, "gad_attention_bwd")) return 1;
+  GAD_CHECK(a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv, "gad_attention_bwd: null pointer (lse / d_o / delta / dq / dk / dv)");
+  const int w = a->heads * a->d;
+  GAD_CHECK(a->ld_do >= w && a->ld_dq >= w && a->ld_dk >= w && a->ld_dv >= w, "gad_attention_bwd: a gradient row stride is smaller than heads*d = %d", w);
+  GAD_CHECK(a->ld_do % 4 == 0 && a->ld_dq % 4 == 0 && a->ld_dk % 4 == 0 && a->ld_dv % 4 == 0, "gad_attention_bwd: gradient row strides must be multiples of 4 floats");
+  GAD_CHECK(a->stride_do % 4 == 0 && a->stride_dq % 4 == 0 && a->stride_dk % 4 == 0 && a->stride_dv % 4 == 0, "gad_attention_bwd: gradient batch strides must be multiples of 4 floats");
+  GAD_CHECK(gad_aligned16(a->d_o) && gad_aligned16(a->dq) && gad_aligned16(a->dk) && gad_aligned16(a->dv), "gad_attention_bwd: gradients must be 16-byte aligned");
+  AttnDev d = make_dev(a);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 0;
+  switch (a->d) {
+    case 16: rc = launch_bwd<16>(d, a->delta, st); break;
+    case 32: rc = launch_bwd<32>(d, a->delta, st); break;
+    case 40: rc = launch_bwd<40>(d, a->delta, st); break;
+    case 64: rc = launch_bwd<64>(d, a->delta, st); break;
+    case 80: rc = launch_bwd<80>(d, a->delta, st); break;
+    case 96: rc = launch_bwd<96>(d, a->delta, st); break;
+    case 128: rc = launch_bwd<128>(d, a->delta, st); break;
+    case 160: rc = launch_bwd<160>(d, a->delta, st); break;
+    case 192: rc = launch_bwd<192>(d, a->delta, st); break;
+    case 224: rc = launch_bwd<224>(d, a->delta, st); break;
+    default: rc = launch_bwd<256>(d, a->delta, st); break;
+  }
+  if (rc) return rc;
+  GAD_LAUNCH_CHECK("gad_attention_bwd");
+  return 0;
+}

@@ -46,6 +46,17 @@ class GroupNormArgs(C.Structure):
                 ("x2", C.c_void_p), ("C1", C.c_int32)]
 
 
+class AttentionArgs(C.Structure):
+    _fields_ = [("q", C.c_void_p), ("k", C.c_void_p), ("v", C.c_void_p), ("o", C.c_void_p), ("lse", C.c_void_p),
+                ("d_o", C.c_void_p), ("delta", C.c_void_p), ("dq", C.c_void_p), ("dk", C.c_void_p), ("dv", C.c_void_p),
+                ("B", C.c_int32), ("heads", C.c_int32), ("Tq", C.c_int32), ("Tk", C.c_int32), ("d", C.c_int32),
+                ("ldq", C.c_int32), ("ldk", C.c_int32), ("ldv", C.c_int32), ("ldo", C.c_int32),
+                ("ld_do", C.c_int32), ("ld_dq", C.c_int32), ("ld_dk", C.c_int32), ("ld_dv", C.c_int32),
+                ("stride_q", C.c_int64), ("stride_k", C.c_int64), ("stride_v", C.c_int64), ("stride_o", C.c_int64),
+                ("stride_do", C.c_int64), ("stride_dq", C.c_int64), ("stride_dk", C.c_int64), ("stride_dv", C.c_int64),
+                ("scale", C.c_float), ("operand_precision", C.c_int32)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("sumsq", C.c_void_p), ("max_norm", C.c_float),
@@ -71,6 +82,9 @@ SIGNATURES = {
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_attention_supported": (C.c_int, [_i32]),
+    "gad_attention_fwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
+    "gad_attention_bwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
     "gad_softmax_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
     "gad_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "gad_layernorm_workspace_bytes": (_i64, [_i64, _i32]),

@@ -600,10 +600,72 @@ def _attn_gemm(A, B, Cm, a_mode, b_mode, M, N, K, lda, ldb, ldc, Bn, heads, sA, 
              sA=sA, sB=sB, sC=sC)
 
 
+def fused_attention_ok(d: int, *lds) -> bool:
+    """Is there a fused (flash-style) instance for this head dim / these row strides?"""
+    return bool(_capi.load().gad_attention_supported(int(d))) and all(int(x) % 4 == 0 for x in lds)
+
+
+def _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, sq, sk, sv):
+    a = _capi.AttentionArgs()
+    a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _ptr(lse)
+    a.B, a.heads, a.Tq, a.Tk, a.d = Bn, heads, Tq, Tk, d
+    a.ldq, a.ldk, a.ldv, a.ldo = ldq, ldk, ldv, heads * d
+    a.stride_q, a.stride_k, a.stride_v, a.stride_o = sq, sk, sv, Tq * heads * d
+    a.scale = 1.0 / math.sqrt(d)
+    a.operand_precision = 0
+    return a
+
+
+def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=True):
+    """Fused attention forward on [Bn, T, *] views (q, k, v may be column blocks of one projection output: their
+    data_ptr is the column offset, ld* the row stride).  -> (o [Bn, Tq, heads*d], lse [Bn, heads, Tq] or None)"""
+    o = torch.empty((Bn, Tq, heads * d), device=q.device, dtype=torch.float32)
+    lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
+    a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv)
+    check(_capi.load().gad_attention_fwd(C.byref(a), _stream()), "gad_attention_fwd")
+    return o, lse
+
+
 class AttentionCoreFn(torch.autograd.Function):
     """F.scaled_dot_product_attention(q, k, v) of AttnProcessor2_0
-    (reference src/diffusers/models/attention_processor.py:1314-1325) on [B, T, heads*d]
-    operands: two batched contractions and one row-softmax kernel; P is kept for backward."""
+    (reference src/diffusers/models/attention_processor.py:1314-1325) on [B, T, heads*d] operands: ONE fused kernel
+    forward (online softmax, the scores never leave the CU; only the per-row log-sum-exp is kept) and a
+    recomputing dQ + dK/dV kernel pair backward (csrc/attention.hip)."""
+
+    @staticmethod
+    def forward(ctx, q, k, v, heads):
+        for t_, n_ in ((q, "q"), (k, "k"), (v, "v")):
+            _req(t_, n_)
+        Bn, Tq, Cq = q.shape
+        Tk = k.shape[1]
+        d = Cq // heads
+        o, lse = attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, need_lse=True)
+        ctx.save_for_backward(q, k, v, o, lse)
+        ctx.heads = heads
+        return o
+
+    @staticmethod
+    def backward(ctx, do):
+        q, k, v, o, lse = ctx.saved_tensors
+        heads = ctx.heads
+        do = do.contiguous()
+        Bn, Tq, Cq = q.shape
+        Tk = k.shape[1]
+        d = Cq // heads
+        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
+        delta = torch.empty_like(lse)
+        a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, Tq * Cq, Tk * Cq, Tk * Cq)
+        a.d_o, a.delta, a.dq, a.dk, a.dv = do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
+        a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq
+        a.stride_do = a.stride_dq = Tq * Cq
+        a.stride_dk = a.stride_dv = Tk * Cq
+        check(_capi.load().gad_attention_bwd(C.byref(a), _stream()), "gad_attention_bwd")
+        return dq, dk, dv, None
+
+
+class UnfusedAttentionCoreFn(torch.autograd.Function):
+    """The same function as three launches (batched Q K^T, row softmax, batched P V; P kept for backward): the route
+    for head dims without a fused instance, and the independent implementation the fused kernels are tested against."""
 
     @staticmethod
     def forward(ctx, q, k, v, heads):
@@ -654,17 +716,25 @@ class AttentionCoreFn(torch.autograd.Function):
 
 
 def attention_core(q, k, v, heads):
-    return AttentionCoreFn.apply(q, k, v, heads)
+    d = q.shape[-1] // heads
+    if fused_attention_ok(d, q.shape[-1]):
+        return AttentionCoreFn.apply(q, k, v, heads)
+    return UnfusedAttentionCoreFn.apply(q, k, v, heads)
+
+
+def attention_core_unfused(q, k, v, heads):
+    return UnfusedAttentionCoreFn.apply(q, k, v, heads)
 
 
 def attention_core_qkv_raw(qkv, Bn, T, Cq, heads):
-    """Inference form of AttentionCoreFn on the output of ONE fused projection: qkv is [Bn*T, 3*Cq] (q | k | v along
-    the columns); the two batched contractions read q, k, v in place through their row stride 3*Cq.  Same products in
-    the same K order as the three-projection path, so the result is bit-identical to it.  No autograd."""
+    """Inference form on the output of ONE fused projection: qkv is [Bn*T, 3*Cq] (q | k | v along the columns); the
+    fused attention kernel reads q, k, v in place through their row stride 3*Cq.  No autograd."""
     d = Cq // heads
-    scale = 1.0 / math.sqrt(d)
     ld = 3 * Cq
     q, k, v = qkv[:, 0:Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:3 * Cq]        # views: data_ptr = column offset
+    if fused_attention_ok(d, ld):
+        return attention_fwd_raw(q, k, v, Bn, heads, T, T, d, ld, ld, ld, need_lse=False)[0]
+    scale = 1.0 / math.sqrt(d)
     S = torch.empty((Bn, heads, T, T), device=qkv.device, dtype=torch.float32)
     _attn_gemm(q, k, S, A_KC, B_KC, T, T, d, ld, ld, T, Bn, heads, (T * ld, d), (T * ld, d), (heads * T * T, T * T))
     check(_capi.load().gad_softmax_fwd(S.data_ptr(), S.data_ptr(), Bn * heads * T, T, scale, _stream()), "gad_softmax_fwd")

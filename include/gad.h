@@ -147,6 +147,36 @@ int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream);
 int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
 
 /* ------------------------------------------------------------------------------
+ * Fused attention core: o = softmax(scale * q k^T) v per (batch, head), the score matrix never leaves the CU
+ * (online softmax over streamed K/V tiles).  Replaces F.scaled_dot_product_attention of AttnProcessor2_0
+ * (src/diffusers/models/attention_processor.py:1314-1325): UNet2DModel attention blocks (head dim 256 on CIFAR, 32 on
+ * CelebA-HQ) and the self / cross attentions of the SD U-Net (head dims 40 / 80 / 160, Tk = Tq or 77;
+ * text_to_image/train_text_to_image_lora.py:1268-1270).
+ * Operands are [B][T][heads*d]-shaped views: row r of batch b, head h starts at base + b*stride + r*ld + h*d, so q, k, v
+ * may be column blocks of one fused [B*T][3C] projection output (ld = 3C).  d in {16, 32, 40, 64, 80, 96, 128, 160, 192, 224, 256} (gad_attention_supported); every ld
+ * and stride a multiple of 4 floats, every pointer 16-byte aligned.
+ * fwd writes o and, if lse != NULL, lse[b][h][q] = log2(sum_k exp2(scale*log2(e)*(q.k)))  (the statistics the backward
+ * pass recomputes the probabilities from).  bwd needs q, k, v, o, lse, d_o and a caller-owned scratch `delta` of
+ * B*heads*Tq floats; it writes dq, dk, dv (no atomics: every element is written once, bit-reproducibly).
+ * ---------------------------------------------------------------------------- */
+typedef struct gad_attention_args {
+  const float* q; const float* k; const float* v;
+  float* o;                 /* fwd: out; bwd: in                                              */
+  float* lse;               /* [B][heads][Tq]; fwd: out (may be NULL); bwd: in                */
+  const float* d_o;         /* bwd: gradient w.r.t. o                                         */
+  float* delta;             /* bwd scratch [B][heads][Tq]                                     */
+  float* dq; float* dk; float* dv;
+  int32_t B, heads, Tq, Tk, d;
+  int32_t ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv;           /* row strides (floats)  */
+  int64_t stride_q, stride_k, stride_v, stride_o, stride_do, stride_dq, stride_dk, stride_dv;   /* batch strides */
+  float scale;              /* 1/sqrt(d)                                                      */
+  int32_t operand_precision;/* 0: exact fp32 products (v_mfma_f32_16x16x4_f32); 1: reserved for bf16 operands */
+} gad_attention_args;
+int gad_attention_supported(int32_t d);      /* 1 if head dim d has a fused instance */
+int gad_attention_fwd(const gad_attention_args* a, void* stream);
+int gad_attention_bwd(const gad_attention_args* a, void* stream);
+
+/* ------------------------------------------------------------------------------
  * Row softmax (attention probabilities), in place allowed.
  *   fwd: p = softmax(scale * s) per row of length n
  *   bwd: ds = scale * p * (dp - sum(dp * p))

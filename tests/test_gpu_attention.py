@@ -1,0 +1,126 @@
+"""Fused attention kernels (csrc/attention.hip, gad_attention_fwd / gad_attention_bwd) against an fp64 restatement of
+F.scaled_dot_product_attention (reference src/diffusers/models/attention_processor.py:1314-1325) at every head dim the
+reference's models use - 256 (CIFAR, 1 head), 32 (CelebA-HQ), 40 / 80 / 160 (SD-1.x self and cross attention,
+Tk = 77), 192 (pruned CIFAR) - plus ragged lengths, strided q|k|v views, a forced online-softmax rescale, and the
+unfused three-launch route as an independent implementation.  Tolerances: outputs 3e-5, gradients 6e-5 (fp32 products,
+fp32 exp2; O(1) data)."""
+import math
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+dev = torch.device("cuda:0")
+
+
+def rnd(*shape, seed=0, scale=1.0):
+    return torch.randn(*shape, generator=torch.Generator().manual_seed(seed)) * scale
+
+
+def sdpa64(q, k, v, heads):
+    B, Tq, C = q.shape
+    Tk, d = k.shape[1], C // heads
+
+    def split(t, T):
+        return t.view(B, T, heads, d).transpose(1, 2)
+    w = torch.softmax(split(q, Tq) @ split(k, Tk).transpose(-1, -2) / math.sqrt(d), dim=-1)
+    return (w @ split(v, Tk)).transpose(1, 2).reshape(B, Tq, C)
+
+
+CASES = [  # B, Tq, Tk, heads, d
+    (2, 256, 256, 1, 256), (3, 16, 16, 1, 256), (2, 64, 64, 7, 32), (1, 1024, 1024, 2, 32), (2, 256, 256, 8, 40),
+    (2, 64, 77, 4, 40), (1, 100, 77, 2, 80), (2, 64, 64, 2, 160), (1, 70, 77, 8, 160), (2, 256, 256, 1, 192),
+    (1, 33, 95, 3, 16), (1, 130, 50, 2, 64), (1, 64, 64, 1, 96), (1, 48, 48, 1, 128), (1, 40, 40, 1, 224),
+]
+
+
+@pytest.mark.parametrize("B,Tq,Tk,heads,d", CASES)
+def test_fused_attention_forward_backward_vs_fp64(B, Tq, Tk, heads, d):
+    from gad import ops
+    C = heads * d
+    assert ops.fused_attention_ok(d, C)
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.7), rnd(B, Tk, C, seed=2, scale=0.7), rnd(B, Tk, C, seed=3)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o = sdpa64(qd, kd, vd, heads)
+    do = rnd(B, Tq, C, seed=4)
+    o.backward(do.double())
+    gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_core(gq, gk, gv, heads)
+    assert out.grad_fn.__class__.__name__.startswith("AttentionCoreFn")          # the fused route, not the fallback
+    out.backward(do.to(dev))
+    for got, want, tol in ((out, o, 3e-5), (gq.grad, qd.grad, 6e-5), (gk.grad, kd.grad, 6e-5), (gv.grad, vd.grad, 6e-5)):
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item()
+        assert err < tol, err
+    # the three-launch route (batched Q K^T, row softmax, P V) is an independent implementation of the same function
+    uq, uk, uv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    ref = ops.attention_core_unfused(uq, uk, uv, heads)
+    ref.backward(do.to(dev))
+    assert (ref - out).abs().max().item() < 3e-5
+    assert (uq.grad - gq.grad).abs().max().item() < 6e-5 and (uk.grad - gk.grad).abs().max().item() < 6e-5
+
+
+@pytest.mark.parametrize("heads,d,T", [(1, 256, 256), (8, 40, 1024), (7, 32, 64)])
+def test_fused_attention_reads_q_k_v_in_place_from_one_projection(heads, d, T):
+    """q | k | v as column blocks of a [B*T, 3C] projection output (row stride 3C): bit-identical to separate tensors."""
+    from gad import ops
+    B, C = 2, heads * d
+    qkv = rnd(B * T, 3 * C, seed=7, scale=0.6).to(dev)
+    fused = ops.attention_core_qkv_raw(qkv, B, T, C, heads)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B, T, C).contiguous() for i in range(3))
+    with torch.no_grad():
+        sep = ops.attention_core(q, k, v, heads)
+    assert torch.equal(fused, sep)
+    want = sdpa64(q.cpu().double(), k.cpu().double(), v.cpu().double(), heads)
+    assert (fused.cpu().double() - want).abs().max().item() < 3e-5
+
+
+def test_online_softmax_rescale_branch_is_exercised():
+    """cdna_hip_programming.md rule 26: a key deep in the sequence that dominates a query's row forces the running
+    maximum to jump at a late tile (O and l rescaled by ~e^-40); early dominant keys exercise the opposite case."""
+    from gad import ops
+    B, T, heads, d = 1, 256, 2, 40
+    C = heads * d
+    q, k, v = rnd(B, T, C, seed=1, scale=0.3), rnd(B, T, C, seed=2, scale=0.3), rnd(B, T, C, seed=3)
+    k[0, 200, :d] = q[0, 17, :d] * 60.0            # query 17 of head 0 meets its maximum in tile 6
+    k[0, 3, d:] = q[0, 90, d:] * 60.0              # query 90 of head 1 meets it in tile 0
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o = sdpa64(qd, kd, vd, heads)
+    do = rnd(B, T, C, seed=4)
+    o.backward(do.double())
+    gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    out = ops.attention_core(gq, gk, gv, heads)
+    out.backward(do.to(dev))
+    assert (out.detach().cpu().double() - o.detach()).abs().max().item() < 5e-5
+    for got, want in ((gq.grad, qd.grad), (gk.grad, kd.grad), (gv.grad, vd.grad)):
+        scale = max(1.0, want.abs().max().item())
+        assert (got.cpu().double() - want).abs().max().item() < 1e-4 * scale
+
+
+def test_fused_attention_is_bit_reproducible_and_leaves_no_score_tensor():
+    """Two runs give identical bits (no atomics anywhere), and the forward allocates nothing of size B*heads*Tq*Tk."""
+    from gad import ops
+    B, T, heads, d = 4, 1024, 8, 40
+    C = heads * d
+    q, k, v, do = (rnd(B, T, C, seed=s, scale=0.5).to(dev) for s in (1, 2, 3, 4))
+    outs = []
+    for _ in range(2):
+        gq, gk, gv = (t.clone().requires_grad_(True) for t in (q, k, v))
+        torch.cuda.reset_peak_memory_stats(dev)
+        base = torch.cuda.memory_allocated(dev)
+        out = ops.attention_core(gq, gk, gv, heads)
+        peak_fwd = torch.cuda.max_memory_allocated(dev) - base
+        out.backward(do)
+        outs.append((out.detach().clone(), gq.grad.clone(), gk.grad.clone(), gv.grad.clone()))
+    for a, b in zip(*outs):
+        assert torch.equal(a, b)
+    assert peak_fwd < 4 * B * heads * T * T                  # the S tensor alone would be 4*B*heads*T*T bytes = 134 MB
+    assert peak_fwd <= 2 * (4 * B * T * C + 4 * B * heads * T) + (1 << 20)
+
+
+def test_attention_argument_contract():
+    from gad import _capi, ops
+    q = rnd(1, 8, 24, seed=1).to(dev)
+    assert not ops.fused_attention_ok(24, 24) and ops.fused_attention_ok(40, 320) and not ops.fused_attention_ok(40, 322)
+    a = ops._attention_args(q, q, q, q, None, 1, 1, 8, 8, 24, 24, 24, 24, 192, 192, 192)
+    with pytest.raises(_capi.GadError, match="no instance"):
+        _capi.check(_capi.load().gad_attention_fwd(_capi.C.byref(a), ops._stream()), "gad_attention_fwd")

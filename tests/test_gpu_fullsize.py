@@ -211,6 +211,9 @@ def test_full_width_training_step_matches_cpu_oracle():
     for (name, p_ref), p_gpu in zip(ref.named_parameters(), net.parameters()):
         gg = (p_gpu._gad_sink.detach().cpu().double() * coef).flatten()
         gr = p_ref.grad.double().flatten()
+        if name.endswith("to_k.bias"):            # analytically ZERO (a constant added to every key's score leaves the
+            assert gg.norm().item() < 1e-5 and gr.norm().item() < 1e-5    # softmax unchanged): both sides hold rounding noise
+            continue
         rel = ((gg - gr).norm() / gr.norm().clamp_min(1e-30)).item()
         cos = (gg @ gr / (gg.norm() * gr.norm()).clamp_min(1e-30)).item()
         assert rel < 2e-3 and cos > 0.99999, (name, rel, cos)
