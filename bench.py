@@ -1,8 +1,9 @@
 #!/usr/bin/env python3
 """bench.py - Shapley coalitions/hour on the CIFAR-20 DDPM sFT cycle (BASELINE.json configs[1]).
 
-    python bench.py --gpus N --steps K --warmup W
+    python bench.py --gpus N --steps K --warmup W            (N > 1: this process only launches the N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
+    python bench.py --workload cifar20-pruned | sd256 | sd512 [--precision bf16]     (separate, labelled lines)
 
 Workload (config.workload): one coalition of the reference's CIFAR-20 configuration =
 gd_steps=1000 fine-tuning steps at B=128 (noise, antithetic t, add_noise, U-Net fwd, MSE, bwd,
@@ -34,6 +35,14 @@ BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
 
 
+PRUNED_WIDTHS = (96, 192, 192, 192)      # magnitude pruning at ratio 0.3 keeps 32-channel GroupNorm groups whole
+WORKLOADS = {
+    "cifar20": dict(kind="cifar", widths=None),
+    "cifar20-pruned": dict(kind="cifar", widths=PRUNED_WIDTHS),
+    "sd256": dict(kind="sd", latent=32, batch=64),
+    "sd512": dict(kind="sd", latent=64, batch=16),
+}
+
 torch = None       # imported in main(): the launcher parent of `--gpus N` must not import it
 
 
@@ -46,6 +55,11 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
+    ap.add_argument("--workload", choices=list(WORKLOADS), default="cifar20",
+                    help="cifar20 = BASELINE configs[1] (the headline); cifar20-pruned = the same cycle at the pruned widths "
+                         "[96,192,192,192] that unlearn.py:363-367 actually fine-tunes; sd256 / sd512 = one SD-1.x LoRA (r=256) "
+                         "sFT training step at B=64 @ 32x32 / B=16 @ 64x64 latents (train_text_to_image_lora.py:1215-1311)")
+    ap.add_argument("--widths", choices=["full", "pruned"], default=None, help="alias: --widths pruned = --workload cifar20-pruned")
     ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
@@ -60,7 +74,10 @@ def parse():
     ap.add_argument("--stub", action="store_true",
                     help="CPU rehearsal of the launcher / process group / final all_gather with a stub engine over gloo "
                          "(tests only: the line is marked \"stub\": true and is not a measurement)")
-    return ap.parse_args()
+    a = ap.parse_args()
+    if a.widths == "pruned":
+        a.workload = "cifar20-pruned"
+    return a
 
 
 def launch_ranks(a) -> int:
@@ -146,16 +163,61 @@ class SliceRunner:
         return loss
 
 
-def cpu_baseline(engine):
-    """The oracle (pure-PyTorch restatement = what "the reference's CPU path" can mean here: diffusers is
-    not installable) timed on the host cores on a bounded sample: 2 training steps and 3 sampler steps at
-    B=8, scaled per image to one coalition."""
-    from oracle import diffusers_ref as R
+class SDRunner:
+    """One SD-1.x LoRA sFT step per bench step: the body of text_to_image/train_text_to_image_lora.py:1215-1311 as the
+    kept entry point runs it - batch drawn from the HBM-resident latent cache, noise, t ~ U{0..999}, add_noise,
+    UNet2DConditionModel (859.5 M frozen parameters + LoRA r=256 on all 32 attentions = 51.0 M trainable) forward, MSE,
+    backward (LoRA gradients only), clip 1.0, AdamW 3e-4 (cosine), wd 1e-6 (src/ddpm_config.py:624-642)."""
+
+    def __init__(self, dev, latent, batch, seed):
+        import gad
+        from gad.coalition import seed_everything
+        seed_everything(seed)
+        with torch.device(dev):
+            self.net = gad.UNet2DConditionModel(sample_size=latent)
+        self.net.to(dev)
+        lora = self.net.inject_lora(rank=256)
+        with torch.no_grad():                       # `up` starts at zero in a fresh LoRA; a coalition resumes a trained one
+            for n, p in self.net.named_parameters():
+                if n.endswith("lora_layer.up.weight"):
+                    p.normal_(0.0, 0.02)
+        self.n_lora = sum(p.numel() for p in lora)
+        self.n_base = sum(p.numel() for p in self.net.parameters()) - self.n_lora
+        sched = gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+        self.trainer = gad.FusedTrainer(self.net, sched, None, lr=3e-4, weight_decay=1e-6, adamw=True, max_grad_norm=1.0,
+                                        params=lora, lr_schedule=gad.lr_lambda("cosine", 200, 0))
+        g = torch.Generator(device=dev).manual_seed(seed)
+        n_cache = 8 * batch                          # latent cache + per-sample text embeddings, resident in HBM
+        self.latents = torch.randn(n_cache, 4, latent, latent, device=dev, generator=g) * 0.8
+        self.text = torch.randn(n_cache, 77, 768, device=dev, generator=g) * 0.5
+        self.batch, self.dev = batch, dev
+        self.perm, self.pos = torch.randperm(n_cache, device=dev), 0
+
+    def slice(self):
+        if self.pos + self.batch > self.perm.numel():
+            self.perm, self.pos = torch.randperm(self.perm.numel(), device=self.dev), 0
+        sel = self.perm[self.pos:self.pos + self.batch]
+        self.pos += self.batch
+        x0 = self.latents.index_select(0, sel)
+        noise = torch.randn_like(x0)
+        ts = torch.randint(0, 1000, (self.batch,), device=self.dev).long()
+        return self.trainer.step(x0, noise, ts, self.text.index_select(0, sel))
+
+
+def _threads():
     try:
         threads = len(os.sched_getaffinity(0))
     except AttributeError:
         threads = os.cpu_count() or 1
-    threads = max(1, min(threads, int(os.environ.get("GAD_CPU_THREADS", "16"))))   # the GPU box grants a 16-CPU share
+    return max(1, min(threads, int(os.environ.get("GAD_CPU_THREADS", "16"))))   # the GPU box grants a 16-CPU share
+
+
+def cpu_baseline(engine):
+    """The oracle (pure-PyTorch restatement = what "the reference's CPU path" can mean here: diffusers is
+    not installable) timed on the host cores on a bounded sample: 2 training steps and 3 sampler steps at
+    B=16, scaled per image to one coalition."""
+    from oracle import diffusers_ref as R
+    threads = _threads()
     torch.set_num_threads(threads)
     log(f"cpu_baseline: oracle on {threads} threads")
     torch.manual_seed(0)
@@ -163,7 +225,7 @@ def cpu_baseline(engine):
     opt = torch.optim.Adam(net.parameters(), lr=1e-4)
     ema = R.EMAModel(net.parameters())
     sch = R.DDPMScheduler(**engine.config["scheduler_config"])
-    B = 8
+    B = 16
     g = torch.Generator().manual_seed(0)
     x, n = torch.rand(B, 3, 32, 32, generator=g) * 2 - 1, torch.randn(B, 3, 32, 32, generator=g)
     t = R.antithetic_timesteps(torch.randint(0, 1000, (B // 2 + 1,), generator=g), 1000, B)
@@ -186,6 +248,49 @@ def cpu_baseline(engine):
             "sample": f"oracle (PyTorch-CPU fp32 restatement) on {threads} threads: 2 train steps + 3 DDIM sampler "
                       f"steps at B={B}, scaled per image to 1000x128 train images + 10240x100 sampler images",
             "train_s_per_image": t_train_img, "sampler_s_per_image": t_fwd_img}
+
+
+def cpu_baseline_sd(latent, batch):
+    """The SD oracle (oracle/sd_unet_ref.py, full SD-1.x width, LoRA r=256 on every attention projection) on the host
+    cores: 1 warm-up + 2 LoRA training steps at B=1, scaled per image to the workload's batch."""
+    from oracle import diffusers_ref as R
+    from oracle.sd_unet_ref import CrossAttention, UNet2DConditionModel
+    threads = _threads()
+    torch.set_num_threads(threads)
+    log(f"cpu_baseline: SD oracle on {threads} threads")
+    torch.manual_seed(0)
+    net = UNet2DConditionModel(sample_size=latent)
+    for p in net.parameters():
+        p.requires_grad_(False)
+    lora = []
+    for m in net.modules():
+        if isinstance(m, CrossAttention):
+            for lin in (m.to_q, m.to_k, m.to_v, m.to_out[0]):
+                layer = R.LoRALinearLayer(lin.in_features, lin.out_features, rank=256)
+                torch.nn.init.normal_(layer.up.weight, std=0.02)
+                lin.set_lora_layer(layer)
+                lora += list(layer.parameters())
+    opt = torch.optim.AdamW(lora, lr=3e-4, weight_decay=1e-6)
+    sch = R.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+    g = torch.Generator().manual_seed(0)
+    x, n = torch.randn(1, 4, latent, latent, generator=g) * 0.8, torch.randn(1, 4, latent, latent, generator=g)
+    ctx, t = torch.randn(1, 77, 768, generator=g) * 0.5, torch.tensor([500])
+
+    def step():
+        opt.zero_grad()
+        loss = torch.nn.functional.mse_loss(net(sch.add_noise(x, n, t), t, ctx).sample, n)
+        loss.backward()
+        torch.nn.utils.clip_grad_norm_(lora, 1.0)
+        opt.step()
+    step()
+    t0 = time.time()
+    for _ in range(2):
+        step()
+    s_img = (time.time() - t0) / 2
+    return {"value": 1.0 / (s_img * batch), "unit": "steps/s", "cores": threads, "kind": "port",
+            "sample": f"SD oracle (PyTorch-CPU fp32 restatement, SD-1.x widths, LoRA r=256) on {threads} threads: 2 LoRA "
+                      f"training steps at B=1 on {latent}x{latent} latents, scaled per image to B={batch}",
+            "train_s_per_image": s_img}
 
 
 def stub_rank(a, rank, world):
@@ -229,6 +334,39 @@ def stub_rank(a, rank, world):
         dist.destroy_process_group()
 
 
+def kernel_report(prof, dt, peak_tf, precision, workload):
+    """roofline of the dominant kernel family + per-family table, from the live HIP-event brackets."""
+    summ = prof.summary()
+    kern = {f"{k[0]}_t{k[1]}_sk{k[2]}_v{k[3]}": dict(launches=v["launches"], avg_us=v["ms"] / v["launches"] * 1e3,
+                                                   tflops=v["flops"] / v["ms"] / 1e9) for k, v in summ.items()}
+    dom_key = max(summ, key=lambda k: summ[k]["ms"])
+    d = summ[dom_key]
+    nm = dom_key[0]
+    if nm.startswith("attn_"):
+        kname = f"attn_{'fwd' if 'fwd' in nm else 'bwd_dq + attn_bwd_dkv'}_f32_kernel<{nm.rsplit('_d', 1)[1]}> ({nm}, Tq={dom_key[1]}, Tk={dom_key[2]})"
+    elif "_patch" in nm:      # the name rocprofv3 shows for it
+        wo = int(nm.rsplit("_w", 1)[1])
+        kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{wo}, {2 if wo == 8 else 1}> ({nm})"
+    else:
+        kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
+    traffic, traffic_src = None, None
+    pmc = os.path.join(ROOT, "profiles", "pmc_summary.json" if workload == "cifar20" else f"pmc_summary_{workload}.json")
+    if precision == "f32" and os.path.exists(pmc):
+        j = json.load(open(pmc))
+        traffic = j.get("dominant_kernel_hbm_bytes_per_launch")
+        traffic_src = (f"STORED counter pass, not measured in this run: profiles/{os.path.basename(pmc)} "
+                       f"({j.get('bench_workload', {}).get('source', j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE'))})")
+    roof = {"bound": "mfma", "kernel": kname, "achieved": d["flops"] / d["ms"] / 1e9, "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": d["flops"] / d["ms"] / 1e9 / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
+            "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
+            "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
+            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "share_of_step_time": d["ms"] / (dt * 1e3)}
+    all_ms = sum(v["ms"] for v in summ.values())
+    all_fl = sum(v["flops"] for v in summ.values())
+    table = {"tflops": all_fl / all_ms / 1e9, "share_of_step_time": all_ms / (dt * 1e3), "by_instance": kern}
+    return roof, table, all_fl
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -269,18 +407,28 @@ def main():
     from gad import ops
     from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
 
+    wl = WORKLOADS[a.workload]
     gad.set_operand_precision(a.precision)
     peak_tf = F32_MFMA_PEAK_TF if a.precision == "f32" else BF16_MFMA_PEAK_TF
-    log(f"rank {rank}/{world} on {dev}: building engine")
-    engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
-                             sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS)
+    log(f"rank {rank}/{world} on {dev}: workload {a.workload}, building")
+    engine = None
+    if wl["kind"] == "cifar":
+        over = dict(block_out_channels=tuple(wl["widths"])) if wl["widths"] else None
+        engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
+                                 sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS, unet_overrides=over)
+        n_groups = engine.n_groups
+    else:
+        if a.full_coalition:
+            print("bench.py: --full-coalition is a CIFAR-workload option", file=sys.stderr)
+            sys.exit(2)
+        n_groups = 258                                                  # artists (src/ddpm_config.py: DatasetStats)
 
     def barrier():
         if world > 1:
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    prof = None
+    prof, dt_train, n_tr = None, 0.0, 0
     if a.full_coalition:
         for i in range(a.warmup):
             engine.run_coalition(10_000 + rank)
@@ -291,8 +439,8 @@ def main():
         dt = time.time() - t0
         units = a.steps * world                                         # coalitions
     else:
-        run = SliceRunner(engine, removal_seed=rank)
-        log("slice runner ready; warm-up")
+        run = SliceRunner(engine, removal_seed=rank) if wl["kind"] == "cifar" else SDRunner(dev, wl["latent"], wl["batch"], seed=rank)
+        log("runner ready; warm-up")
         for _ in range(a.warmup):
             run.slice()
         log("timed region")
@@ -307,20 +455,26 @@ def main():
         dt = time.time() - t0
         log(f"timed region done: {dt:.2f}s for {a.steps} steps")
         ops.PROFILER = None
-        units = a.steps * world / float(GD_STEPS)
-        # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
-        n_tr = 0 if a.no_train_rate else 10
-        barrier()
-        t1 = time.time()
-        for _ in range(n_tr):
-            run.train_step()
-        barrier()
-        dt_train = time.time() - t1
-        recs = [CoalitionRecord(rank, len(run.loader.x), 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
+        if wl["kind"] == "cifar":
+            units = a.steps * world / float(GD_STEPS)
+            # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
+            n_tr = 0 if a.no_train_rate else 10
+            barrier()
+            t1 = time.time()
+            for _ in range(n_tr):
+                run.train_step()
+            barrier()
+            dt_train = time.time() - t1
+            n_rem = len(run.loader.x)
+        else:
+            units = a.steps * world                                     # LoRA training steps
+            n_rem = run.latents.shape[0]
+        recs = [CoalitionRecord(rank, n_rem, 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
     # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
+    ranks_seen = [0]
     if world > 1:
         cdev = dev if backend == "nccl" else torch.device("cpu")
-        packed = gather_records([r.pack(engine.n_groups) for r in recs], CoalitionRecord.NSCALAR + engine.n_groups, cdev)
+        packed = gather_records([r.pack(n_groups) for r in recs], CoalitionRecord.NSCALAR + n_groups, cdev)
         assert len(packed) == world * len(recs)
         ids = [torch.zeros(1, device=cdev, dtype=torch.int64) for _ in range(world)]
         dist.all_gather(ids, torch.tensor([rank], device=cdev, dtype=torch.int64))     # device all_gather of the rank ids
@@ -328,76 +482,59 @@ def main():
         tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
         dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
         dt = float(tmax.item())
-        if not a.full_coalition:
+        if n_tr:
             tmax.fill_(dt_train)
             dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
             dt_train = float(tmax.item())
-    value = units / (dt / 3600.0)
 
     if rank == 0:
-        out = {
-            "metric": "shapley_coalitions_per_hour", "value": value, "unit": "coalitions/hour",
-            "n_gpus": dist.get_world_size() if world > 1 else 1,
-            "steps": a.steps, "warmup": a.warmup, "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True,
-            "scaling": "weak", "vs_baseline": None,
-            "dtype": "f32" if a.precision == "f32" else "bf16 operands, f32 accumulate/storage (NOT the reference default)",
-            "data": "synthetic",
-            "config": {"workload": ("CIFAR-20 DDPM sFT coalition (BASELINE configs[1]): gd_steps=1000 @B=128 + 10240 samples"
-                                    " x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel 35.75M params fp32" + ("" if a.precision == "f32" else " storage, bf16 MFMA operands") + "; "
-                                    + ("step = one complete coalition" if a.full_coalition else
-                                       "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024")),
-                       "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"},
-        }
+        f32 = a.precision == "f32"
+        dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
+        if wl["kind"] == "cifar":
+            widths = list(wl["widths"]) if wl["widths"] else [128, 256, 256, 256]
+            nparam = sum(p.numel() for p in run.model.parameters()) if not a.full_coalition else None
+            out = {"metric": "shapley_coalitions_per_hour", "value": units / (dt / 3600.0), "unit": "coalitions/hour"}
+            workload = (f"CIFAR-20 DDPM sFT coalition (BASELINE configs[1]{'' if not wl['widths'] else ', PRUNED widths - the shape unlearn.py:363-367 fine-tunes'}): "
+                        f"gd_steps=1000 @B=128 + 10240 samples x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel widths {widths}"
+                        + (f" {nparam / 1e6:.2f}M params" if nparam else "") + " fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; "
+                        + ("step = one complete coalition" if a.full_coalition else "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"))
+            config = {"workload": workload, "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
+        else:
+            out = {"metric": "sd_lora_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
+            config = {"workload": (f"SD-1.x LoRA sFT training step (BASELINE configs[3]/[4] body, train_text_to_image_lora.py:1215-1311): "
+                                   f"B={wl['batch']} x 4x{wl['latent']}x{wl['latent']} latents ({8 * wl['latent']}x{8 * wl['latent']} images), ctx [B,77,768], "
+                                   f"UNet2DConditionModel {run.n_base / 1e6:.1f}M frozen + LoRA r=256 on 32 attentions ({run.n_lora / 1e6:.1f}M trainable), "
+                                   f"AdamW + clip, fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; step = one training step"),
+                      "images_per_s": units * wl["batch"] / dt, "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
+        out.update({"n_gpus": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
+                    "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                    "dtype": dtype, "data": "synthetic", "config": config})
         if world > 1:
             out["rccl_ranks_seen"] = ranks_seen                       # from the collective, not from the flag
             out["dist_backend"] = dist.get_backend()
-        # published reference figure for this metric: 3.27 coalitions per GPU-hour on an unnamed single GPU
-        # (empirical_verification.ipynb:128,132) -> per-GPU ratio
-        out["vs_baseline"] = value / world / 3.27 if a.precision == "f32" else None   # the published figure is fp32
-        if a.gd_steps != GD_STEPS or a.n_samples != N_SAMPLES:                          # a reduced workload is not the metric
-            out["config"]["workload"] += f" -- OVERRIDDEN: gd_steps={a.gd_steps}, n_samples={a.n_samples} (not the BASELINE workload)"
+        # published reference figures (empirical_verification.ipynb:128,132): 3.27 coalitions per GPU-hour
+        # (fp32, pruned CIFAR model, unnamed GPU); 0.74 SD LoRA steps/s at B=64 @256^2 (fp16, RTX 6000) -> per-GPU ratios
+        if wl["kind"] == "cifar" and f32:
+            out["vs_baseline"] = out["value"] / world / 3.27
+        if a.workload == "sd256" and not f32:
+            out["vs_baseline"] = out["value"] / world / 0.74
+        if wl["kind"] == "cifar" and (a.gd_steps != GD_STEPS or a.n_samples != N_SAMPLES):      # a reduced workload is not the metric
+            config["workload"] += f" -- OVERRIDDEN: gd_steps={a.gd_steps}, n_samples={a.n_samples} (not the BASELINE workload)"
             out["vs_baseline"] = None
-        if not a.full_coalition:
-            train_flop = 3 * UNET_GFLOP_PER_IMG * 1e9 * TRAIN_B
-            samp_flop = UNET_GFLOP_PER_IMG * 1e9 * N_SAMPLES * DDIM_STEPS / GD_STEPS
-            out["unet_tflops_per_gpu"] = (train_flop + samp_flop) * a.steps / dt / 1e12
-            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
-            if n_tr:
-                out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
-                                                 "ms_per_step": dt_train / n_tr * 1e3,
-                                                 "tflops_per_gpu": train_flop * n_tr / dt_train / 1e12,
-                                                 "reference": 3.81}                   # 3.81 steps/s, 1 GPU
         if prof is not None:
             torch.cuda.synchronize(dev)
-            summ = prof.summary()
-            kern = {f"{k[0]}_t{k[1]}_sk{k[2]}_v{k[3]}": dict(launches=v["launches"], avg_us=v["ms"] / v["launches"] * 1e3,
-                                                           tflops=v["flops"] / v["ms"] / 1e9) for k, v in summ.items()}
-            dom_key = max(summ, key=lambda k: summ[k]["ms"])
-            d = summ[dom_key]
-            traffic = None
-            pmc = os.path.join(ROOT, "profiles", "pmc_summary.json")
-            if os.path.exists(pmc):
-                traffic = json.load(open(pmc)).get("dominant_kernel_hbm_bytes_per_launch")
-            nm = dom_key[0]
-            if "_patch" in nm:      # the name rocprofv3 shows for it
-                wo = int(nm.rsplit("_w", 1)[1])
-                kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{wo}, {2 if wo == 8 else 1}> ({nm})"
-            else:
-                kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
-            out["roofline"] = {"bound": "mfma", "kernel": kname,
-                               "achieved": d["flops"] / d["ms"] / 1e9, "peak": peak_tf, "unit": "TFLOP/s",
-                               "frac": d["flops"] / d["ms"] / 1e9 / peak_tf,
-                               "traffic": traffic if a.precision == "f32" else None,
-                               "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
-                               "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-                               "algorithmic_bytes_per_launch": d["bytes"] / d["launches"],
-                               "share_of_step_time": d["ms"] / (dt * 1e3)}
-            all_ms = sum(v["ms"] for v in summ.values())
-            all_fl = sum(v["flops"] for v in summ.values())
-            out["contraction_kernels"] = {"tflops": all_fl / all_ms / 1e9, "share_of_step_time": all_ms / (dt * 1e3),
-                                          "by_instance": kern}
+            out["roofline"], out["contraction_kernels"], all_fl = kernel_report(prof, dt, peak_tf, a.precision, a.workload)
+            out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs of every contraction / attention launch
+            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
+        elif a.workload == "cifar20" and not a.full_coalition:
+            fl = (3 * UNET_GFLOP_PER_IMG * TRAIN_B + UNET_GFLOP_PER_IMG * N_SAMPLES * DDIM_STEPS / GD_STEPS) * 1e9
+            out["unet_tflops_per_gpu"] = fl * a.steps / dt / 1e12
+            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf
+        if n_tr:
+            out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
+                                             "ms_per_step": dt_train / n_tr * 1e3, "reference": 3.81}   # 3.81 steps/s, 1 GPU
         if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(engine)
+            out["cpu_baseline"] = cpu_baseline(engine) if wl["kind"] == "cifar" else cpu_baseline_sd(wl["latent"], wl["batch"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

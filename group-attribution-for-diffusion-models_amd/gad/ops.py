@@ -204,6 +204,19 @@ class GemmProfiler:
         nbytes = 4.0 * max(1, batch) * (a_elems + b_elems + a.M * a.N + extra)
         self.records.append((key, 2.0 * a.M * a.N * a.K * max(1, batch), nbytes, s, e))
 
+    def attention(self, fn, a, what):
+        """Bracket a fused attention launch.  Algorithmic FLOPs: forward 4 B h Tq Tk d (Q K^T and P V), backward
+        10 B h Tq Tk d (the five products of the minimal scheme; the recomputing kernels execute seven).  Bytes: q, k,
+        v, o once forward; those plus dO, dq, dk, dv backward."""
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        check(fn(C.byref(a), _stream()), f"gad_attention_{what}")
+        e.record()
+        unit = float(a.B) * a.heads * a.Tq * a.Tk * a.d
+        qb, kb = 4.0 * a.B * a.Tq * a.heads * a.d, 4.0 * a.B * a.Tk * a.heads * a.d
+        flops, nbytes = (4.0 * unit, 2 * qb + 2 * kb) if what == "fwd" else (10.0 * unit, 4 * qb + 4 * kb)
+        self.records.append(((f"attn_{what}_d{a.d}", a.Tq, a.Tk, 4), flops, nbytes, s, e))
+
     def summary(self):
         """{key: dict(launches, ms, flops)} - call after a device synchronize."""
         out = {}
@@ -622,7 +635,10 @@ def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=Tru
     o = torch.empty((Bn, Tq, heads * d), device=q.device, dtype=torch.float32)
     lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
     a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv)
-    check(_capi.load().gad_attention_fwd(C.byref(a), _stream()), "gad_attention_fwd")
+    if PROFILER is not None:
+        PROFILER.attention(_capi.load().gad_attention_fwd, a, "fwd")
+    else:
+        check(_capi.load().gad_attention_fwd(C.byref(a), _stream()), "gad_attention_fwd")
     return o, lse
 
 
@@ -659,7 +675,10 @@ class AttentionCoreFn(torch.autograd.Function):
         a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq
         a.stride_do = a.stride_dq = Tq * Cq
         a.stride_dk = a.stride_dv = Tk * Cq
-        check(_capi.load().gad_attention_bwd(C.byref(a), _stream()), "gad_attention_bwd")
+        if PROFILER is not None:
+            PROFILER.attention(_capi.load().gad_attention_bwd, a, "bwd")
+        else:
+            check(_capi.load().gad_attention_bwd(C.byref(a), _stream()), "gad_attention_bwd")
         return dq, dk, dv, None
 
 
