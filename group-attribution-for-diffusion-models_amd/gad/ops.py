@@ -736,9 +736,17 @@ class UnfusedAttentionCoreFn(torch.autograd.Function):
 
 def attention_core(q, k, v, heads):
     d = q.shape[-1] // heads
-    if fused_attention_ok(d, q.shape[-1]):
+    # Training at one wide head over a short sequence (CIFAR: d = 256 / 192, T <= 256) keeps the three-launch route: S is a
+    # few MB there, and the recomputing backward (7 products, 1 wave per SIMD at d >= 192) measured 0.48 ms against
+    # 0.32 ms (tools/bench_attention.py).  Everything else - every sampling forward, CelebA's and SD's heads - is fused.
+    wide_short = torch.is_grad_enabled() and d > 160 and q.shape[1] * k.shape[1] <= 256 * 256
+    if fused_attention_ok(d, q.shape[-1]) and not wide_short:
         return AttentionCoreFn.apply(q, k, v, heads)
     return UnfusedAttentionCoreFn.apply(q, k, v, heads)
+
+
+def attention_core_fused(q, k, v, heads):
+    return AttentionCoreFn.apply(q, k, v, heads)
 
 
 def attention_core_unfused(q, k, v, heads):

@@ -45,8 +45,7 @@ def test_fused_attention_forward_backward_vs_fp64(B, Tq, Tk, heads, d):
     do = rnd(B, Tq, C, seed=4)
     o.backward(do.double())
     gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
-    out = ops.attention_core(gq, gk, gv, heads)
-    assert out.grad_fn.__class__.__name__.startswith("AttentionCoreFn")          # the fused route, not the fallback
+    out = ops.attention_core_fused(gq, gk, gv, heads)
     out.backward(do.to(dev))
     for got, want, tol in ((out, o, 3e-5), (gq.grad, qd.grad, 6e-5), (gk.grad, kd.grad, 6e-5), (gv.grad, vd.grad, 6e-5)):
         err = (got.detach().cpu().double() - want.detach()).abs().max().item()
@@ -88,7 +87,7 @@ def test_online_softmax_rescale_branch_is_exercised():
     do = rnd(B, T, C, seed=4)
     o.backward(do.double())
     gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
-    out = ops.attention_core(gq, gk, gv, heads)
+    out = ops.attention_core_fused(gq, gk, gv, heads)
     out.backward(do.to(dev))
     assert (out.detach().cpu().double() - o.detach()).abs().max().item() < 5e-5
     for got, want in ((gq.grad, qd.grad), (gk.grad, kd.grad), (gv.grad, vd.grad)):
