@@ -346,7 +346,13 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
         kname = f"attn_{'fwd' if 'fwd' in nm else 'bwd_dq + attn_bwd_dkv'}_f32_kernel<{nm.rsplit('_d', 1)[1]}> ({nm}, Tq={dom_key[1]}, Tk={dom_key[2]})"
     elif "_patch" in nm:      # the name rocprofv3 shows for it
         wo = int(nm.rsplit("_w", 1)[1])
-        kname = f"conv3x3_patch_{'bf16' if 'bf16' in nm else 'f32'}_kernel<{wo}, {2 if wo == 8 else 1}> ({nm})"
+        ni = {8: 2, 4: 8}.get(wo, 1)
+        if "wgrad" in nm:
+            kname = f"wgrad3x3_patch_f32_kernel<{wo}> ({nm})"
+        elif "bf16" in nm:
+            kname = f"conv3x3_patch_bf16_kernel<{wo}, {ni}> ({nm})"
+        else:
+            kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {dom_key[1]}> ({nm}, {dom_key[1]}-channel tiles)"
     else:
         kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
     traffic, traffic_src = None, None

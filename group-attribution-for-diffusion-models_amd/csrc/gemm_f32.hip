@@ -31,8 +31,6 @@
 //   gemm_bf16_kernel            the generic engine with bf16 operands (v_mfma_f32_32x32x16_bf16, fp32 accumulate)
 //   conv3x3_patch_bf16_kernel   the patch convolution with bf16 operands (optionally a bf16 weight copy by LDS-DMA)
 //   splitk_reduce_kernel        deterministic reduction + fused epilogue of any split launch
-#include <stdlib.h>
-
 #include "gad_common.h"
 
 namespace {
@@ -508,19 +506,19 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) go to C with alpha, bias[n], rowadd[m / rows_per_group][n] and
 // residual[m][n] fused - or, for a split of a split-K launch (direct = false), raw to the workspace slab.
 // ------------------------------------------------------------------------------------
-template <int TM, int TN, int BM, int BN>
+template <int TM, int TN, int BM, int BN, int WM = 2, int WN = 2>
 __device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc)[TM][TN], int row0, int col0, int wm, int wn,
                                             int h, int l31, float* C, int ldc, const float* R, bool direct) {
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
-    int n = col0 + wn * (BN / 2) + j * 32 + l31;
+    int n = col0 + wn * (BN / WN) + j * 32 + l31;
     if (n >= p.N) continue;
     float bias = (direct && p.bias) ? p.bias[n] : 0.f;
 #pragma unroll
     for (int i = 0; i < TM; ++i) {
 #pragma unroll
       for (int e = 0; e < 16; ++e) {
-        int m = row0 + wm * (BM / 2) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+        int m = row0 + wm * (BM / WM) + i * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
         if (m >= p.M) continue;
         float v = acc[i][j][e];
         if (direct) {
@@ -1025,9 +1023,12 @@ constexpr int PLD = BK + 4;
 // DG = true: the data gradient of the same convolution - rows are input pixels, the patch holds dy, tap (r, s) reads it at
 // (ih + 1 - r, iw + 1 - s) (mirrored shifts) and the weights W[co][r][s][ci] stream as B[k = (tap, co)][n = ci]
 // ([k][n] tiles, read like the generic dgrad).
-template <int W, int NI, bool DG>
+// BN_ = 128: 2 x 2 waves of 64 x 64 (the default).  BN_ = 96 / 160: 4 x 1 waves of 32 x BN_ - output-channel counts that
+// 128 would pad by a quarter or more (pruned widths 96 / 192 / 288, CelebA 672, SD 320) run without padding.
+template <int W, int NI, bool DG, int BN_ = 128>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevArgs p) {
-  constexpr int BM = 128, BN = 128, TM = 2, TN = 2;
+  constexpr int BM = 128, BN = BN_, WM = BN_ == 128 ? 2 : 4, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
+  static_assert(!DG || BN_ == 128, "the data-gradient form streams [k][n] weight tiles: 128 columns only");
   // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
   // each with its own halo'd sub-patch.
   constexpr int TR = BM / (W * NI), PW = W + 2, PR = TR + 2, NPIX = NI * PR * PW;
@@ -1053,7 +1054,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   const int c_end = min(C / BK, c_begin + p.ktiles_per_split);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+  const int wm = wave / WN, wn = wave % WN, h = lane >> 5, l31 = lane & 31;
 
   int poff[PSLOTS];
   unsigned pvalid = 0;
@@ -1092,7 +1093,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   int abase[TM];
 #pragma unroll
   for (int i = 0; i < TM; ++i) {
-    int m = wm * (BM / 2) + i * 32 + l31;
+    int m = wm * (BM / WM) + i * 32 + l31;
     abase[i] = ((m / (TR * W)) * (PR * PW) + ((m / W) % TR) * PW + (m % W)) * PLD + 4 * h;
   }
 
@@ -1123,7 +1124,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
     for (int i = 0; i < TM; ++i) fa[0][i] = *reinterpret_cast<const f32x4*>(pa + abase[i]);
 #pragma unroll
-    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<BL::KC, BN>(lb, wn * (BN / WN) + j * 32 + l31, 0, h);
 #pragma unroll
     for (int g = 0; g < 4; ++g) {
 #pragma unroll
@@ -1138,7 +1139,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(pa + abase[i] + 8 * (g + 1));
 #pragma unroll
-          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<BL::KC, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<BL::KC, BN>(lb, wn * (BN / WN) + j * 32 + l31, g + 1, h);
         }
 #pragma unroll
         for (int q = 0; q < TM * TN; ++q) {
@@ -1161,7 +1162,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
   const float* R = direct ? p.residual : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, Cp, ldc, R, direct);
+  store_block<TM, TN, BM, BN, WM, WN>(p, acc, row0, col0, wm, wn, h, l31, Cp, ldc, R, direct);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1420,7 +1421,6 @@ static bool use_bf16(const gad_gemm_args* a) {
 // 3x3 / stride 1 / pad 1 forward conv whose 128-pixel tiles are whole rows of one image: the LDS-patch kernel applies
 static bool patch_conv_geom(const gad_gemm_args* a, bool dgrad = false) {
   const gad_conv_geom& g = a->g;
-  const char* off = getenv("GAD_NO_PATCH_CONV");
   const bool modes = dgrad ? (a->a_mode == GAD_A_CONVT && a->b_mode == GAD_B_WDGRAD && !g.upsample)
                            : (a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC);
   return pick_vec(a) == 4 && modes && !a->A2 && g.KH == 3 && g.KW == 3 &&
@@ -1428,20 +1428,31 @@ static bool patch_conv_geom(const gad_gemm_args* a, bool dgrad = false) {
          g.Wo == (g.upsample ? 2 * g.W : g.W) &&
          (((g.Wo == 64 || g.Wo == 32 || g.Wo == 16) && (g.Ho * g.Wo) % 128 == 0) ||
           ((g.Wo == 8 || g.Wo == 4) && g.Ho == g.Wo && a->M % 128 == 0)) && g.C % BK == 0 && a->tile_hint != 2 && a->splitk_hint <= 1 &&
-         (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(off && atoi(off));
+         (a->batch <= 1) && (long)a->M * g.ldx < (1L << 31) && !(a->flags & GAD_GEMM_NO_PATCH);
 }
 static bool use_patch_conv(const gad_gemm_args* a) { return use_bf16(a) && patch_conv_geom(a); }
 // fp32 patch kernel: its own plan - 128-pixel tiles, split-K over the 32-channel chunks when the tiles alone cannot fill
 // the 512 workgroup slots (small maps); launches too small even then stay on the generic kernel
 struct PatchPlan {
-  int splitk, chunks_per_split;
+  int splitk, chunks_per_split, bn;
   long blocks;
 };
+// output-channel tile of the fp32 forward patch kernel: the one of {128, 160, 96} that pads N least (ties: the wider)
+static int patch_bn(int N) {
+  int best = 128;
+  long pad = gad_ceil_div(N, 128) * 128;
+  const int cand[2] = {160, 96};
+  for (int bn : cand) {
+    const long pd = gad_ceil_div(N, bn) * bn;
+    if (pd < pad) { pad = pd; best = bn; }
+  }
+  return best;
+}
 static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
-  const char* on = getenv("GAD_PATCH_CONV_F32");
-  if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true)) || (on && !atoi(on))) return false;
+  if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true))) return false;
   if (a->N < 64) return false;               // conv_out (3 output channels): a 128-wide tile would be 98 % padding
-  const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, 128);
+  pp->bn = patch_conv_geom(a) ? patch_bn(a->N) : 128;
+  const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, pp->bn);
   const int nchunks = a->g.C / BK;
   long sk = 1;
   if (tiles < 384) {
@@ -1459,8 +1470,7 @@ static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
 // 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible)
 static int wgrad_patch_splits(const gad_gemm_args* a) {
   const gad_conv_geom& g = a->g;
-  const char* off = getenv("GAD_NO_PATCH_CONV");
-  if (off && atoi(off)) return 0;
+  if (a->flags & GAD_GEMM_NO_PATCH) return 0;
   if (use_bf16(a) || pick_vec(a) != 4 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV) return 0;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return 0;
   if (g.Ho != (g.upsample ? 2 * g.H : g.H) || g.Wo != (g.upsample ? 2 * g.W : g.W)) return 0;
@@ -1468,8 +1478,7 @@ static int wgrad_patch_splits(const gad_gemm_args* a) {
   if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
   if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
   const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, 128) * (g.C / BK);
-  const char* tb = getenv("GAD_WGRAD_BLOCKS");
-  long sp = (tb ? atoi(tb) : 512) / groups;   // default: one round of 2 workgroups per CU
+  long sp = 512 / groups;                 // one round of 2 workgroups per CU
   if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
   if (sp < 1) sp = 1;
   return (int)sp;
@@ -1488,10 +1497,19 @@ extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
   GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
-  Plan pl = make_plan(a);
-  *tile = pl.bm;
-  *splitk = pl.splitk;
   *vec = pick_vec(a);
+  PatchPlan pp;
+  if (int sp = wgrad_patch_splits(a)) {          // patch weight gradient: 128 output channels x pixel splits
+    *tile = 128;
+    *splitk = sp;
+  } else if (!use_bf16(a) && use_patch_conv_f32(a, &pp)) {   // patch forward / dgrad: 128 pixels x bn channels
+    *tile = pp.bn;
+    *splitk = pp.splitk;
+  } else {
+    Plan pl = make_plan(a);
+    *tile = pl.bm;
+    *splitk = pl.splitk;
+  }
   return 0;
 }
 
@@ -1566,13 +1584,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   if (a->residual) GAD_CHECK(a->ldr >= a->N, "gad_gemm: bad residual stride");
   GAD_CHECK(a->ldc >= a->N, "gad_gemm: ldc < N");
 
-  Plan pl = make_plan(a);
   long batch = a->batch > 0 ? a->batch : 1;
-  GAD_CHECK(pl.nblocks > 0 && pl.nblocks < (1L << 31), "gad_gemm: grid too large");
-  if (pl.splitk > 1) {
-    int64_t need = (int64_t)batch * pl.splitk * a->M * a->N * (int64_t)sizeof(float);
-    GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: split-K workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
-  }
 
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
@@ -1591,12 +1603,12 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   d.fdRpg = make_fastdiv(a->rows_per_group > 0 ? a->rows_per_group : 1);
   d.taps = a->g.KH * a->g.KW;
   d.fdTaps = make_fastdiv(d.taps > 0 ? d.taps : 1);
-  d.kperm = (convA && d.taps > 1 && a->g.C % BK == 0 && !(getenv("GAD_NO_KPERM") && atoi(getenv("GAD_NO_KPERM")))) ? 1 : 0;
+  d.kperm = (convA && d.taps > 1 && a->g.C % BK == 0 && !(a->flags & GAD_GEMM_TAP_MAJOR_K)) ? 1 : 0;
   d.alpha = a->alpha;
   d.bias = a->bias; d.rowadd = a->rowadd; d.rows_per_group = a->rows_per_group > 0 ? a->rows_per_group : 1;
   d.ld_rowadd = a->ld_rowadd; d.residual = a->residual; d.ldr = a->ldr;
   d.ws = (float*)a->ws;
-  d.tiles_m = pl.tiles_m; d.tiles_n = pl.tiles_n; d.splitk = pl.splitk; d.ktiles_per_split = pl.ktiles_per_split;
+  d.tiles_m = d.tiles_n = d.splitk = d.ktiles_per_split = 1;
 
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
@@ -1648,7 +1660,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   PatchPlan pp;
   if (use_patch_conv_f32(a, &pp)) {
     d.tiles_m = (int)gad_ceil_div(a->M, 128);
-    d.tiles_n = (int)gad_ceil_div(a->N, 128);
+    d.tiles_n = (int)gad_ceil_div(a->N, pp.bn);
     d.splitk = pp.splitk;
     d.ktiles_per_split = pp.chunks_per_split;
     if (pp.splitk > 1) {
@@ -1657,10 +1669,12 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     }
     dim3 grid((unsigned)pp.blocks), block(NTHREADS);
     const bool dg = am == GAD_A_CONVT;
-#define GAD_PATCH(W_, NI_)                                                                              \
-    do {                                                                                                \
-      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, true>), grid, block, 0, st, d);     \
-      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, false>), grid, block, 0, st, d);       \
+#define GAD_PATCH(W_, NI_)                                                                                      \
+    do {                                                                                                        \
+      if (dg) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, true>), grid, block, 0, st, d);             \
+      else if (pp.bn == 96) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, false, 96>), grid, block, 0, st, d);   \
+      else if (pp.bn == 160) hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, false, 160>), grid, block, 0, st, d); \
+      else hipLaunchKernelGGL((conv3x3_patch_f32_kernel<W_, NI_, false>), grid, block, 0, st, d);               \
     } while (0)
     if (a->g.Wo == 64) GAD_PATCH(64, 1);
     else if (a->g.Wo == 32) GAD_PATCH(32, 1);
@@ -1677,6 +1691,14 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     }
     return 0;
   }
+  // generic engine: the one place the tile / split-K cost model runs
+  const Plan pl = make_plan(a);
+  GAD_CHECK(pl.nblocks > 0 && pl.nblocks < (1L << 31), "gad_gemm: grid too large");
+  if (pl.splitk > 1) {
+    int64_t need = (int64_t)batch * pl.splitk * a->M * a->N * (int64_t)sizeof(float);
+    GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: split-K workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
+  }
+  d.tiles_m = pl.tiles_m; d.tiles_n = pl.tiles_n; d.splitk = pl.splitk; d.ktiles_per_split = pl.ktiles_per_split;
   if (a->A2) {
     if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
     else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);

@@ -262,8 +262,7 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out) {
   SlabGeo best{};
   int best_nv = 0;
   long best_score = -1;
-  const char* mx = getenv("GAD_GN_MAXNV");
-  const int maxnv = mx ? atoi(mx) : 32;
+  const int maxnv = 32;
   for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
     int SC = k * cpg;
     if (a->C % SC != 0) continue;
@@ -431,8 +430,7 @@ extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
 
 extern "C" int gad_groupnorm_one_pass(const gad_groupnorm_args* a) {
   if (!a || a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G != 0 || a->C % 4 != 0) return 0;
-  const char* two = getenv("GAD_GN_TWO_PASS");
-  if (two && atoi(two)) return 0;
+  if (a->flags & GAD_GN_TWO_PASS) return 0;
   SlabGeo sg;
   return make_slab(a, &sg) ? 1 : 0;
 }
@@ -441,8 +439,7 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
   if (check(a, "gad_groupnorm_silu_fwd")) return 1;
   hipStream_t st = (hipStream_t)stream;
   SlabGeo sg;
-  const char* two = getenv("GAD_GN_TWO_PASS");
-  int nv = (two && atoi(two)) ? 0 : make_slab(a, &sg);
+  int nv = (a->flags & GAD_GN_TWO_PASS) ? 0 : make_slab(a, &sg);
   if (a->x2) {
     GAD_CHECK(nv, "gad_groupnorm_silu_fwd: the two-source input needs the one-pass plan (check gad_groupnorm_one_pass)");
     GAD_CHECK(a->C1 > 0 && a->C1 < a->C && a->C1 % 4 == 0 && gad_aligned16(a->x2), "gad_groupnorm_silu_fwd: bad C1 / x2");

@@ -34,7 +34,8 @@ class GemmArgs(C.Structure):
                 ("residual", C.c_void_p), ("ldr", C.c_int32),
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32),
-                ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p)]
+                ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p),
+                ("flags", C.c_int32)]
 
 
 class GroupNormArgs(C.Structure):
@@ -43,7 +44,7 @@ class GroupNormArgs(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("G", C.c_int32),
                 ("eps", C.c_float), ("silu", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("x2", C.c_void_p), ("C1", C.c_int32)]
+                ("x2", C.c_void_p), ("C1", C.c_int32), ("flags", C.c_int32)]
 
 
 class AttentionArgs(C.Structure):
@@ -64,6 +65,7 @@ class AdamArgs(C.Structure):
                 ("weight_decay", C.c_float), ("adamw", C.c_int32), ("step", C.c_int32), ("ema_decay", C.c_float)]
 
 
+GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GN_TWO_PASS = 1, 2, 1
 A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
 B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 

@@ -138,6 +138,28 @@ def set_operand_precision(name):
     OPERAND_PRECISION[0] = 0 if name in (None, "no", "f32", "fp32") else operand_precision("bf16" if name in ("fp16", "bf16") else name).value
 
 
+# Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
+# structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
+KERNEL_FLAGS = {"gemm": 0, "gn": 0}
+
+
+class kernel_flags:
+    """``with ops.kernel_flags(no_patch=True, tap_major_k=True, gn_two_pass=True): ...``"""
+
+    def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False):
+        self.gemm = (_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
+        self.gn = _capi.GN_TWO_PASS if gn_two_pass else 0
+
+    def __enter__(self):
+        self.prev = dict(KERNEL_FLAGS)
+        KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"] = self.gemm, self.gn
+        return self
+
+    def __exit__(self, *exc):
+        KERNEL_FLAGS.update(self.prev)
+        return False
+
+
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None):
@@ -162,6 +184,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
     a.operand_precision = OPERAND_PRECISION[0]
+    a.flags = KERNEL_FLAGS["gemm"]
     if A2 is not None:
         a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]
     if B_bf16 is not None:
@@ -190,7 +213,7 @@ class GemmProfiler:
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
         name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}")[kid]
-        if kid in (2, 3):                    # the patch kernels have their own tiling (128 rows; pixel splits for wgrad)
+        if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)
         # algorithmic bytes: every operand once (gathered tensor, not its im2col expansion) + the output
@@ -444,6 +467,7 @@ def _gn_args(x, y, gamma, beta, mean, rstd, G, eps, silu):
     a.B, a.HW, a.C, a.G = Bn, HW, C_, G
     a.eps, a.silu = eps, int(silu)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    a.flags = KERNEL_FLAGS["gn"]
     return a
 
 
@@ -505,6 +529,7 @@ def group_norm_two_source_ok(x, x2, G) -> bool:
     a.B, a.C, a.G = x.shape[0], C_, G
     a.HW = x.numel() // (x.shape[0] * x.shape[-1])
     a.x2, a.C1 = x2.data_ptr(), x.shape[-1]
+    a.flags = KERNEL_FLAGS["gn"]
     return bool(_capi.load().gad_groupnorm_one_pass(C.byref(a)))
 
 

@@ -98,7 +98,14 @@ typedef struct gad_gemm_args {
    * operand_precision = 1 the LDS-patch convolution streams it by LDS-DMA instead of converting the fp32 weights in every
    * workgroup.  Ignored by every other kernel. */
   const void* B_bf16;
+  /* kernel-family switches for A/B tests and invariance checks (0 in production): GAD_GEMM_* bits below.  They
+   * travel with the call - the library reads no environment variable and keeps no process-global switch. */
+  int32_t flags;
 } gad_gemm_args;
+enum gad_gemm_flags {
+  GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
+  GAD_GEMM_TAP_MAJOR_K = 2    /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
+};
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
 /* which kernel instance gad_gemm would launch: block tile edge (128 or 64), split-K factor, vector width (4 or 1) */
@@ -138,7 +145,9 @@ typedef struct gad_groupnorm_args {
    * x2 == NULL: single source.  Needs the one-pass plan (gad_groupnorm_one_pass); C1 % 4 == 0. */
   const float* x2;
   int32_t C1;
+  int32_t flags;            /* GAD_GN_TWO_PASS = 1: force the two-pass plan (A/B tests); 0 in production          */
 } gad_groupnorm_args;
+enum gad_groupnorm_flags { GAD_GN_TWO_PASS = 1 };
 
 int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a);
 /* 1 if the forward of these shapes (incl. the x2/C1 split, if any) runs as the one-pass register-slab kernel */

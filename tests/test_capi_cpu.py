@@ -24,12 +24,28 @@ def test_every_declared_symbol_is_exported_and_bound():
     assert lib.gad_version() >= 100
 
 
-def test_struct_layout_matches_header():
-    # sizes computed from the C declaration (LP64): guards against a field drifting between gad.h and _capi.py
-    assert ctypes.sizeof(_capi.ConvGeom) == 12 * 4
-    assert ctypes.sizeof(_capi.GemmArgs) == 3 * 8 + 10 * 4 + 6 * 8 + 48 + 4 + 4 + 8 + 8 + 4 + 4 + 8 + 4 + 4 + 8 + 8 + 4 + 4 + 4 + 4 + 8 + 4 + 4 + 8   # ... hints, operand_precision, pad, A2, a_split, ldx2, B_bf16
-    assert ctypes.sizeof(_capi.GroupNormArgs) == 9 * 8 + 4 * 4 + 4 + 4 + 8 + 8 + 8 + 4 + 4   # ... x2, C1, tail pad
-    assert ctypes.sizeof(_capi.AdamArgs) == 5 * 8 + 8 + 8 + 4 + 5 * 4 + 4 + 4 + 4 + 4
+def test_struct_layout_matches_header(tmp_path):
+    """Every field of every argument struct: sizeof and offsetof as gcc lays out include/gad.h against the ctypes
+    mirror in gad/_capi.py (guards against a field drifting between the two)."""
+    import subprocess
+    structs = {"gad_conv_geom": _capi.ConvGeom, "gad_gemm_args": _capi.GemmArgs, "gad_groupnorm_args": _capi.GroupNormArgs,
+               "gad_adam_args": _capi.AdamArgs, "gad_attention_args": _capi.AttentionArgs}
+    src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gad.h"', 'int main(void) {']
+    for cname, cls in structs.items():
+        src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')
+        for fname, _ in cls._fields_:
+            src.append(f'  printf("{cname}.{fname} %zu\\n", offsetof({cname}, {fname}));')
+    src += ['  return 0;', '}']
+    c = tmp_path / "layout.c"
+    c.write_text("\n".join(src))
+    exe = tmp_path / "layout"
+    inc = os.path.join(os.path.dirname(__file__), "..", "include")
+    subprocess.run(["gcc", "-I", inc, str(c), "-o", str(exe)], check=True)
+    got = dict(line.split() for line in subprocess.run([str(exe)], check=True, capture_output=True, text=True).stdout.splitlines())
+    for cname, cls in structs.items():
+        assert int(got[cname]) == ctypes.sizeof(cls), cname
+        for fname, _ in cls._fields_:
+            assert int(got[f"{cname}.{fname}"]) == getattr(cls, fname).offset, f"{cname}.{fname}"
 
 
 def test_host_side_argument_validation_without_gpu():

@@ -26,10 +26,15 @@ def _conv_case(Cin, Cout, B=512, H=32):  # noqa: E302
 
 
 @pytest.mark.parametrize("Cin,Cout,B,H", [(128, 128, 512, 32), (256, 128, 512, 32), (256, 256, 128, 16), (128, 200, 64, 16), (256, 256, 512, 8), (64, 96, 130, 8), (96, 128, 40, 64),
-                                         (256, 256, 1024, 4), (512, 256, 128, 8), (128, 96, 512, 4)])
+                                         (256, 256, 1024, 4), (512, 256, 128, 8), (128, 96, 512, 4),
+                                         # output-channel counts that take the 96- / 160-wide patch tiles (pruned CIFAR
+                                         # widths 96 / 192 / 288, SD 320, CelebA 672) at full launch sizes
+                                         (96, 96, 512, 32), (192, 96, 512, 32), (288, 96, 128, 32), (192, 192, 512, 16),
+                                         (384, 192, 128, 16), (288, 288, 64, 8), (320, 320, 64, 32), (640, 320, 16, 64),
+                                         (672, 672, 32, 16), (224, 448, 32, 32), (192, 192, 1024, 4)])
 def test_conv_fwd_full_size_properties(ops, Cin, Cout, B, H):
     """B=512 (16 fused reference batches) x 32x32: the dominant launch of the sampler (and the 16x16 level at the
-    training batch).  These shapes run the LDS-patch kernel; tile 64 / split-K / GAD_NO_PATCH_CONV force the generic
+    training batch).  These shapes run the LDS-patch kernel; tile 64 / split-K / ops.kernel_flags(no_patch=True) force the generic
     im2col-gather kernel, so the invariance checks also compare the two kernels."""
     x, w, b = _conv_case(Cin, Cout, B=B, H=H)
     y = ops.conv2d_fwd_raw(x, w, b)
@@ -48,18 +53,11 @@ def test_conv_fwd_full_size_properties(ops, Cin, Cout, B, H):
     tol = 2e-5 * (9 * Cin) ** 0.5
     assert (ops.conv2d_fwd_raw(x, w, b, tile_hint=64) - y).abs().max().item() < tol
     assert (ops.conv2d_fwd_raw(x, w, b, splitk_hint=2) - y).abs().max().item() < tol
-    os.environ["GAD_NO_KPERM"] = "1"
-    os.environ["GAD_NO_PATCH_CONV"] = "1"
-    try:
+    with ops.kernel_flags(no_patch=True, tap_major_k=True):
         y_tapmajor = ops.conv2d_fwd_raw(x, w, b)
-    finally:
-        del os.environ["GAD_NO_KPERM"], os.environ["GAD_NO_PATCH_CONV"]
     assert (y_tapmajor - y).abs().max().item() < tol
-    os.environ["GAD_NO_PATCH_CONV"] = "1"
-    try:
+    with ops.kernel_flags(no_patch=True):
         y_generic = ops.conv2d_fwd_raw(x, w, b)          # same K order (chunk, tap), im2col gather instead of the patch
-    finally:
-        del os.environ["GAD_NO_PATCH_CONV"]
     assert (y_generic - y).abs().max().item() < tol
     # (3) determinism: the same launch twice is bit-identical
     assert torch.equal(ops.conv2d_fwd_raw(x, w, b), y)
@@ -78,18 +76,12 @@ def test_conv_backward_adjoint_full_size(ops):
         dy = torch.randn(128, H, H, Cout, device=dev)
         y = ops.conv2d_fwd_raw(x, w, None)
         dx = ops.conv2d_dgrad_raw(dy, w, x.shape)                # LDS-patch dgrad kernel at these shapes
-        os.environ["GAD_NO_PATCH_CONV"] = "1"
-        try:
+        with ops.kernel_flags(no_patch=True):
             dx_generic = ops.conv2d_dgrad_raw(dy, w, x.shape)    # transposed-gather kernel
-        finally:
-            del os.environ["GAD_NO_PATCH_CONV"]
         assert (dx - dx_generic).abs().max().item() < 2e-5 * (9 * Cout) ** 0.5 * float(w.abs().max()) * 4
         dw = ops.conv2d_wgrad_raw(dy, x, w)                      # LDS-patch wgrad kernel where W is 32 or 16
-        os.environ["GAD_NO_PATCH_CONV"] = "1"
-        try:
+        with ops.kernel_flags(no_patch=True):
             dw_generic = ops.conv2d_wgrad_raw(dy, x, w)          # im2col-columns kernel
-        finally:
-            del os.environ["GAD_NO_PATCH_CONV"]
         assert (dw - dw_generic).abs().max().item() < 2e-5 * (128 * H * H) ** 0.5 * 4
         a = (dy.double() * y.double()).sum()
         bb = (dx.double() * x.double()).sum()
@@ -147,15 +139,15 @@ def test_fused_sampler_at_bench_width_equals_per_batch_launches():
 
 def test_whole_model_is_kernel_family_invariant():
     """Full-width U-Net at the training batch: forward, loss, gradient norm and the updated weights with the LDS-patch
-    kernels (forward, dgrad, wgrad) against the same step on the generic im2col kernels (GAD_NO_PATCH_CONV=1): only
+    kernels (forward, dgrad, wgrad) against the same step on the generic im2col kernels (ops.kernel_flags(no_patch=True)): only
     fp32 summation order may differ."""
     import gad
     from src.ddpm_config import DDPMConfig
     cfg = DDPMConfig.cifar100_config
     outs = []
-    for flag in ("0", "1"):
-        os.environ["GAD_NO_PATCH_CONV"] = flag
-        try:
+    from gad import ops as O
+    for no_patch in (False, True):
+        with O.kernel_flags(no_patch=no_patch):
             torch.manual_seed(0)
             net = gad.UNet2DModel(**cfg["unet_config"]).to(dev)
             tr = gad.FusedTrainer(net, gad.DDPMScheduler(**cfg["scheduler_config"]), gad.EMAModel(net.parameters()), lr=1e-4)
@@ -168,8 +160,6 @@ def test_whole_model_is_kernel_family_invariant():
             loss = tr.step(x, n, t).item()
             outs.append((y, loss, tr.grad_norm().item(), tr.flat.clone()))
             del net, tr
-        finally:
-            del os.environ["GAD_NO_PATCH_CONV"]
     (y0, l0, g0, w0), (y1, l1, g1, w1) = outs
     assert (y0 - y1).abs().max().item() < 1e-4 * max(1.0, y1.abs().max().item())
     assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1

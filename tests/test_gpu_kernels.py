@@ -156,11 +156,14 @@ def test_conv_autograd_function(ops):
                                           (2, 384, 32, 32, True), (2, 96, 8, 32, True), (3, 256, 32, 32, False),
                                           (2, 320, 64, 32, True)])
 @pytest.mark.parametrize("two_pass", [False, True])
-def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu, two_pass, monkeypatch):
+def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu, two_pass):
     """Forward has two plans: one pass with the (image, channel slab) held in registers, or stats + apply passes
     (odd channels per group, slabs that are not whole 128-B lines, too many pixels); both against fp64."""
-    if two_pass:
-        monkeypatch.setenv("GAD_GN_TWO_PASS", "1")
+    with ops.kernel_flags(gn_two_pass=two_pass):
+        _groupnorm_case(ops, B, C, H, G, silu)
+
+
+def _groupnorm_case(ops, B, C, H, G, silu):
     x = (rnd(B, C, H, H, seed=1) * 2 + 0.7).double().requires_grad_(True)   # non-zero mean stresses the variance
     ga, be = (rnd(C, seed=2) * 0.3 + 1).double().requires_grad_(True), (rnd(C, seed=3) * 0.2).double().requires_grad_(True)
     eps = 1e-6
@@ -544,7 +547,17 @@ def test_unet_sampling_forward_without_concat_equals_grad_mode_forward(ops):
     with torch.no_grad():
         a = net(x, t).sample
     b = net(x, t).sample.detach()
-    assert torch.equal(a, b)
+    # the concat-free gathers are bit-identical to the materialised torch.cat; since round 2 the two modes differ in ONE
+    # other place - training at one 256-wide head keeps the three-launch attention, sampling runs the fused kernel -
+    # which is fp32 summation order only
+    assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
+    monkey = ops.attention_core
+    ops.attention_core = ops.attention_core_fused            # same attention route in both modes -> bit-identical again
+    try:
+        b2 = net(x, t).sample.detach()
+    finally:
+        ops.attention_core = monkey
+    assert torch.equal(a, b2)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
@@ -564,11 +577,13 @@ def test_conv_patch_kernel_small_maps(ops, prec):
     assert (got - gen).abs().max().item() < 3e-5
 
 
-def test_attention_fused_qkv_inference_path_is_bit_identical(ops):
+def test_attention_fused_qkv_inference_path_is_bit_identical(ops, monkeypatch):
     """no_grad forward of the attention block (one [3C, C] projection, q/k/v read in place) vs the grad-mode forward
-    (three projections); the cached fused weight follows in-place parameter updates."""
+    (three projections); the cached fused weight follows in-place parameter updates.  Both modes are put on the fused
+    attention kernel (training at one 256-wide head would otherwise take the three-launch route)."""
     import gad
     from gad.nn import Attention
+    monkeypatch.setattr(ops, "attention_core", ops.attention_core_fused)
     torch.manual_seed(0)
     for C, heads, d, H in ((256, 1, 256, 16), (224, 7, 32, 8)):
         att = Attention(C, heads, d, 1e-6, 32).to(dev)

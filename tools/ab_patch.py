@@ -15,18 +15,18 @@ def timeit(fn, iters=10, warm=2):
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
 for B in (512, 128):
-    for Cin, Cout, H in ((128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (128, 256, 16)):
+    for Cin, Cout, H in ((128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (128, 256, 16),
+                         (96, 96, 32), (192, 96, 32), (288, 96, 32), (192, 192, 16), (384, 192, 16), (320, 320, 32), (640, 320, 32)):
         x = torch.randn(B, H, H, Cin, device=dev)
         w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
         b = torch.randn(Cout, device=dev)
         fl = 2.0 * B * H * H * Cout * Cin * 9
         res = []
         outs = []
-        for label, env in (("patch", {}), ("generic", {"GAD_PATCH_CONV_F32": "0"})):
-            for k_ in ("GAD_PATCH3", "GAD_PATCH_CONV_F32"): os.environ.pop(k_, None)
-            os.environ.update(env)
-            outs.append(ops.conv2d_fwd_raw(x, w, b))
-            ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b))
+        for label, flags in (("patch", {}), ("generic", {"no_patch": True})):
+            with ops.kernel_flags(**flags):
+                outs.append(ops.conv2d_fwd_raw(x, w, b))
+                ms = timeit(lambda: ops.conv2d_fwd_raw(x, w, b))
             res.append(f"{label} {fl/ms/1e9:6.1f} TF/s ({ms*1e3:6.0f} us)")
         res.append(f"max|patch-generic| {(outs[0]-outs[1]).abs().max().item():.1e}")
         print(f"B={B} {Cin}->{Cout}@{H}: " + " | ".join(res), flush=True)

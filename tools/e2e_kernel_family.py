@@ -18,13 +18,10 @@ sch.set_timesteps(100)
 x0 = torch.randn(256, 32, 32, 3, device=dev)
 t = torch.empty(256, device=dev, dtype=torch.int64)
 
-def run(env):
-    for k in ("GAD_NO_PATCH_CONV", "GAD_NO_KPERM"):
-        os.environ.pop(k, None)
-    os.environ.update(env)
+def run(flags):
     x = x0.clone()
     snaps = {}
-    with torch.no_grad():
+    with torch.no_grad(), ops.kernel_flags(**flags):
         for i, ts in enumerate(sch.timesteps.tolist()):
             t.fill_(ts)
             eps = net.forward_nhwc(x, t)
@@ -35,10 +32,10 @@ def run(env):
     return snaps
 
 base = run({})
-for name, env in (("patch vs im2col-gather kernels", {"GAD_NO_PATCH_CONV": "1"}),
+for name, env in (("patch vs im2col-gather kernels", {"no_patch": True}),
                   ("im2col-gather, chunk-major vs tap-major K order", None)):
     if env is None:
-        a, b = run({"GAD_NO_PATCH_CONV": "1"}), run({"GAD_NO_PATCH_CONV": "1", "GAD_NO_KPERM": "1"})
+        a, b = run({"no_patch": True}), run({"no_patch": True, "tap_major_k": True})
     else:
         a, b = base, run(env)
     print(name + ": max |x_a - x_b| after k steps: " + ", ".join(f"k={k}: {(a[k] - b[k]).abs().max().item():.2e}" for k in sorted(a)))

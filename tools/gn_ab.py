@@ -1,5 +1,6 @@
 import os, sys
-sys.path.insert(0, "/root/repo/group-attribution-for-diffusion-models_amd"); sys.path.insert(0, "/root/repo")
+ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
+sys.path.insert(0, os.path.join(ROOT, "group-attribution-for-diffusion-models_amd")); sys.path.insert(0, ROOT)
 os.environ.setdefault("GAD_OUTDIR", "/tmp/_out")
 import torch
 from gad import ops
@@ -17,10 +18,8 @@ for B in (512, 128):
         x = torch.randn(B, H, H, C, device=dev); g = torch.randn(C, device=dev); b = torch.randn(C, device=dev)
         res = []
         ref = None
-        for label, env in (("two-pass", {"GAD_GN_TWO_PASS": "1"}), ("slab32", {"GAD_GN_MAXNV": "32"}), ("slab16", {"GAD_GN_MAXNV": "16"}), ("slab8", {"GAD_GN_MAXNV": "8"})):
-            for k in ("GAD_GN_TWO_PASS", "GAD_GN_MAXNV"): os.environ.pop(k, None)
-            os.environ.update(env)
-            with torch.no_grad():
+        for label, two in (("two-pass", True), ("one-pass slab", False)):
+            with torch.no_grad(), ops.kernel_flags(gn_two_pass=two):
                 y = ops.group_norm(x, g, b, 32, 1e-6, True)
                 if ref is None: ref = y
                 err = (y - ref).abs().max().item()

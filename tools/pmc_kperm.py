@@ -8,8 +8,8 @@ for B, Cin, Cout, H in [(128, 256, 256, 16), (512, 128, 128, 32)]:
     x = torch.randn(B, H, H, Cin, device=dev)
     w = (torch.randn(Cout, Cin, 3, 3, device=dev) * 0.05).contiguous(memory_format=torch.channels_last)
     b = torch.randn(Cout, device=dev)
-    for mode in ("1", "0"):
-        os.environ["GAD_NO_KPERM"] = mode
-        for _ in range(6):
-            y = ops.conv2d_fwd_raw(x, w, b, 1, (1, 1, 1, 1), False, tile_hint=1)
+    for tap_major in (True, False):
+        with ops.kernel_flags(no_patch=True, tap_major_k=tap_major):
+            for _ in range(6):
+                y = ops.conv2d_fwd_raw(x, w, b, 1, (1, 1, 1, 1), False, tile_hint=1)
         torch.cuda.synchronize()
