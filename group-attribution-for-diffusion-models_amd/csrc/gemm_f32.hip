@@ -1023,11 +1023,12 @@ constexpr int PLD = BK + 4;
 // DG = true: the data gradient of the same convolution - rows are input pixels, the patch holds dy, tap (r, s) reads it at
 // (ih + 1 - r, iw + 1 - s) (mirrored shifts) and the weights W[co][r][s][ci] stream as B[k = (tap, co)][n = ci]
 // ([k][n] tiles, read like the generic dgrad).
-// BN_ = 128: 2 x 2 waves of 64 x 64 (the default).  BN_ = 96 / 160: 4 x 1 waves of 32 x BN_ - output-channel counts that
-// 128 would pad by a quarter or more (pruned widths 96 / 192 / 288, CelebA 672, SD 320) run without padding.
-template <int W, int NI, bool DG, int BN_ = 128>
+// Forward: 4 x 1 waves of 32 pixels x BN_ channels, BN_ = 128, or 96 / 160 for output-channel counts that 128 would pad
+// by a quarter or more (pruned widths 96 / 192 / 288, CelebA 672, SD 320).  4 x 1 measured 1-4 % over 2 x 2 waves of
+// 64 x 64 at BN_ = 128 (tools/ab_patch.py).  The data gradient keeps 2 x 2 (its [k][n] weight tiles are read per column).
+template <int W, int NI, bool DG, int BN_ = 128, int WM_ = (DG ? 2 : 4)>
 __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevArgs p) {
-  constexpr int BM = 128, BN = BN_, WM = BN_ == 128 ? 2 : 4, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
+  constexpr int BM = 128, BN = BN_, WM = WM_, WN = 4 / WM, TM = BM / (32 * WM), TN = BN / (32 * WN);
   static_assert(!DG || BN_ == 128, "the data-gradient form streams [k][n] weight tiles: 128 columns only");
   // NI = 1: the tile is TR = 128 / W rows of one image.  NI > 1 (small maps): the tile is NI whole TR x W images,
   // each with its own halo'd sub-patch.

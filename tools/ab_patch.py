@@ -14,7 +14,7 @@ def timeit(fn, iters=10, warm=2):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters
-for B in (512, 128):
+for B in (1024, 128):
     for Cin, Cout, H in ((128, 128, 32), (256, 128, 32), (384, 128, 32), (256, 256, 16), (512, 256, 16), (384, 256, 16), (128, 256, 16),
                          (96, 96, 32), (192, 96, 32), (288, 96, 32), (192, 192, 16), (384, 192, 16), (320, 320, 32), (640, 320, 32)):
         x = torch.randn(B, H, H, Cin, device=dev)
