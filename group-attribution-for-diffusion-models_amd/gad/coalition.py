@@ -119,7 +119,8 @@ class FusedSampler:
 @dataclass
 class CoalitionRecord:
     """What one coalition contributes to the .jsonl "db" (unlearn.py:960-968) - and the payload of
-    the final all-gather."""
+    the final all-gather: 11 fixed float64 scalars, `n_extra` engine-defined behaviour scalars (`extra`: CelebA entropy
+    and cluster counts, SD aesthetic / CLIP quantiles ...; the engine names them in `extra_keys`), then the contributor mask."""
     removal_seed: int
     n_remaining: int
     n_removed: int
@@ -132,25 +133,32 @@ class CoalitionRecord:
     inception_score: float = float("nan")
     precision: float = float("nan")
     recall: float = float("nan")
+    extra: List[float] = field(default_factory=list)
 
-    NSCALAR = 11        # float64 scalars ahead of the contributor mask in the packed record
+    NSCALAR = 11        # float64 scalars ahead of the extras and the contributor mask in the packed record
 
-    def pack(self, n_groups: int) -> torch.Tensor:
-        v = torch.zeros(self.NSCALAR + n_groups, dtype=torch.float64)
+    def pack(self, n_groups: int, n_extra: int = 0) -> torch.Tensor:
+        if len(self.extra) != n_extra:
+            raise ValueError(f"record carries {len(self.extra)} extra scalars, the engine declares {n_extra}")
+        v = torch.zeros(self.NSCALAR + n_extra + n_groups, dtype=torch.float64)
         v[:self.NSCALAR] = torch.tensor([self.removal_seed, self.n_remaining, self.n_removed, self.fid_value,
                                          self.loss_last, self.total_steps_time, self.total_sampling_time,
                                          self.trained_steps, self.inception_score, self.precision, self.recall],
                                         dtype=torch.float64)
+        if n_extra:
+            v[self.NSCALAR:self.NSCALAR + n_extra] = torch.tensor([float("nan") if x is None else float(x) for x in self.extra],
+                                                                  dtype=torch.float64)
         for c in self.remaining_classes:
-            v[self.NSCALAR + int(c)] = 1.0
+            v[self.NSCALAR + n_extra + int(c)] = 1.0
         return v
 
     @classmethod
-    def unpack(cls, v: torch.Tensor):
+    def unpack(cls, v: torch.Tensor, n_extra: int = 0):
         s = v[:cls.NSCALAR].tolist()
-        mask = v[cls.NSCALAR:]
+        extra = v[cls.NSCALAR:cls.NSCALAR + n_extra].tolist()
+        mask = v[cls.NSCALAR + n_extra:]
         return cls(int(s[0]), int(s[1]), int(s[2]), s[3], s[4], s[5], s[6], int(s[7]),
-                   [i for i in range(mask.numel()) if mask[i] > 0.5], s[8], s[9], s[10])
+                   [i for i in range(mask.numel()) if mask[i] > 0.5], s[8], s[9], s[10], extra)
 
 
 class CoalitionEngine:
@@ -310,7 +318,9 @@ def _rank_shard(db_path: str, rank: int) -> str:
     return f"{db_path}.rank{rank}"
 
 
-def _read_rows(path: str) -> List[dict]:
+def _read_rows(path: str, bad: Optional[list] = None) -> List[dict]:
+    """Rows of a jsonl file that carry a `removal_seed`; lines that do not parse (the torn last line of a killed writer:
+    that seed is simply redone) or have no seed are counted into `bad`."""
     rows = []
     if os.path.exists(path):
         with open(path) as f:
@@ -321,7 +331,9 @@ def _read_rows(path: str) -> List[dict]:
                 try:
                     row = json.loads(line)
                     int(row["removal_seed"])
-                except (ValueError, KeyError, TypeError):      # a torn last line of a killed writer: the seed is simply redone
+                except (ValueError, KeyError, TypeError):
+                    if bad is not None:
+                        bad.append(line)
                     continue
                 rows.append(row)
     return rows
@@ -354,17 +366,22 @@ def merge_shards(db_path: str, extra_rows: Sequence[dict] = ()) -> List[int]:
     rank shard that are not in the db yet are appended in seed order; then the shards are removed.  Returns the
     seeds appended."""
     have = {int(r["removal_seed"]) for r in _read_rows(db_path)}
-    new = {}
+    new, keep = {}, set()
     for path in _shard_paths(db_path):
-        for r in _read_rows(path):
+        bad = []
+        for r in _read_rows(path, bad):
             new.setdefault(int(r["removal_seed"]), r)
+        if bad:                                            # never drop lines this function could not account for
+            keep.add(path)
+            print(f"[merge_shards] {path}: {len(bad)} unreadable line(s) left in place", flush=True)
     for r in extra_rows:                                   # gathered records win: they are this run's data path
         new[int(r["removal_seed"])] = r
     seeds = sorted(s for s in new if s not in have)
     for s in seeds:
         _append_row(db_path, new[s])
     for path in _shard_paths(db_path):
-        os.remove(path)
+        if path not in keep:
+            os.remove(path)
     return seeds
 
 
@@ -441,8 +458,9 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
         attempt += 1
         todo = again if attempt <= retries else []
         failed = again
-    width = CoalitionRecord.NSCALAR + engine.n_groups
-    packed = [r.pack(engine.n_groups) for r in recs]
+    n_extra = len(getattr(engine, "extra_keys", ()))
+    width = CoalitionRecord.NSCALAR + n_extra + engine.n_groups
+    packed = [r.pack(engine.n_groups, n_extra) for r in recs]
     gathered = True
     if dist_on:
         timeout = rendezvous_timeout_s if rendezvous_timeout_s is not None else float(os.environ.get("GAD_SHARD_TIMEOUT", 24 * 3600))
@@ -454,9 +472,13 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
                   flush=True)
         else:
             packed = gather_records(packed, width, engine.device if dist.get_backend() == "nccl" else "cpu")
-    all_recs = [CoalitionRecord.unpack(v) for v in packed]
+    all_recs = [CoalitionRecord.unpack(v, n_extra) for v in packed]
     if rank == 0 and db_path:
-        merge_shards(db_path, [engine.jsonl_row(r) for r in all_recs] if (gathered and dist_on) else ())
+        # rows of the gathered records where this rank can rebuild them from the scalars (the CIFAR engine); an engine whose
+        # rows carry more than the record (entry-point cycles: per-image behaviours, args) answers None for coalitions it
+        # did not run itself - those rows come from the owning rank's shard
+        rows = [engine.jsonl_row(r) for r in all_recs] if (gathered and dist_on) else []
+        merge_shards(db_path, [r for r in rows if r is not None])
     if failed and verbose:
         print(f"[rank {rank}] seeds still failing after {retries} retries: {failed}", flush=True)
     return all_recs

@@ -99,6 +99,11 @@ def _parse(argv=None):
     ap.add_argument("--requeue", type=int, default=1, help="re-entries of the whole launch while seeds are missing")
     ap.add_argument("--retries", type=int, default=1, help="in-process retries of a coalition that raised")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
+    ap.add_argument("--cycle", default="cifar", choices=["cifar", "celeba", "sd"],
+                    help="cifar: the in-process CIFAR-family engine; celeba / sd: the kept entry points of configs 3 / 4-5 run "
+                         "in-process per coalition (gad.cycles)")
+    ap.add_argument("--cycle_args", default="[]", help="celeba: JSON list of shared unlearn.py flags; sd: JSON object "
+                    "{\"train\": [...], \"behaviours\": [...], \"n_groups\": 258}")
     ap.add_argument("--worker", action="store_true", help=argparse.SUPPRESS)
     return ap.parse_args(argv)
 
@@ -120,8 +125,15 @@ def worker(a) -> int:
         else:
             dist.init_process_group("gloo")
     gad.set_operand_precision(a.mixed_precision)
-    engine = CoalitionEngine(a.dataset, device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
-                             sample_batch=a.batch_size, num_inference_steps=a.num_inference_steps, opt_seed=a.opt_seed)
+    if a.cycle == "cifar":
+        engine = CoalitionEngine(a.dataset, device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
+                                 sample_batch=a.batch_size, num_inference_steps=a.num_inference_steps, opt_seed=a.opt_seed)
+    else:
+        import json
+        from gad import cycles
+        spec = json.loads(a.cycle_args)
+        engine = (cycles.CelebaCycle(dev, spec) if a.cycle == "celeba"
+                  else cycles.SDLoRACycle(dev, spec["train"], spec["behaviours"], int(spec.get("n_groups", 258))))
     recs = run_sharded(engine, parse_seeds(a.seeds), db_path=a.db, verbose=True, retries=a.retries)
     if rank == 0:
         print(f"[gad.launch] {len(recs)} coalition records consolidated into {a.db}", flush=True)

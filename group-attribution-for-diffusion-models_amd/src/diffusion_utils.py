@@ -94,10 +94,18 @@ def build_pipeline(args, model, backend=None):
     return pipeline, None, None
 
 
-def generate_images(args, pipeline):
+def generate_images(args, pipeline, fuse=32):
     """n_samples images in batches of args.batch_size; batch b draws its noise from a CPU generator seeded
     with b; every image goes through the uint8 round trip of the PNG writer (:344-355).  Returns a float
-    tensor [n,3,H,W] of k/255 values."""
+    tensor [n,3,H,W] of k/255 values.
+
+    A `gad` DDPM/DDIM/latent-LDM pipeline (DDIM scheduler, no VQ-VAE decode) takes the engine's fused-batch sampler:
+    `fuse` reference batches - each with its own CPU-generator seed, exactly as below - are stacked per U-Net launch
+    (the U-Net has no cross-sample op), which is what the benchmarked throughput is measured with.  Any other
+    pipeline (the oracle backend of the CPU tests, a VQ-VAE-decoding LDM) runs batch by batch."""
+    fused = _fused_sampler_for(pipeline, args.batch_size, fuse)
+    if fused is not None:
+        return fused.generate(args.n_samples, args.num_inference_steps).float()
     sizes = [args.batch_size] * (args.n_samples // args.batch_size)
     if args.n_samples % args.batch_size:
         sizes.append(args.n_samples % args.batch_size)
@@ -110,6 +118,21 @@ def generate_images(args, pipeline):
             q = x.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)
             out.append(q.float().div_(255))
     return torch.cat(out, 0).float()
+
+
+def _fused_sampler_for(pipeline, batch_size, fuse):
+    try:
+        import gad
+        from gad.coalition import FusedSampler
+    except Exception:
+        return None
+    if not isinstance(pipeline, gad.DDPMPipeline) or getattr(pipeline, "vqvae", None) is not None:
+        return None
+    if not isinstance(pipeline.scheduler, gad.DDIMScheduler) or not isinstance(pipeline.unet, gad.UNet2DModel):
+        return None
+    if pipeline.unet.device.type != "cuda" or fuse <= 1:
+        return None
+    return FusedSampler(pipeline.unet, pipeline.scheduler, batch_size, fuse)
 
 
 def run_inference(model, ema_model, config, args, backend=None):

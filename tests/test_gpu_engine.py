@@ -71,6 +71,27 @@ def test_fused_sampler_equals_per_batch_pipeline_calls():
     assert ((got - want).abs() > 1e-6).float().mean().item() < 1e-3
 
 
+def test_generate_images_routes_through_the_fused_sampler():
+    """the kept CLI's generate_images (src/diffusion_utils.py:319-357) on a gad pipeline = the engine's
+    fused-batch sampler - same per-batch CPU-generator seeds, same images as batch-by-batch pipeline calls (one 8-bit
+    level allowed where a value sits on a rounding boundary: the launch width changes the fp32 summation order)."""
+    from types import SimpleNamespace
+    import gad
+    from src.diffusion_utils import _fused_sampler_for, generate_images
+    ucfg, _ = _cfg()
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**ucfg).to(dev).eval()
+    args = SimpleNamespace(batch_size=4, n_samples=10, num_inference_steps=5)
+    pipe = gad.DDPMPipeline(net, gad.DDIMScheduler())
+    assert _fused_sampler_for(pipe, 4, 32) is not None and _fused_sampler_for(pipe, 4, 1) is None
+    fused = generate_images(args, pipe).cpu()
+    per_batch = generate_images(args, pipe, fuse=1).cpu()
+    assert fused.shape == per_batch.shape == (10, 3, 32, 32)
+    assert (fused - per_batch).abs().max().item() <= 1 / 255 + 1e-6
+    assert ((fused - per_batch).abs() > 1e-6).float().mean().item() < 1e-3
+    assert (fused * 255 - (fused * 255).round()).abs().max().item() < 1e-4    # the uint8 round trip survived
+
+
 def test_entry_points_and_sharded_runner_on_gpu(tmp_path, monkeypatch):
     from src.ddpm_config import DDPMConfig
     cfg = {**DDPMConfig.cifar100_config}
@@ -159,6 +180,22 @@ def test_celeba_latent_mode_entry_points(tmp_path, monkeypatch):
     assert len(row["cluster_count"]) == 20 and sum(row["cluster_count"]) == 12
     assert abs(sum(row["cluster_proportions"]) - 1.0) < 1e-9 and 0.0 <= row["entropy"] <= np.log2(20) + 1e-9
     assert "fid_value" not in row and row["trained_steps"] == 2
+    # the same coalitions through the one-coalition-per-GPU scheduler (configs 3-5 in flight: gad.cycles + run_sharded)
+    from gad.coalition import run_sharded
+    from gad.cycles import CelebaCycle
+    db2 = str(tmp_path / "db_sharded.jsonl")
+    cyc = CelebaCycle(dev, ["--load", mdir, "--outdir", out, "--gd_steps", "2", "--n_samples", "12", "--batch_size", "6",
+                            "--num_inference_steps", "5", "--precompute_stage", "reuse"])
+    assert cyc.n_groups == 5 and len(cyc.extra_keys) == 21
+    recs = run_sharded(cyc, [2, 3], db_path=db2, verbose=True)
+    rows = [json.loads(l) for l in open(db2)]
+    assert [r["removal_seed"] for r in rows] == [2, 3] and not os.path.exists(db2 + ".rank0")
+    assert rows[0]["remaining_idx"] == row["remaining_idx"] and rows[0]["cluster_count"] == row["cluster_count"]
+    assert rows[0]["entropy"] == pytest.approx(row["entropy"], abs=1e-12)      # same seeds -> the same coalition, bit for bit
+    assert recs[0].extra[0] == pytest.approx(row["entropy"]) and recs[0].extra[1:] == row["cluster_count"]
+    assert recs[0].remaining_classes == sorted(kept)
+    v = recs[0].pack(cyc.n_groups, 21)                                         # what the final all_gather carries
+    assert type(recs[0]).unpack(v, 21).extra == recs[0].extra
 
 
 def test_ddpm_pipeline_with_the_ancestral_scheduler():

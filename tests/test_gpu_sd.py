@@ -295,6 +295,17 @@ def test_sd_model_behaviours_entry_point(tmp_path):
         assert math.isfinite(r[f"generated_image_{i}_simple_loss"]) and r[f"generated_image_{i}_simple_loss"] > 0
     for k in ("aesthetic_score_0.5", "aesthetic_score_0.9", "clip_prompt_score_avg", "aesthetic_score_avg", "exp_name", "seed"):
         assert k in r
+    # configs 4 / 5 through the one-coalition-per-GPU scheduler: train on the coalition, then the behaviours, one row each
+    from gad.coalition import run_sharded
+    from gad.cycles import SDLoRACycle
+    db2 = str(tmp_path / "sharded.jsonl")
+    cyc = SDLoRACycle(dev, common, [a_ for a_ in base if a_ not in ("--db", db)], n_groups=10)
+    recs = run_sharded(cyc, [1, 2], db_path=db2, verbose=True)                # seed 1 finds its trained LoRA (cancelled), seed 2 trains
+    srows = [json.loads(l) for l in open(db2)]
+    assert [r_["exp_name"] for r_ in srows] == ["retrain_artist_shapley_seed_1", "retrain_artist_shapley_seed_2"]
+    assert srows[0]["remaining_idx"] == r["remaining_idx"]
+    assert srows[0]["aesthetic_score_0.9"] == pytest.approx(r["aesthetic_score_0.9"], rel=1e-6)
+    assert recs[1].extra[2] == pytest.approx(srows[1]["aesthetic_score_0.9"]) and len(recs[1].extra) == 8
     assert rows[1]["remaining_idx"] is None                                   # full-data LoRA dir has no removal_idx.csv
     for i in range(3):                                                         # same weights, same seed -> identical samples
         assert rows[1][f"generated_image_{i}_nrmse"] == 0.0
