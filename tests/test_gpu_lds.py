@@ -2,7 +2,7 @@
 run on the HIP engine against the same coalitions run on the CPU oracle - same toy problem, same seeds, same host-drawn
 randomness (batches, noise, timesteps, sampler noise), same scorer - must agree within 0.02 (2 points on lds.py's x100
 scale).  Toy problem: CIFAR-20 layout at GAD_SYNTH_SCALE=0.032 (20 contributor classes x 16 images), a 4-stage U-Net,
-3 sFT steps at B=32, 16 samples x 5 DDIM steps per coalition; 24 Shapley coalitions to fit, 3 test sets x 16
+3 sFT steps at B=32, 16 samples x 5 DDIM steps per coalition; 20 Shapley coalitions to fit, 3 test sets x 12
 datamodel(alpha=0.5) subsets, full / null behaviours for the efficiency constraint; behaviour = Frechet distance under
 the test backend's projection features (the same function scores both sides)."""
 import numpy as np
@@ -60,6 +60,7 @@ def test_lds_from_hip_rows_matches_lds_from_oracle_rows(monkeypatch):
     from src.datasets import create_dataset, remove_data_by_datamodel, remove_data_by_shapley
     from src.ddpm_config import DDPMConfig
     monkeypatch.setenv("GAD_SYNTH_SCALE", "0.032")
+    torch.set_num_threads(min(16, torch.get_num_threads()))               # the GPU box grants a 16-CPU share
     ds = create_dataset("cifar100", train=True)
     assert len(ds) == 320 and len(set(ds.targets)) == 20
     x_all = ds.device_tensor("cpu")
@@ -74,10 +75,15 @@ def test_lds_from_hip_rows_matches_lds_from_oracle_rows(monkeypatch):
         return OB.fid_against_dataset(_coalition_images(kind, base_sd, x_all, remaining, rng_seed, ucfg, scfg), ds, "cpu")
 
     def rows(kind, subsets, seed0):
-        return [dict(removal_seed=k, remaining_idx=[int(i) for i in rem], fid_value=behaviour(kind, rem, seed0 + k))
-                for k, rem in subsets]
-    fit = [(k, remove_data_by_shapley(ds, seed=k, by_class=True)[0]) for k in range(24)]
-    tests = [(k, remove_data_by_datamodel(ds, alpha=0.5, seed=k, by_class=True)[0]) for k in range(16)]
+        import sys
+        import time
+        t0 = time.time()
+        out = [dict(removal_seed=k, remaining_idx=[int(i) for i in rem], fid_value=behaviour(kind, rem, seed0 + k))
+               for k, rem in subsets]
+        print(f"[lds toy] {kind}: {len(out)} coalitions in {time.time() - t0:.1f}s", file=sys.stderr, flush=True)
+        return out
+    fit = [(k, remove_data_by_shapley(ds, seed=k, by_class=True)[0]) for k in range(20)]
+    tests = [(k, remove_data_by_datamodel(ds, alpha=0.5, seed=k, by_class=True)[0]) for k in range(12)]
     res = {}
     for kind in ("hip", "oracle"):
         tr_m, tr_y, _ = masks_and_behaviours(rows(kind, fit, 1000), group_of, 20)
