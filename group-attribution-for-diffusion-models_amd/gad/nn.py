@@ -173,13 +173,14 @@ class Attention(nn.Module):
 
 
 class DownBlock(nn.Module):
-    def __init__(self, cin, cout, temb_c, layers, eps, groups, add_down, down_pad, head_dim=None):
+    def __init__(self, cin, cout, temb_c, layers, eps, groups, add_down, down_pad, attn=None):
+        """attn: None or (heads, dim_head) of the block's attentions"""
         super().__init__()
         resnets = nn.ModuleList([ResnetBlock2D(cin if i == 0 else cout, cout, temb_c, groups, eps)
                                  for i in range(layers)])
         # registration order attentions -> resnets as in diffusers (parameters() order == EMA shadow list order)
-        self.attentions = nn.ModuleList([Attention(cout, cout // head_dim, head_dim, eps, groups)
-                                         for _ in range(layers)]) if head_dim is not None else None
+        self.attentions = nn.ModuleList([Attention(cout, attn[0], attn[1], eps, groups)
+                                         for _ in range(layers)]) if attn is not None else None
         self.resnets = resnets
         if add_down:
             pad = (0, 1, 0, 1) if down_pad == 0 else (down_pad,) * 4   # Downsample2D: F.pad(0,1,0,1) when padding==0
@@ -212,10 +213,10 @@ class _Sampler(nn.Module):
 
 
 class UNetMidBlock2D(nn.Module):
-    def __init__(self, c, temb_c, eps, groups, head_dim, add_attention=True):
+    def __init__(self, c, temb_c, eps, groups, attn, add_attention=True):
         super().__init__()
         resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps), ResnetBlock2D(c, c, temb_c, groups, eps)])
-        self.attentions = nn.ModuleList([Attention(c, c // head_dim, head_dim, eps, groups) if add_attention else None])
+        self.attentions = nn.ModuleList([Attention(c, attn[0], attn[1], eps, groups) if add_attention else None])
         self.resnets = resnets
 
     def forward(self, h, temb_act):
@@ -226,15 +227,15 @@ class UNetMidBlock2D(nn.Module):
 
 
 class UpBlock(nn.Module):
-    def __init__(self, cin, prev_c, cout, temb_c, layers, eps, groups, add_up, head_dim=None):
+    def __init__(self, cin, prev_c, cout, temb_c, layers, eps, groups, add_up, attn=None):
         super().__init__()
         res = []
         for i in range(layers):
             skip_c = cin if i == layers - 1 else cout
             r_in = prev_c if i == 0 else cout
             res.append(ResnetBlock2D(r_in + skip_c, cout, temb_c, groups, eps))
-        self.attentions = nn.ModuleList([Attention(cout, cout // head_dim, head_dim, eps, groups)
-                                         for _ in range(layers)]) if head_dim is not None else None
+        self.attentions = nn.ModuleList([Attention(cout, attn[0], attn[1], eps, groups)
+                                         for _ in range(layers)]) if attn is not None else None
         self.resnets = nn.ModuleList(res)
         self.upsamplers = nn.ModuleList([_Sampler(Conv2d(cout, cout, 3, upsample=True))]) if add_up else None
 
@@ -272,7 +273,12 @@ class UNet2DModel(nn.Module):
                  downsample_padding=1, downsample_type="conv", upsample_type="conv", dropout=0.0,
                  act_fn="silu", attention_head_dim=8, norm_num_groups=32, attn_norm_num_groups=None,
                  norm_eps=1e-5, resnet_time_scale_shift="default", add_attention=True,
-                 class_embed_type=None, num_class_embeds=None, num_train_timesteps=None, **unused):
+                 class_embed_type=None, num_class_embeds=None, num_train_timesteps=None, attention_layout=None,
+                 **unused):
+        """attention_layout (not a diffusers key): [[heads, dim_head], ...] per resolution level for a head-grouped
+        pruned model (unconditional_generation/prune.py): the reference keeps the pickled module whose to_q/k/v lost the
+        same in-head channels in every head (prune.py:337-342), so heads stay and the head dim shrinks - a shape
+        `channels // attention_head_dim` cannot express."""
         super().__init__()
         cfg = dict(locals())
         for k in ("self", "unused", "__class__"):
@@ -285,6 +291,12 @@ class UNet2DModel(nn.Module):
             raise NotImplementedError("UNet2DModel: configuration outside the reference's registry")
         boc = list(block_out_channels)
         temb_c = boc[0] * 4
+
+        def attn_of(level, c):          # (heads, dim_head) of the attentions at resolution level `level`
+            if attention_layout is not None:
+                return int(attention_layout[level][0]), int(attention_layout[level][1])
+            hd = attention_head_dim if attention_head_dim is not None else c
+            return c // hd, hd
         self.conv_in = Conv2d(in_channels, boc[0], 3)
         self.time_proj = SimpleNamespace(num_channels=boc[0], flip_sin_to_cos=flip_sin_to_cos,
                                          downscale_freq_shift=freq_shift)
@@ -293,15 +305,14 @@ class UNet2DModel(nn.Module):
         out_c = boc[0]
         for i, typ in enumerate(down_block_types):
             in_c, out_c = out_c, boc[i]
-            hd = None
+            at = None
             if typ == "AttnDownBlock2D":
-                hd = attention_head_dim if attention_head_dim is not None else out_c
+                at = attn_of(i, out_c)
             elif typ != "DownBlock2D":
                 raise NotImplementedError(typ)
             self.down_blocks.append(DownBlock(in_c, out_c, temb_c, layers_per_block, norm_eps, norm_num_groups,
-                                              i != len(boc) - 1, downsample_padding, hd))
-        self.mid_block = UNetMidBlock2D(boc[-1], temb_c, norm_eps, norm_num_groups,
-                                        attention_head_dim if attention_head_dim is not None else boc[-1],
+                                              i != len(boc) - 1, downsample_padding, at))
+        self.mid_block = UNetMidBlock2D(boc[-1], temb_c, norm_eps, norm_num_groups, attn_of(len(boc) - 1, boc[-1]),
                                         add_attention)
         self.up_blocks = nn.ModuleList()
         rev = list(reversed(boc))
@@ -309,13 +320,13 @@ class UNet2DModel(nn.Module):
         for i, typ in enumerate(up_block_types):
             prev_c, out_c = out_c, rev[i]
             in_c = rev[min(i + 1, len(boc) - 1)]
-            hd = None
+            at = None
             if typ == "AttnUpBlock2D":
-                hd = attention_head_dim if attention_head_dim is not None else out_c
+                at = attn_of(len(boc) - 1 - i, out_c)
             elif typ != "UpBlock2D":
                 raise NotImplementedError(typ)
             self.up_blocks.append(UpBlock(in_c, prev_c, out_c, temb_c, layers_per_block + 1, norm_eps,
-                                          norm_num_groups, i != len(boc) - 1, hd))
+                                          norm_num_groups, i != len(boc) - 1, at))
         g = norm_num_groups if norm_num_groups is not None else min(boc[0] // 4, 32)
         self.conv_norm_out = GroupNorm(g, boc[0], norm_eps)
         self.conv_out = Conv2d(boc[0], out_channels, 3)

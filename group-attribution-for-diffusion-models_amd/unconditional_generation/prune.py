@@ -52,11 +52,20 @@ def pruned_width(w, ratio, groups):
     return w - (n_pruned // groups) * groups
 
 
+def pruned_head_dim(c, head_dim, ratio):
+    """Head dim a [heads * head_dim]-wide q / k / v projection keeps: the pruner removes int-truncated `ratio` of the
+    channels, the same number - and the same in-head positions - from every head."""
+    heads = c // head_dim
+    n_pruned = c - int(c * (1 - ratio))
+    return head_dim - n_pruned // heads
+
+
 class Space:
     """One tied channel dimension: `members` = (param name, dim, offset) with `width` channels each."""
 
-    def __init__(self, name, width, gn_groups=None, target=None):
+    def __init__(self, name, width, gn_groups=None, target=None, heads=None):
         self.name, self.width, self.gn, self.target = name, width, gn_groups, target
+        self.heads = heads         # head-grouped space: the same in-head channels are kept in every head
         self.members = []          # every tensor dim that is sliced with this space's kept indices
         self.scored = []           # subset of members that are conv / linear weights (importance)
         self.keep = None
@@ -75,8 +84,8 @@ def build_spaces(cfg, ratio=0.0):
     lpb = cfg.get("layers_per_block", 2)
     spaces = []
 
-    def new(name, width, gn=True, target=None):
-        s = Space(name, width, G if gn else None, target if target is not None else pruned_width(width, ratio, G))
+    def new(name, width, gn=True, target=None, heads=None):
+        s = Space(name, width, G if gn else None, target if target is not None else pruned_width(width, ratio, G), heads)
         spaces.append(s)
         return s
 
@@ -123,9 +132,17 @@ def build_spaces(cfg, ratio=0.0):
         produce(out, prefix + ".conv2")
         return out
 
+    head_dim = cfg.get("attention_head_dim")
+
     def attention(prefix, stream, c):
         consume([(stream, 0)], prefix + ".group_norm", norm=True)
-        qk, v = new(prefix + ".qk", c, gn=False), new(prefix + ".v", c, gn=False)
+        if head_dim is None:                         # one head of the full width (CIFAR): plain magnitude pruning
+            qk, v = new(prefix + ".qk", c, gn=False), new(prefix + ".v", c, gn=False)
+        else:                                        # multi-head (CelebA): channel_groups[to_q/k/v] = heads (prune.py:337-342)
+            heads = c // head_dim
+            tgt = heads * pruned_head_dim(c, head_dim, ratio)
+            qk = new(prefix + ".qk", c, gn=False, target=tgt, heads=heads)
+            v = new(prefix + ".v", c, gn=False, target=tgt, heads=heads)
         for proj, sp in (("to_q", qk), ("to_k", qk), ("to_v", v)):
             consume([(stream, 0)], f"{prefix}.{proj}")
             produce(sp, f"{prefix}.{proj}")
@@ -184,6 +201,11 @@ def channel_scores(space, sd):
 
 def select_channels(space, sd, target, mode="magnitude", rng=None):
     score = channel_scores(space, sd) if mode == "magnitude" else rng.rand(space.width)
+    if space.heads:                                  # importance summed over the heads per in-head position
+        d = space.width // space.heads
+        keep_d = target // space.heads
+        pos = np.sort(np.argsort(-score.reshape(space.heads, d).sum(axis=0), kind="stable")[:keep_d])
+        return np.concatenate([h * d + pos for h in range(space.heads)])
     if space.gn:
         cpg = space.width // space.gn
         keep_per = target // space.gn
@@ -216,9 +238,11 @@ def prune_state_dict(cfg, sd, ratio, mode="magnitude", seed=42):
             idx = torch.as_tensor(np.concatenate([off + keep for off, _, keep in parts]))
             t = t.index_select(dim, idx)
         out[name] = t.contiguous()
-    if cfg.get("attention_head_dim") is not None:
-        raise NotImplementedError("head-grouped q/k/v pruning (CelebA, prune.py:337-342) is not restated yet")
-    return dict(cfg, block_out_channels=new_boc), out
+    new_cfg = dict(cfg, block_out_channels=new_boc)
+    if cfg.get("attention_head_dim") is not None:    # heads stay, the head dim shrinks: not expressible as channels // head_dim
+        hd = cfg["attention_head_dim"]
+        new_cfg["attention_layout"] = [[w // hd, pruned_head_dim(w, hd, ratio)] for w in boc]
+    return new_cfg, out
 
 
 def main(args, backend=None):

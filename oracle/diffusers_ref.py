@@ -193,14 +193,14 @@ class DownBlock(nn.Module):
     """DownBlock2D / AttnDownBlock2D."""
 
     def __init__(self, in_c, out_c, temb_c, num_layers, eps, groups, add_downsample, downsample_padding,
-                 attn_head_dim=None):
+                 attn=None):
         super().__init__()
         resnets = nn.ModuleList([
             ResnetBlock2D(in_c if i == 0 else out_c, out_c, temb_c, groups, eps) for i in range(num_layers)])
         # diffusers registers `attentions` before `resnets` in Attn*Block2D (parameters() order -> EMA list order)
-        if attn_head_dim is not None:
+        if attn is not None:                       # (heads, dim_head)
             self.attentions = nn.ModuleList([
-                Attention(out_c, out_c // attn_head_dim, attn_head_dim, eps, groups) for _ in range(num_layers)])
+                Attention(out_c, attn[0], attn[1], eps, groups) for _ in range(num_layers)])
         else:
             self.attentions = None
         self.resnets = resnets
@@ -220,12 +220,12 @@ class DownBlock(nn.Module):
 
 
 class UNetMidBlock2D(nn.Module):
-    def __init__(self, c, temb_c, eps, groups, attn_head_dim, add_attention=True):
+    def __init__(self, c, temb_c, eps, groups, attn, add_attention=True):
         super().__init__()
         resnets = nn.ModuleList([ResnetBlock2D(c, c, temb_c, groups, eps),
                                  ResnetBlock2D(c, c, temb_c, groups, eps)])
         self.attentions = nn.ModuleList([
-            Attention(c, c // attn_head_dim, attn_head_dim, eps, groups) if add_attention else None])
+            Attention(c, attn[0], attn[1], eps, groups) if add_attention else None])
         self.resnets = resnets
 
     def forward(self, h, temb):
@@ -238,16 +238,16 @@ class UNetMidBlock2D(nn.Module):
 class UpBlock(nn.Module):
     """UpBlock2D / AttnUpBlock2D."""
 
-    def __init__(self, in_c, prev_c, out_c, temb_c, num_layers, eps, groups, add_upsample, attn_head_dim=None):
+    def __init__(self, in_c, prev_c, out_c, temb_c, num_layers, eps, groups, add_upsample, attn=None):
         super().__init__()
         res = []
         for i in range(num_layers):
             skip_c = in_c if i == num_layers - 1 else out_c
             r_in = prev_c if i == 0 else out_c
             res.append(ResnetBlock2D(r_in + skip_c, out_c, temb_c, groups, eps))
-        if attn_head_dim is not None:
+        if attn is not None:
             self.attentions = nn.ModuleList([
-                Attention(out_c, out_c // attn_head_dim, attn_head_dim, eps, groups) for _ in range(num_layers)])
+                Attention(out_c, attn[0], attn[1], eps, groups) for _ in range(num_layers)])
         else:
             self.attentions = None
         self.resnets = nn.ModuleList(res)
@@ -277,7 +277,8 @@ class UNet2DModel(nn.Module):
                  downsample_padding=1, downsample_type="conv", upsample_type="conv", dropout=0.0,
                  act_fn="silu", attention_head_dim=8, norm_num_groups=32, attn_norm_num_groups=None,
                  norm_eps=1e-5, resnet_time_scale_shift="default", add_attention=True,
-                 class_embed_type=None, num_class_embeds=None, num_train_timesteps=None, **unused):
+                 class_embed_type=None, num_class_embeds=None, num_train_timesteps=None, attention_layout=None,
+                 **unused):
         super().__init__()
         cfg = dict(locals())
         for k in ("self", "unused", "__class__"):
@@ -292,19 +293,23 @@ class UNet2DModel(nn.Module):
         self.time_proj = Timesteps(boc[0], flip_sin_to_cos, freq_shift)
         self.time_embedding = TimestepEmbedding(boc[0], temb_c)
         self.down_blocks = nn.ModuleList()
+        def attn_of(level, c):          # (heads, dim_head); attention_layout: head-grouped pruned models (prune.py:337-342)
+            if attention_layout is not None:
+                return int(attention_layout[level][0]), int(attention_layout[level][1])
+            hd_ = attention_head_dim if attention_head_dim is not None else c
+            return c // hd_, hd_
         out_c = boc[0]
         for i, typ in enumerate(down_block_types):
             in_c, out_c = out_c, boc[i]
             final = i == len(boc) - 1
             hd = None
             if typ == "AttnDownBlock2D":
-                hd = attention_head_dim if attention_head_dim is not None else out_c
+                hd = attn_of(i, out_c)
             elif typ != "DownBlock2D":
                 raise ValueError(typ)
             self.down_blocks.append(DownBlock(in_c, out_c, temb_c, layers_per_block, norm_eps, norm_num_groups,
                                               not final, downsample_padding, hd))
-        self.mid_block = UNetMidBlock2D(boc[-1], temb_c, norm_eps, norm_num_groups,
-                                        attention_head_dim if attention_head_dim is not None else boc[-1],
+        self.mid_block = UNetMidBlock2D(boc[-1], temb_c, norm_eps, norm_num_groups, attn_of(len(boc) - 1, boc[-1]),
                                         add_attention)
         self.up_blocks = nn.ModuleList()
         rev = list(reversed(boc))
@@ -315,7 +320,7 @@ class UNet2DModel(nn.Module):
             final = i == len(boc) - 1
             hd = None
             if typ == "AttnUpBlock2D":
-                hd = attention_head_dim if attention_head_dim is not None else out_c
+                hd = attn_of(len(boc) - 1 - i, out_c)
             elif typ != "UpBlock2D":
                 raise ValueError(typ)
             self.up_blocks.append(UpBlock(in_c, prev_c, out_c, temb_c, layers_per_block + 1, norm_eps,

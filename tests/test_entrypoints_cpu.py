@@ -211,6 +211,66 @@ def test_structural_magnitude_pruning(tmp_path):
     assert out.endswith("toy2/pruned/models/pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
 
 
+def test_head_grouped_pruning_of_the_celeba_topology():
+    """prune.py:337-342 (channel_groups[to_q/k/v] = heads): every head of q / k / v keeps the SAME in-head channels, the
+    stream widths follow the GroupNorm rule, the sliced state_dict loads strictly into the `attention_layout` model and
+    - when the dropped channels are exactly zero - the pruned attention computes the same function."""
+    from src.ddpm_config import DDPMConfig
+    from unconditional_generation import prune as P
+    cfg = dict(DDPMConfig.celeba_config["unet_config"], block_out_channels=[64, 128, 128, 128], attention_head_dim=16,
+               norm_num_groups=16, sample_size=16)
+    assert P.pruned_head_dim(448, 32, 0.3) == 23 and P.pruned_head_dim(896, 32, 0.3) == 23       # the real CelebA widths
+    assert P.pruned_head_dim(128, 16, 0.3) == 12
+    torch.manual_seed(0)
+    net = OB.UNet2DModel(**cfg)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    # in-head positions 1, 5, 9, 13 of every head of one attention: zero q / k / v rows (and the to_out columns of v)
+    pre = "down_blocks.1.attentions.0"
+    dead = [h * 16 + j for h in range(8) for j in (1, 5, 9, 13)]
+    for proj in ("to_q", "to_k", "to_v"):
+        sd[f"{pre}.{proj}.weight"][dead] = 0
+        sd[f"{pre}.{proj}.bias"][dead] = 0
+    new_cfg, new_sd = P.prune_state_dict(cfg, sd, 0.3)
+    assert new_cfg["block_out_channels"] == [48, 96, 96, 96] and new_cfg["attention_layout"] == [[4, 11], [8, 12], [8, 12], [8, 12]]
+    assert new_sd[f"{pre}.to_q.weight"].shape == (96, 96) and new_sd[f"{pre}.to_out.0.weight"].shape == (96, 96)
+    spaces = {s.name: s for s in P.build_spaces(cfg, 0.3)}
+    for nm in (f"{pre}.qk", f"{pre}.v"):
+        keep = P.select_channels(spaces[nm], sd, spaces[nm].target)
+        assert len(keep) == 96 and not set(keep) & set(dead)
+        per_head = keep.reshape(8, 12) - 16 * np.arange(8)[:, None]
+        assert (per_head == per_head[0]).all()                                 # identical in-head positions in every head
+    small = OB.UNet2DModel(**new_cfg)
+    small.load_state_dict(new_sd)                                              # strict
+    assert small.down_blocks[1].attentions[0].heads == 8
+    y = small(torch.randn(1, 3, 16, 16), torch.tensor([10])).sample
+    assert y.shape == (1, 3, 16, 16) and torch.isfinite(y).all()
+    # function preservation on the attention whose dropped q/k/v channels were zero: slice the stream channels by hand
+    att, att_s = net.down_blocks[1].attentions[0], small.down_blocks[1].attentions[0]
+    net.load_state_dict(sd)
+    skeep = P.select_channels(spaces["down_blocks.1.resnets.0.out"], sd, 96)
+    qk_keep = P.select_channels(spaces[f"{pre}.qk"], sd, 96)
+    v_keep = P.select_channels(spaces[f"{pre}.v"], sd, 96)
+    h = torch.randn(2, 64, 128)                                                # [B, T, C] tokens after the group norm
+    with torch.no_grad():
+        def core(a, x, heads):
+            q, k, v = a.to_q(x), a.to_k(x), a.to_v(x)
+            d = q.shape[-1] // heads
+            sp = lambda z: z.view(2, 64, heads, d).transpose(1, 2)
+            return torch.nn.functional.scaled_dot_product_attention(sp(q), sp(k), sp(v)).transpose(1, 2).reshape(2, 64, -1)
+        hs = h.clone()
+        mask = torch.zeros(128, dtype=torch.bool)
+        mask[torch.as_tensor(skeep)] = True
+        hs[..., ~mask] = 0                                                     # the pruned stream channels are silent
+        got = core(att_s, h[..., torch.as_tensor(skeep)], 8)
+    # the softmax scale changes with the head dim (1/sqrt(12) instead of 1/sqrt(16)): compare against the full model
+    # evaluated at the new scale
+    with torch.no_grad():
+        q, k, v = (getattr(att, n)(hs) for n in ("to_q", "to_k", "to_v"))
+        sp = lambda z, idx: z[..., torch.as_tensor(idx)].view(2, 64, 8, 12).transpose(1, 2)
+        ref = torch.nn.functional.scaled_dot_product_attention(sp(q, qk_keep), sp(k, qk_keep), sp(v, v_keep)).transpose(1, 2).reshape(2, 64, -1)
+    assert torch.allclose(got, ref, atol=1e-5)
+
+
 def test_artbench_metadata_to_latent_cache(tmp_path):
     """metadata.csv / {style}_artists.csv grammar of the reference (create_metadata.py:77-95,113-114) joined with
     precomputed latents into the trainer's latent cache."""

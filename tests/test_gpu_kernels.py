@@ -372,6 +372,38 @@ def test_unet_forward_pruned_widths(ops):
     close(mine(x.to(dev), t.to(dev)).sample, ref(x, t).sample, atol=1e-4)
 
 
+def test_unet_forward_backward_head_grouped_pruned_celeba_layout(ops):
+    """A CelebA-topology model after unconditional_generation/prune.py (head-grouped q/k/v, prune.py:337-342): heads stay,
+    the head dim shrinks (32 -> 23 at the real widths; 16 -> 12 here, plus an odd 16 -> 11 level), inner dim != stream
+    width.  Forward and a parameter gradient against the oracle on the same pruned weights."""
+    import gad
+    from oracle import diffusers_ref as R
+    from src.ddpm_config import DDPMConfig
+    from unconditional_generation import prune as P
+    cfg = dict(DDPMConfig.celeba_config["unet_config"], block_out_channels=[64, 128, 128, 128], attention_head_dim=16,
+               norm_num_groups=16, sample_size=16, down_block_types=["AttnDownBlock2D"] * 4, up_block_types=["AttnUpBlock2D"] * 4)
+    torch.manual_seed(0)
+    big = R.UNet2DModel(**cfg)
+    new_cfg, new_sd = P.prune_state_dict(cfg, {k: v.detach().clone() for k, v in big.state_dict().items()}, 0.3)
+    assert new_cfg["attention_layout"] == [[4, 11], [8, 12], [8, 12], [8, 12]]
+    ref, mine = R.UNet2DModel(**new_cfg), gad.UNet2DModel(**new_cfg)
+    ref.load_state_dict(new_sd)
+    mine.load_state_dict(new_sd)
+    mine.to(dev)
+    x, t = rnd(2, 3, 16, 16, seed=1), torch.tensor([3, 700])
+    want = ref(x, t).sample
+    got = mine(x.to(dev), t.to(dev)).sample
+    close(got, want, atol=1e-4)
+    dy = rnd(2, 3, 16, 16, seed=2)
+    want.backward(dy)
+    got.backward(dy.to(dev))
+    for name in ("down_blocks.0.attentions.0.to_q.weight", "mid_block.attentions.0.to_v.weight", "up_blocks.1.attentions.2.to_out.0.weight"):
+        gr, gm = dict(ref.named_parameters())[name].grad, dict(mine.named_parameters())[name].grad.cpu()
+        assert ((gm - gr).norm() / gr.norm()).item() < 2e-3, name
+    with torch.no_grad():                                      # sampling mode: inner != stream width -> three projections
+        close(mine(x.to(dev), t.to(dev)).sample, want, atol=1e-4)
+
+
 # ------------------------------------------------------------------- bf16-operand mode ----
 def _bf16_round(t):
     return t.to(torch.bfloat16).to(torch.float64)
