@@ -285,15 +285,29 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
              tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
-             B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and not torch.is_grad_enabled()
-                                       and Cin % 32 == 0 and not torch.cuda.is_current_stream_capturing()) else None)
+             B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
+                                       and not torch.cuda.is_current_stream_capturing()) else None)
     return y
 
 
 def bf16_weight(w):
-    """bf16 (RNE) copy of a conv weight in its [Cout][KH][KW][Cin] storage, cached on the parameter until it changes
-    (torch version counter, or the epoch the raw optimizer kernels bump).  Inference only: the bf16-mode patch
-    convolution streams it by LDS-DMA instead of rounding the fp32 weights in every workgroup."""
+    """bf16 (RNE) copy of a conv weight in its [Cout][KH][KW][Cin] storage: the bf16-mode patch convolution streams it by
+    LDS-DMA instead of rounding the fp32 weights in every workgroup.  A parameter that lives in a flat buffer
+    (training.flatten_params) is served from ONE bf16 shadow of the whole buffer, refreshed by a single cast when the
+    weights changed (torch version counter, or the epoch the raw optimizer kernels bump) - so training pays one cast per
+    step, not one per layer; any other parameter caches its own copy."""
+    home = getattr(w, "_gad_flat", None)
+    if home is not None and w.data_ptr() == home[0].data_ptr() + 4 * home[1]:
+        flat, off, n = home
+        key = (flat._version, WEIGHT_EPOCH[0])
+        cached = getattr(flat, "_gad_bf16", None)
+        if cached is None or cached[0] != key:
+            shadow = cached[1] if cached is not None else torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
+            shadow.copy_(flat.detach())
+            cached = (key, shadow)
+            flat._gad_bf16 = cached
+        o, i, kh, kw = w.shape
+        return cached[1][off:off + n].view(o, kh, kw, i)
     key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
     cached = getattr(w, "_gad_bf16", None)
     if cached is None or cached[0] != key:

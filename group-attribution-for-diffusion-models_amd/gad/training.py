@@ -8,12 +8,20 @@ import torch
 from . import ops
 
 
+SLOT = 8      # slices start at multiples of 8 elements: 32-B aligned in fp32, 16-B aligned in a bf16 shadow of the buffer
+
+
+def _slot(n):
+    return (n + SLOT - 1) // SLOT * SLOT
+
+
 def flatten_params(params):
     """Re-home the given parameters (and their .grad) in one contiguous fp32 buffer each, keeping conv weights'
-    [Cout,KH,KW,Cin] storage.  Every slice starts 16-B aligned.  Returns (flat, flat_grad)."""
+    [Cout,KH,KW,Cin] storage.  Every slice starts 32-B aligned (so the same offsets are 16-B aligned in a bf16 copy of
+    the whole buffer: `ops.bf16_weight`).  Returns (flat, flat_grad)."""
     params = list(params)
     dev = params[0].device
-    sizes = [(p.numel() + 3) // 4 * 4 for p in params]
+    sizes = [_slot(p.numel()) for p in params]
     flat = torch.zeros(sum(sizes), device=dev, dtype=torch.float32)
     gflat = torch.zeros_like(flat)
     off = 0
@@ -33,6 +41,7 @@ def flatten_params(params):
             p.grad = None
             p._gad_sink = view_like(gflat)               # gradient kernels write here directly (ops._sink)
             p._gad_sink_epoch = -1
+            p._gad_flat = (flat, off, n)                 # where the parameter lives (one bf16 cast serves all of them)
             off += sz
     return flat, gflat
 
@@ -47,7 +56,7 @@ def flat_views(params, buf):
             yield buf[off:off + n].view(o, kh, kw, i).permute(0, 3, 1, 2)
         else:
             yield buf[off:off + n].view(p.shape)
-        off += (n + 3) // 4 * 4
+        off += _slot(n)
 
 
 def adam_state_to_torch(params, m, v, step, hp):
@@ -147,7 +156,7 @@ class EMAModel:
                 v = sflat[off:off + n].view(p.shape)
             v.copy_(s.to(v.device))
             new.append(v)
-            off += (n + 3) // 4 * 4
+            off += _slot(n)
         self.shadow_params = new
         self._flat = sflat
         return sflat
