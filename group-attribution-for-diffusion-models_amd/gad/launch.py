@@ -117,6 +117,8 @@ def worker(a) -> int:
     from gad.coalition import CoalitionEngine, run_sharded
 
     world, rank, local = int(os.environ["WORLD_SIZE"]), int(os.environ["RANK"]), int(os.environ["LOCAL_RANK"])
+    if os.environ.get("GAD_SHARE_GPU0"):            # rehearsal of the N-rank path on a one-GPU box (with --backend gloo)
+        local = 0
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
