@@ -73,6 +73,10 @@ struct DevArgs {
   const unsigned short* Bh;   // bf16 copy of B ([N][ldb], k contiguous): bf16 patch conv streams it by LDS-DMA
   const float* A2;   // two-source conv gather (virtual channel concat): channels >= a_split come from A2
   int a_split, ldx2;
+  // K-concatenated dense operands (fused LoRA side path): for k >= k_split the products read Ak2 / Bk2 at k - k_split
+  const float* Ak2;
+  const float* Bk2;
+  int lda2, ldb2, k_split;
   int M, N, K;
   int lda, ldb, ldc;
   int batch_inner;
@@ -183,6 +187,74 @@ struct LoadKCDense : KCSlots<ROWS> {
     }
     v[i] = t;
   }
+};
+
+// dense [row][k] whose K axis is the concatenation of two tensors: k < ksplit from (base, ld), the rest from (base2, ld2)
+// at k - ksplit.  ksplit % 32 == 0, so a K step lies inside one segment; float4 path only.
+template <int ROWS>
+struct LoadKCDense2 : KCSlots<ROWS> {
+  using S = KCSlots<ROWS>;
+  const float* base;
+  const float* base2;
+  long roff[S::NS], roff2[S::NS];
+  unsigned rowmask;
+  int kend, ksplit, k;
+  bool kok, second;
+  __device__ void init(const float* b, int ld, const float* b2, int ld2, int ksplit_, int row0, int nrows, int kend_) {
+    base = b;
+    base2 = b2;
+    kend = kend_;
+    ksplit = ksplit_;
+    rowmask = 0;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int r = row0 + S::row(i);
+      bool ok = r < nrows;
+      roff[i] = ok ? (long)r * ld : 0;
+      roff2[i] = ok ? (long)r * ld2 : 0;
+      rowmask |= (unsigned)ok << i;
+    }
+  }
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) {
+    second = k0 >= ksplit;
+    k = k0 + S::kq4();
+    kok = k < kend;
+    mask = rowmask;
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    bool ok = kok && ((rowmask >> i) & 1u);
+    return second ? sel_src(base2, roff2[i] + (k - ksplit), ok) : sel_src(base, roff[i] + k, ok);
+  }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
+};
+
+// dense [k][row] with the same K concatenation (rows of the second tensor follow the first's)
+template <int ROWS>
+struct LoadMCDense2 : MCSlots<ROWS> {
+  using S = MCSlots<ROWS>;
+  const float* base;
+  const float* base2;
+  int ld, ld2, kend, ksplit, c0, nrows, k0;
+  __device__ void init(const float* b, int ld_, const float* b2, int ld2_, int ksplit_, int row0, int nrows_, int kend_) {
+    base = b;
+    base2 = b2;
+    ld = ld_;
+    ld2 = ld2_;
+    ksplit = ksplit_;
+    kend = kend_;
+    nrows = nrows_;
+    c0 = row0 + S::rq4();
+  }
+  __device__ __forceinline__ void prep(int k0_, unsigned& mask) {
+    k0 = k0_;
+    mask = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const {
+    int k = k0 + S::krow(i);
+    bool ok = k < kend && c0 < nrows;
+    return k >= ksplit ? sel_src(base2, (long)(k - ksplit) * ld2 + c0, ok) : sel_src(base, (long)k * ld + c0, ok);
+  }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
 };
 
 // dense [k][row]
@@ -470,8 +542,32 @@ struct ALoader<GAD_A_CONVT, ROWS, VEC> : LoadConvRows<ROWS, true, VEC> {
   __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p, row0, p.M, kend); }
 };
 
+constexpr int A_KC2 = 17;     // internal: A_KC whose K axis continues in a second tensor (fused LoRA)
+template <int ROWS, int VEC>
+struct ALoader<A_KC2, ROWS, VEC> : LoadKCDense2<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) {
+    this->init(a, p.lda, p.Ak2, p.lda2, p.k_split, row0, p.M, kend);
+  }
+};
+
 template <int MODE, int ROWS, int VEC>
 struct BLoader;
+constexpr int B_KC2 = 18, B_MC2 = 19;   // internal: B_KC / B_MC with the same K concatenation
+template <int ROWS, int VEC>
+struct BLoader<B_KC2, ROWS, VEC> : LoadKCDense2<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) {
+    this->init(b, p.ldb, p.Bk2, p.ldb2, p.k_split, col0, p.N, kend);
+  }
+};
+template <int ROWS, int VEC>
+struct BLoader<B_MC2, ROWS, VEC> : LoadMCDense2<ROWS> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) {
+    this->init(b, p.ldb, p.Bk2, p.ldb2, p.k_split, col0, p.N, kend);
+  }
+};
 template <int ROWS, int VEC>
 struct BLoader<GAD_B_KC, ROWS, VEC> : LoadKCDense<ROWS, VEC> {
   static constexpr bool KC = true;
@@ -1536,8 +1632,9 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   // --- shape / alignment contracts of the float4 paths (checked on the host so that a
   //     mismatch is an error, never an out-of-bounds access on the device) ---
   GAD_CHECK(gad_aligned16(a->A) && gad_aligned16(a->B), "gad_gemm: A/B must be 16-byte aligned");
+  const int k_first = a->A_k2 ? a->k_split : a->K;      // K-concatenated form: the first tensor covers k < k_split only
   if (am == GAD_A_KC) {
-    GAD_CHECK(a->lda >= a->K, "gad_gemm: A_KC needs lda >= K (K=%d lda=%d)", a->K, a->lda);
+    GAD_CHECK(a->lda >= k_first, "gad_gemm: A_KC needs lda >= K (K=%d lda=%d)", k_first, a->lda);
     if (a->K % 4 != 0 || a->lda % 4 != 0) vec = 1;
   }
   if (am == GAD_A_MC) {
@@ -1545,7 +1642,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     if (a->M % 4 != 0 || a->lda % 4 != 0) vec = 1;
   }
   if (bmode == GAD_B_KC) {
-    GAD_CHECK(a->ldb >= a->K, "gad_gemm: B_KC needs ldb >= K (K=%d ldb=%d)", a->K, a->ldb);
+    GAD_CHECK(a->ldb >= k_first, "gad_gemm: B_KC needs ldb >= K (K=%d ldb=%d)", k_first, a->ldb);
     if (a->K % 4 != 0 || a->ldb % 4 != 0) vec = 1;
   }
   if (bmode == GAD_B_MC) {
@@ -1581,6 +1678,18 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     GAD_CHECK(a->ldx2 >= a->g.C - a->a_split && a->ldx2 % 4 == 0 && gad_aligned16(a->A2) && vec == 4,
               "gad_gemm: two-source gather: bad ldx2 / alignment");
   }
+  const bool ksplit2 = a->A_k2 != nullptr;
+  if (ksplit2) {
+    GAD_CHECK(am == GAD_A_KC && (bmode == GAD_B_KC || bmode == GAD_B_MC) && a->B_k2 && !a->A2 && a->batch <= 1,
+              "gad_gemm: the K-concatenated form (A_k2 / B_k2) is an A_KC x B_KC|B_MC feature");
+    GAD_CHECK(a->k_split > 0 && a->k_split < a->K && a->k_split % 32 == 0, "gad_gemm: k_split must be a multiple of 32 inside (0, K) (k_split=%d K=%d)", a->k_split, a->K);
+    const int k2 = a->K - a->k_split;
+    GAD_CHECK(a->lda >= a->k_split && a->lda_k2 >= k2 && a->lda_k2 % 4 == 0 && k2 % 4 == 0 && gad_aligned16(a->A_k2) && gad_aligned16(a->B_k2),
+              "gad_gemm: K-concatenated operands need 16-byte alignment and K2 %% 4 == 0 (K2=%d lda_k2=%d)", k2, a->lda_k2);
+    if (bmode == GAD_B_KC) GAD_CHECK(a->ldb >= a->k_split && a->ldb_k2 >= k2 && a->ldb_k2 % 4 == 0, "gad_gemm: bad ldb_k2");
+    else GAD_CHECK(a->ldb_k2 >= a->N && a->ldb_k2 % 4 == 0, "gad_gemm: bad ldb_k2");
+    GAD_CHECK(vec == 4, "gad_gemm: the K-concatenated form needs the float4 path");
+  }
   if (a->rowadd) GAD_CHECK(a->rows_per_group > 0 && a->ld_rowadd >= a->N, "gad_gemm: bad rowadd");
   if (a->residual) GAD_CHECK(a->ldr >= a->N, "gad_gemm: bad residual stride");
   GAD_CHECK(a->ldc >= a->N, "gad_gemm: ldc < N");
@@ -1590,6 +1699,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   DevArgs d;
   d.A = a->A; d.B = a->B; d.C = a->C;
   d.A2 = a->A2; d.a_split = a->a_split; d.ldx2 = a->ldx2;
+  d.Ak2 = a->A_k2; d.Bk2 = a->B_k2; d.lda2 = a->lda_k2; d.ldb2 = a->ldb_k2; d.k_split = a->k_split;
   d.Bh = nullptr;
   d.M = a->M; d.N = a->N; d.K = a->K;
   d.lda = a->lda; d.ldb = a->ldb; d.ldc = a->ldc;
@@ -1703,6 +1813,14 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   if (a->A2) {
     if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
     else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);
+  } else if (ksplit2) {
+    if (bmode == GAD_B_KC) {
+      if (bf16) launch_bf16<A_KC2, B_KC2>(d, pl, st);
+      else launch_mode<A_KC2, B_KC2, 4>(d, pl, st);
+    } else {
+      if (bf16) launch_bf16<A_KC2, B_MC2>(d, pl, st);
+      else launch_mode<A_KC2, B_MC2, 4>(d, pl, st);
+    }
   } else
 #define GAD_CASE(AMODE, BMODE_)                                                        \
   if (am == AMODE && bmode == BMODE_) {                                                \

@@ -35,7 +35,8 @@ class GemmArgs(C.Structure):
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
                 ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32),
                 ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p),
-                ("flags", C.c_int32)]
+                ("A_k2", C.c_void_p), ("B_k2", C.c_void_p), ("lda_k2", C.c_int32), ("ldb_k2", C.c_int32),
+                ("k_split", C.c_int32), ("flags", C.c_int32)]
 
 
 class GroupNormArgs(C.Structure):

@@ -59,10 +59,14 @@ class Linear(nn.Module):
     def forward(self, x, residual=None, scale: float = 1.0):
         if self.lora_layer is None:
             return ops.linear(x, self.weight, self.bias, residual)
-        # y = xW^T + b + scale * up(down(x)): the rank-r side path accumulates into the base
-        # GEMM's output through the residual epilogue (LoRACompatibleLinear)
+        # y = xW^T + b + scale * up(down(x))  (LoRACompatibleLinear)
+        ll = self.lora_layer
+        if ops.lora_fusable(self.weight.shape[1], self.weight.shape[0], ll.rank):
+            s = scale * (ll.network_alpha / ll.rank if ll.network_alpha is not None else 1.0)
+            return ops.lora_linear(x, self.weight, self.bias, ll.down.weight, ll.up.weight, s, residual)   # one K-concatenated launch
+        # ragged ranks that are not multiples of 4: the side path accumulates into the base GEMM's output (two launches)
         base = ops.linear(x, self.weight, self.bias, residual)
-        return self.lora_layer(x, residual=base, scale=scale)
+        return ll(x, residual=base, scale=scale)
 
 
 class LoRALinearLayer(nn.Module):

@@ -162,7 +162,8 @@ class kernel_flags:
 
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
-             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None):
+             sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
+             A_k2=None, B_k2=None, k_split=0):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -189,6 +190,9 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
         a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]
     if B_bf16 is not None:
         a.B_bf16 = B_bf16.data_ptr()
+    if A_k2 is not None:            # K-concatenated operands (fused LoRA): k >= k_split reads A_k2 / B_k2
+        a.A_k2, a.B_k2, a.k_split = A_k2.data_ptr(), B_k2.data_ptr(), k_split
+        a.lda_k2, a.ldb_k2 = A_k2.shape[-1], B_k2.shape[-1]
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -469,6 +473,66 @@ class LinearFn(torch.autograd.Function):
 
 def linear(x, w, bias=None, residual=None):
     return LinearFn.apply(x, w, bias, residual)
+
+
+def lora_fusable(in_features: int, out_features: int, rank: int) -> bool:
+    """Can y = x W^T + b + s (x A^T) B^T run as down-GEMM + ONE K-concatenated GEMM (forward and data gradient)?
+    The K split points (in_features forward, out_features backward) must be multiples of the 32-wide K step and the rank
+    a multiple of 4 (float4 staging); pruned ragged ranks that are not take the two-launch route."""
+    return in_features % 32 == 0 and out_features % 32 == 0 and rank % 4 == 0 and rank > 0
+
+
+class LoraLinearFn(torch.autograd.Function):
+    """diffusers LoRACompatibleLinear with a LoRALinearLayer set (text_to_image/train_text_to_image_lora.py:786-820,
+    SURVEY A.11): y = x W^T + b + s (x A^T) B^T [+ residual].
+    Forward:  mid = s x A^T (alpha epilogue), then ONE launch over the concatenated K axis [x | mid] . [W | B]^T.
+    Backward: dmid = s dy B, then ONE launch dx = [dy | dmid] . [W ; A]; dB = dy^T mid, dA = dmid^T x (and dW, db when
+    the base is trainable).  Against base GEMM + residual-accumulating side GEMM this drops one launch and one
+    read + write pass over y (forward) / dx (backward) per projection - 128 projections in the SD U-Net."""
+
+    @staticmethod
+    def forward(ctx, x, w, bias, down, up, s, residual):
+        shp = x.shape
+        x2 = _req(x, "lora linear x").view(-1, shp[-1])
+        M, K = x2.shape
+        N, r = up.shape
+        mid = torch.empty((M, r), device=x.device, dtype=torch.float32)
+        gemm_raw(x2, down, mid, A_KC, B_KC, M, r, K, K, K, r, alpha=s)
+        y = torch.empty((M, N), device=x.device, dtype=torch.float32)
+        r2 = residual.view(-1, N) if residual is not None else None
+        gemm_raw(x2, w, y, A_KC, B_KC, M, N, K + r, K, K, N, bias=bias, residual=r2, ldr=N, A_k2=mid, B_k2=up, k_split=K)
+        ctx.save_for_backward(x2, w, down, up, mid)
+        ctx.meta = (shp, s, bias, residual is not None)
+        return y.view(*shp[:-1], N)
+
+    @staticmethod
+    def backward(ctx, dy):
+        x2, w, down, up, mid = ctx.saved_tensors
+        shp, s, bias, has_res = ctx.meta
+        M, K = x2.shape
+        N, r = up.shape
+        dy2 = dy.contiguous().view(-1, N)
+        need_x = ctx.needs_input_grad[0]
+        need_lora = ctx.needs_input_grad[3] or ctx.needs_input_grad[4]
+        dmid = None
+        if need_x or ctx.needs_input_grad[3]:
+            dmid = torch.empty((M, r), device=dy2.device, dtype=torch.float32)
+            gemm_raw(dy2, up, dmid, A_KC, B_MC, M, r, N, N, r, r, alpha=s)                  # s dy B
+        dx = None
+        if need_x:
+            dx = torch.empty((M, K), device=dy2.device, dtype=torch.float32)
+            gemm_raw(dy2, w, dx, A_KC, B_MC, M, K, N + r, N, K, K, A_k2=dmid, B_k2=down, k_split=N)
+            dx = dx.view(shp)
+        dw = _param_grad(w, lambda o: linear_wgrad_raw(dy2, x2, out=o)) if ctx.needs_input_grad[1] else None
+        db = _param_grad(bias, lambda o: colsum_raw(dy2, 1, out=o).view(-1)) if (bias is not None and ctx.needs_input_grad[2]) else None
+        dd = _param_grad(down, lambda o: linear_wgrad_raw(dmid, x2, out=o)) if ctx.needs_input_grad[3] else None      # dmid^T x
+        du = _param_grad(up, lambda o: linear_wgrad_raw(dy2, mid, out=o)) if ctx.needs_input_grad[4] else None        # dy^T mid
+        dres = dy if (has_res and ctx.needs_input_grad[6]) else None
+        return dx, dw, db, dd, du, None, dres
+
+
+def lora_linear(x, w, bias, down, up, s=1.0, residual=None):
+    return LoraLinearFn.apply(x, w, bias, down, up, float(s), residual)
 
 
 def _gn_args(x, y, gamma, beta, mean, rstd, G, eps, silu):

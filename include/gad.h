@@ -98,6 +98,16 @@ typedef struct gad_gemm_args {
    * operand_precision = 1 the LDS-patch convolution streams it by LDS-DMA instead of converting the fp32 weights in every
    * workgroup.  Ignored by every other kernel. */
   const void* B_bf16;
+  /* K-concatenated dense operands - the fused LoRA-compatible linear (diffusers LoRACompatibleLinear as injected at
+   * text_to_image/train_text_to_image_lora.py:786-820): for k >= k_split the products read A_k2[m][k - k_split] and
+   * B_k2 (laid out like B: [n][k - k_split] for B_KC, [k - k_split][n] for B_MC), so
+   *   y = x W^T + mid (s B_up)^T            is ONE launch with A = x, A_k2 = mid, B = W, B_k2 = B_up   (forward)
+   *   dx = dy W + dmid A_down               is ONE launch with A = dy, A_k2 = dmid, B = W, B_k2 = A_down (B_MC)
+   * instead of a base GEMM plus a residual-accumulating side GEMM.  A_KC x B_KC|B_MC only; k_split % 32 == 0;
+   * (K - k_split) % 4 == 0 (ragged LoRA ranks that are not multiples of 4 take the two-launch route). */
+  const float* A_k2;
+  const float* B_k2;
+  int32_t lda_k2, ldb_k2, k_split;
   /* kernel-family switches for A/B tests and invariance checks (0 in production): GAD_GEMM_* bits below.  They
    * travel with the call - the library reads no environment variable and keeps no process-global switch. */
   int32_t flags;

@@ -228,6 +228,57 @@ def test_linear_and_lora(ops):
     close(lora.up.weight.grad, Bm.grad, atol=1e-4)
 
 
+@pytest.mark.parametrize("K,N,r,bias,res,rows", [(320, 320, 256, False, True, (4, 256)), (768, 640, 256, False, False, (3, 77)),
+                                                 (1280, 1280, 64, True, True, (2, 64)), (320, 640, 4, True, False, (1, 100)),
+                                                 (640, 320, 131, False, True, (2, 50)), (96, 64, 8, True, True, (2, 33))])
+def test_fused_lora_linear_forward_backward(ops, K, N, r, bias, res, rows):
+    """LoRACompatibleLinear with a LoRALinearLayer (train_text_to_image_lora.py:786-820): the K-concatenated launches
+    (y = [x | s x A^T] [W | B]^T, dx = [dy | s dy B] [W ; A]) against fp64, at the SD shapes (q/out 320x320 r=256;
+    cross-attention k/v 768 -> 640 on 77 tokens; 1280 wide) and a pruned ragged rank (131: not a multiple of 4 -> the
+    two-launch route).  LoRA-only training (base frozen) and base-trainable gradients."""
+    from gad import nn as gnn
+    torch.manual_seed(0)
+    lin = gnn.Linear(K, N, bias=bias).to(dev)
+    lora = gnn.LoRALinearLayer(K, N, rank=r).to(dev)
+    with torch.no_grad():
+        lora.up.weight.copy_(rnd(N, r, seed=9, scale=0.1))
+    lin.set_lora_layer(lora)
+    assert ops.lora_fusable(K, N, r) == (r % 4 == 0)
+    x = rnd(*rows, K, seed=1)
+    residual = rnd(*rows, N, seed=3) if res else None
+    dy = rnd(*rows, N, seed=2)
+    xd = x.double().requires_grad_(True)
+    W = lin.weight.detach().cpu().double().requires_grad_(True)
+    A, Bm = lora.down.weight.detach().cpu().double().requires_grad_(True), lora.up.weight.detach().cpu().double().requires_grad_(True)
+    want = xd @ W.T + 0.7 * ((xd @ A.T) @ Bm.T)
+    if bias:
+        want = want + lin.bias.detach().cpu().double()
+    if res:
+        want = want + residual.double()
+    want.backward(dy.double())
+    for freeze in (False, True):
+        for p_ in lin.parameters(recurse=False):
+            p_.requires_grad_(not freeze)
+            p_.grad = None
+        for p_ in lora.parameters():
+            p_.grad = None
+        gx = x.to(dev).requires_grad_(True)
+        gres = residual.to(dev).requires_grad_(True) if res else None
+        y = lin(gx, residual=gres, scale=0.7)
+        y.backward(dy.to(dev))
+        tol = 2e-5 * math.sqrt(K + r)
+        close(y, want, atol=tol)
+        close(gx.grad, xd.grad, atol=2e-5 * math.sqrt(N + r))
+        close(lora.down.weight.grad, A.grad, atol=1e-4)
+        close(lora.up.weight.grad, Bm.grad, atol=1e-4)
+        if res:
+            close(gres.grad, dy)
+        if freeze:
+            assert lin.weight.grad is None
+        else:
+            close(lin.weight.grad, W.grad, atol=1e-4)
+
+
 # ------------------------------------------------------------------------ elementwise ----
 def test_timestep_embedding(ops):
     from oracle.diffusers_ref import get_timestep_embedding
