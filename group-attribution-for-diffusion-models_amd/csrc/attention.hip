@@ -443,6 +443,386 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   }
 }
 
+// ==================================================================================================================
+// bf16-operand instances (gad_attention_args.operand_precision = 1; the analogue of the reference's fp16 autocast for
+// configs 4 / 5): the same three kernels on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16 (RNE), products exact,
+// fp32 accumulation, fp32 softmax statistics; q, k, v, o, gradients stay fp32 in HBM.
+//   * streamed tiles (K, V forward / dQ; Q, dO for dK/dV) pass through registers once per workgroup: fp32 float4
+//     loads issued before the tile's MFMAs, converted and written to the other LDS buffer after them (T14 split);
+//   * LDS images are row-major bf16: rows of Dk32+8 elements serve the fragments whose lanes run along the tile's
+//     rows (one ds_read_b128 = 8 k), rows of SV elements (SV = 16 mod 32: the 8 rows x 4 segments of a 32-lane half
+//     cover the 64 banks once) serve the fragments whose lanes run along the columns through the transposing
+//     ds_read_b64_tr_b16 - 4 rows x 16 columns per 16-lane group, i.e. exactly the (k slot, column) shape of an
+//     MFMA operand;
+//   * the accumulator-as-operand trick carries over: a 32-deep contraction step takes lane group g's slots
+//     j < 4 from the first 16x16 accumulator (rows 4 g + j) and j >= 4 from the second (rows 16 + 4 g + j - 4): the
+//     eight probabilities a lane holds are packed to bf16 in place and ARE the B operand; the A operand is read with
+//     the same row assignment.
+// ==================================================================================================================
+typedef __bf16 bf16x8_t __attribute__((ext_vector_type(8)));
+typedef __bf16 bf16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x4_t __attribute__((ext_vector_type(4)));
+typedef short s16x8_t __attribute__((ext_vector_type(8)));
+
+template <int D>
+struct CfgH {
+  static_assert(D % 8 == 0, "head dim must be a multiple of 8");
+  static constexpr int DK32 = (D + 31) / 32 * 32;          // contraction over the head dim: 32-deep MFMA steps
+  static constexpr int KS = DK32 / 32;
+  static constexpr int SK = DK32 + 8;                      // row stride (bf16) of the image read along rows
+  static constexpr int DV16 = (D + 15) / 16 * 16;
+  static constexpr int NDV = DV16 / 16;
+  static constexpr int SV = (DV16 % 32 == 16) ? DV16 : DV16 + 16;   // row stride (bf16) of the image read transposed
+  static constexpr int NF4 = KV * D / 4;                   // float4 per streamed tile
+  static constexpr int SLOTS = (NF4 + NT - 1) / NT;        // per thread
+};
+
+__device__ __forceinline__ f32x4 mfma16h(bf16x8_t a, bf16x8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
+
+// issue the fp32 loads of rows row0 .. row0+KV-1 (zeros past T)
+template <int D>
+__device__ __forceinline__ void tile_fetch(f32x4 (&r)[CfgH<D>::SLOTS], const float* base, int ld, int row0, int T) {
+  using C = CfgH<D>;
+#pragma unroll
+  for (int i = 0; i < C::SLOTS; ++i) {
+    const int f = threadIdx.x + NT * i;
+    const int row = f / (D / 4), c4 = (f - row * (D / 4)) * 4;
+    const bool ok = f < C::NF4 && row0 + row < T;
+    r[i] = ok ? *reinterpret_cast<const f32x4*>(base + (long)(row0 + row) * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+}
+// convert and write a fetched tile into a row-major bf16 image with row stride S
+template <int D, int S>
+__device__ __forceinline__ void tile_commit(unsigned short* img, const f32x4 (&r)[CfgH<D>::SLOTS], float mul = 1.f) {
+  using C = CfgH<D>;
+#pragma unroll
+  for (int i = 0; i < C::SLOTS; ++i) {
+    const int f = threadIdx.x + NT * i;
+    if (f < C::NF4) {
+      const int row = f / (D / 4), c4 = (f - row * (D / 4)) * 4;
+      const bf16x4_t h = {(__bf16)(r[i][0] * mul), (__bf16)(r[i][1] * mul), (__bf16)(r[i][2] * mul), (__bf16)(r[i][3] * mul)};
+      *reinterpret_cast<bf16x4_t*>(img + row * S + c4) = h;
+    }
+  }
+}
+// fragment whose lanes run along the image's rows: lane (row r0 + (l & 15), k group g = l >> 4) -> k = 32 s + 8 g + j
+template <int S>
+__device__ __forceinline__ bf16x8_t row_frag_h(const unsigned short* img, int r0, int s) {
+  const int lane = threadIdx.x & 63;
+  return *reinterpret_cast<const bf16x8_t*>(img + (r0 + (lane & 15)) * S + 32 * s + 8 * (lane >> 4));
+}
+// fragment whose lanes run along the image's columns, contraction over 32 rows rb .. rb+31 with the slot assignment
+// (g, j < 4) -> row rb + 4 g + j, (g, j >= 4) -> row rb + 16 + 4 g + j - 4; lane l holds column c0 + (l & 15)
+template <int S>
+__device__ __forceinline__ bf16x8_t col_frag_h(const unsigned short* img, int rb, int c0) {
+  const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const unsigned short* a0 = img + (rb + 4 * g + q) * S + c0 + 4 * pp;
+  const s16x4_t lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)a0);
+  const s16x4_t hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4_t*)(a0 + 16 * S));
+  const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8_t, both);
+}
+// loop-invariant row fragments straight from global memory (fp32 -> bf16, zero past the head dim / the sequence)
+template <int D>
+__device__ __forceinline__ void row_frag_global_h(const float* base, int ld, int row, bool ok, float mul, bf16x8_t (&f)[CfgH<D>::KS]) {
+  using C = CfgH<D>;
+  const int g = (threadIdx.x & 63) >> 4;
+  const float* p = base + (long)(ok ? row : 0) * ld;
+#pragma unroll
+  for (int s = 0; s < C::KS; ++s) {
+    const int k = 32 * s + 8 * g;
+    const bool in = ok && k < D;                      // D % 8 == 0: a group of 8 is all inside or all outside
+    const f32x4 a = in ? *reinterpret_cast<const f32x4*>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b = in ? *reinterpret_cast<const f32x4*>(p + k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    f[s] = bf16x8_t{(__bf16)(a[0] * mul), (__bf16)(a[1] * mul), (__bf16)(a[2] * mul), (__bf16)(a[3] * mul),
+                    (__bf16)(b[0] * mul), (__bf16)(b[1] * mul), (__bf16)(b[2] * mul), (__bf16)(b[3] * mul)};
+  }
+}
+__device__ __forceinline__ bf16x8_t pack8(const f32x4& a, const f32x4& b) {
+  return bf16x8_t{(__bf16)a[0], (__bf16)a[1], (__bf16)a[2], (__bf16)a[3], (__bf16)b[0], (__bf16)b[1], (__bf16)b[2], (__bf16)b[3]};
+}
+__device__ __forceinline__ void zero_lds(unsigned short* lds, int n_elems) {
+  for (int i = threadIdx.x * 8; i < n_elems; i += NT * 8) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+}
+
+template <int D, int NQ>
+__global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
+  using C = CfgH<D>;
+  constexpr int KIMG = KV * C::SK, VIMG = KV * C::SV, BUF = (KIMG + VIMG + 7) / 8 * 8;
+  extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * D;
+  const float* K = p.k + b * p.sk + h * D;
+  const float* V = p.v + b * p.sv + h * D;
+  const int qw = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+
+  bf16x8_t qf[NQ][C::KS];
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) row_frag_global_h<D>(Q, p.ldq, qw + 16 * t + c, qw + 16 * t + c < p.Tq, p.scale * LOG2E, qf[t]);
+  f32x4 o[C::NDV][NQ];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i)
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) o[i][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m[NQ], l[NQ];
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) { m[t] = NEG_BIG; l[t] = 0.f; }
+
+  zero_lds(ldsh, 2 * BUF);          // pad columns (k >= D of the K image, dv >= D of the V image) stay zero for good
+  __syncthreads();
+  f32x4 rk[C::SLOTS], rv[C::SLOTS];
+  tile_fetch<D>(rk, K, p.ldk, 0, p.Tk);
+  tile_fetch<D>(rv, V, p.ldv, 0, p.Tk);
+  tile_commit<D, C::SK>(ldsh, rk);
+  tile_commit<D, C::SV>(ldsh + KIMG, rv);
+  __syncthreads();
+
+  const int ntiles = (p.Tk + KV - 1) / KV;
+  for (int it = 0; it < ntiles; ++it) {
+    const unsigned short* kimg = ldsh + (it & 1) * BUF;
+    const unsigned short* vimg = kimg + KIMG;
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      tile_fetch<D>(rk, K, p.ldk, (it + 1) * KV, p.Tk);
+      tile_fetch<D>(rv, V, p.ldv, (it + 1) * KV, p.Tk);
+    }
+    f32x4 s[2][NQ];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) s[kt][t] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < C::KS; ++st) {
+        const bf16x8_t kf = row_frag_h<C::SK>(kimg, 16 * kt, st);
+#pragma unroll
+        for (int t = 0; t < NQ; ++t) s[kt][t] = mfma16h(kf, qf[t][st], s[kt][t]);
+      }
+    }
+    if ((it + 1) * KV > p.Tk) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (it * KV + 16 * kt + 4 * g + e >= p.Tk)
+#pragma unroll
+            for (int t = 0; t < NQ; ++t) s[kt][t][e] = -__builtin_inff();
+    }
+    bf16x8_t pb[NQ];
+#pragma unroll
+    for (int t = 0; t < NQ; ++t) {
+      float mx = fmaxf(fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3])),
+                       fmaxf(fmaxf(s[1][t][0], s[1][t][1]), fmaxf(s[1][t][2], s[1][t][3])));
+      mx = xmax16_32(mx);
+      const float mn = fmaxf(m[t], mx);
+      const float alpha = ex2(m[t] - mn);
+      m[t] = mn;
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = ex2(s[kt][t][e] - mn);
+          s[kt][t][e] = pe;
+          ps += pe;
+        }
+      l[t] = l[t] * alpha + ps;
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) o[i][t] *= alpha;
+      pb[t] = pack8(s[0][t], s[1][t]);          // slots j < 4: keys 4 g + j, j >= 4: keys 16 + 4 g + j - 4
+    }
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const bf16x8_t vf = col_frag_h<C::SV>(vimg, 0, 16 * i);
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) o[i][t] = mfma16h(vf, pb[t], o[i][t]);
+    }
+    if (more) {
+      unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
+      tile_commit<D, C::SK>(nb, rk);
+      tile_commit<D, C::SV>(nb + KIMG, rv);
+    }
+    __syncthreads();
+  }
+
+  float* O = p.o + b * p.so + h * D;
+#pragma unroll
+  for (int t = 0; t < NQ; ++t) {
+    const float lt = xsum16_32(l[t]);
+    const float inv = 1.f / lt;
+    const int row = qw + 16 * t + c;
+    if (row < p.Tq) {
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        const int dv = 16 * i + 4 * g;
+        if (dv < D) *reinterpret_cast<f32x4*>(O + (long)row * p.ldo + dv) = o[i][t] * inv;
+      }
+      if (g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m[t] + __builtin_amdgcn_logf(lt);
+    }
+  }
+}
+
+// dQ, bf16 operands: workgroup = 64 queries, wave = 16; K and V tiles in ONE image type (row stride SV) read both along
+// rows (S^T = K Q^T, dP^T = V dO^T) and transposed (dQ^T += K^T dS^T).  Row reads past the head dim meet zero B
+// operands (the loop-invariant fragments are zero there), so whatever finite bf16 they pick up contributes nothing.
+template <int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
+  using C = CfgH<D>;
+  constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
+  extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image] + tail pad
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* K = p.k + b * p.sk + h * D;
+  const float* V = p.v + b * p.sv + h * D;
+  const int row = blockIdx.x * 64 + wave * 16 + c;
+  const bool rok = row < p.Tq;
+  bf16x8_t qf[C::KS], dof[C::KS];
+  row_frag_global_h<D>(p.q + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
+  row_frag_global_h<D>(p.d_o + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
+  const float L2 = rok ? p.lse[(long)bh * p.Tq + row] : 0.f;
+  const float dl = rok ? p.delta[(long)bh * p.Tq + row] : 0.f;
+  f32x4 dq[C::NDV];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+
+  zero_lds(ldsh, 2 * BUF + 64);
+  __syncthreads();
+  f32x4 rk[C::SLOTS], rv[C::SLOTS];
+  tile_fetch<D>(rk, K, p.ldk, 0, p.Tk);
+  tile_fetch<D>(rv, V, p.ldv, 0, p.Tk);
+  tile_commit<D, C::SV>(ldsh, rk);
+  tile_commit<D, C::SV>(ldsh + IMG, rv);
+  __syncthreads();
+  const int ntiles = (p.Tk + KV - 1) / KV;
+  for (int it = 0; it < ntiles; ++it) {
+    const unsigned short* kimg = ldsh + (it & 1) * BUF;
+    const unsigned short* vimg = kimg + IMG;
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      tile_fetch<D>(rk, K, p.ldk, (it + 1) * KV, p.Tk);
+      tile_fetch<D>(rv, V, p.ldv, (it + 1) * KV, p.Tk);
+    }
+    f32x4 ds[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < C::KS; ++st) {
+        s = mfma16h(row_frag_h<C::SV>(kimg, 16 * kt, st), qf[st], s);
+        dp = mfma16h(row_frag_h<C::SV>(vimg, 16 * kt, st), dof[st], dp);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
+        const float pe = kok ? ex2(s[e] - L2) : 0.f;
+        ds[kt][e] = pe * (dp[e] - dl);
+      }
+    }
+    const bf16x8_t dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) dq[i] = mfma16h(col_frag_h<C::SV>(kimg, 0, 16 * i), dsb, dq[i]);
+    if (more) {
+      unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
+      tile_commit<D, C::SV>(nb, rk);
+      tile_commit<D, C::SV>(nb + IMG, rv);
+    }
+    __syncthreads();
+  }
+  if (rok) {
+    float* DQ = p.dq + b * p.sdq + h * D + (long)row * p.lddq;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const int kk = 16 * i + 4 * g;
+      if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[i] * p.scale;
+    }
+  }
+}
+
+// dK / dV, bf16 operands: workgroup = 64 keys, wave = 16; Q and dO tiles in one image type, read along rows for
+// S = Q K^T and dP = dO V^T and transposed for dV^T += dO^T P and dK^T += Q^T dS.
+template <int D>
+__global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) {
+  using C = CfgH<D>;
+  constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
+  extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * D;
+  const float* DO = p.d_o + b * p.sdo + h * D;
+  const int key = blockIdx.x * 64 + wave * 16 + c;
+  const bool kok = key < p.Tk;
+  bf16x8_t kf[C::KS], vf[C::KS];
+  row_frag_global_h<D>(p.k + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
+  row_frag_global_h<D>(p.v + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
+  f32x4 dk[C::NDV], dv[C::NDV];
+#pragma unroll
+  for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  const float* lse = p.lse + (long)bh * p.Tq;
+  const float* dlt = p.delta + (long)bh * p.Tq;
+
+  zero_lds(ldsh, 2 * BUF + 64);
+  __syncthreads();
+  f32x4 rq[C::SLOTS], rg[C::SLOTS];
+  tile_fetch<D>(rq, Q, p.ldq, 0, p.Tq);
+  tile_fetch<D>(rg, DO, p.lddo, 0, p.Tq);
+  tile_commit<D, C::SV>(ldsh, rq);
+  tile_commit<D, C::SV>(ldsh + IMG, rg);
+  __syncthreads();
+  const int ntiles = (p.Tq + KV - 1) / KV;
+  for (int it = 0; it < ntiles; ++it) {
+    const unsigned short* qimg = ldsh + (it & 1) * BUF;
+    const unsigned short* gimg = qimg + IMG;
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      tile_fetch<D>(rq, Q, p.ldq, (it + 1) * KV, p.Tq);
+      tile_fetch<D>(rg, DO, p.lddo, (it + 1) * KV, p.Tq);
+    }
+    f32x4 pr[2], ds[2];
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < C::KS; ++st) {
+        s = mfma16h(row_frag_h<C::SV>(qimg, 16 * t, st), kf[st], s);
+        dp = mfma16h(row_frag_h<C::SV>(gimg, 16 * t, st), vf[st], dp);
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qrow = it * KV + 16 * t + 4 * g + e;
+        const bool qok = qrow < p.Tq;
+        const float L2 = qok ? lse[qrow] : 0.f, dl = qok ? dlt[qrow] : 0.f;
+        const float pe = qok ? ex2(s[e] - L2) : 0.f;
+        pr[t][e] = pe;
+        ds[t][e] = pe * (dp[e] - dl);
+      }
+    }
+    const bf16x8_t pb = pack8(pr[0], pr[1]), dsb = pack8(ds[0], ds[1]);
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      dv[i] = mfma16h(col_frag_h<C::SV>(gimg, 0, 16 * i), pb, dv[i]);
+      dk[i] = mfma16h(col_frag_h<C::SV>(qimg, 0, 16 * i), dsb, dk[i]);
+    }
+    if (more) {
+      unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
+      tile_commit<D, C::SV>(nb, rq);
+      tile_commit<D, C::SV>(nb + IMG, rg);
+    }
+    __syncthreads();
+  }
+  if (kok) {
+    float* DK = p.dk + b * p.sdk + h * D + (long)key * p.lddk;
+    float* DV = p.dv + b * p.sdv + h * D + (long)key * p.lddv;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const int kk = 16 * i + 4 * g;
+      if (kk < D) {
+        *reinterpret_cast<f32x4*>(DK + kk) = dk[i] * p.scale;
+        *reinterpret_cast<f32x4*>(DV + kk) = dv[i];
+      }
+    }
+  }
+}
+
 template <typename F>
 static int set_lds(F kernel, int bytes, const char* what) {
   if (bytes > 64 * 1024) {
@@ -501,6 +881,16 @@ static int launch_fwd(const AttnDev& d, hipStream_t st) {
   return 0;
 }
 
+template <int D, int NQ>
+static int launch_fwd_h(const AttnDev& d, hipStream_t st) {
+  using C = CfgH<D>;
+  const int bytes = 2 * ((KV * C::SK + KV * C::SV + 7) / 8 * 8) * (int)sizeof(unsigned short);
+  if (set_lds(attn_fwd_bf16_kernel<D, NQ>, bytes, "gad_attention_fwd")) return 1;
+  dim3 grid((unsigned)gad_ceil_div(d.Tq, 64 * NQ), (unsigned)(d.B * d.heads));
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, NQ>), grid, dim3(NT), bytes, st, d);
+  return 0;
+}
+
 template <int D>
 static int launch_bwd(const AttnDev& d, float* delta, hipStream_t st) {
   const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
@@ -509,6 +899,18 @@ static int launch_bwd(const AttnDev& d, float* delta, hipStream_t st) {
   hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
   hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tq, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
   hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  return 0;
+}
+
+template <int D>
+static int launch_bwd_h(const AttnDev& d, float* delta, hipStream_t st) {
+  using C = CfgH<D>;
+  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short);
+  if (set_lds(attn_bwd_dq_bf16_kernel<D>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_bf16_kernel<D>, bytes, "gad_attention_bwd")) return 1;
+  const long total = (long)d.B * d.Tq * d.heads;
+  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tq, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
   return 0;
 }
 
@@ -521,6 +923,24 @@ extern "C" int gad_attention_fwd(const gad_attention_args* a, void* stream) {
   int rc = 0;
   // queries per workgroup: 128 while the (b, h, block) grid still fills the chip twice over, else 64
   const bool wide = gad_ceil_div(a->Tq, 128) * a->B * a->heads >= 512;
+  if (a->operand_precision == 1) {
+    switch (a->d) {
+      case 16: rc = wide ? launch_fwd_h<16, 2>(d, st) : launch_fwd_h<16, 1>(d, st); break;
+      case 32: rc = wide ? launch_fwd_h<32, 2>(d, st) : launch_fwd_h<32, 1>(d, st); break;
+      case 40: rc = wide ? launch_fwd_h<40, 2>(d, st) : launch_fwd_h<40, 1>(d, st); break;
+      case 64: rc = wide ? launch_fwd_h<64, 2>(d, st) : launch_fwd_h<64, 1>(d, st); break;
+      case 80: rc = wide ? launch_fwd_h<80, 2>(d, st) : launch_fwd_h<80, 1>(d, st); break;
+      case 96: rc = wide ? launch_fwd_h<96, 2>(d, st) : launch_fwd_h<96, 1>(d, st); break;
+      case 128: rc = launch_fwd_h<128, 1>(d, st); break;
+      case 160: rc = launch_fwd_h<160, 1>(d, st); break;
+      case 192: rc = launch_fwd_h<192, 1>(d, st); break;
+      case 224: rc = launch_fwd_h<224, 1>(d, st); break;
+      default: rc = launch_fwd_h<256, 1>(d, st); break;
+    }
+    if (rc) return rc;
+    GAD_LAUNCH_CHECK("gad_attention_fwd(bf16)");
+    return 0;
+  }
   switch (a->d) {
     case 16: rc = wide ? launch_fwd<16, 2>(d, st) : launch_fwd<16, 1>(d, st); break;
     case 32: rc = wide ? launch_fwd<32, 2>(d, st) : launch_fwd<32, 1>(d, st); break;
@@ -550,6 +970,24 @@ extern "C" int gad_attention_bwd(const gad_attention_args* a, void* stream) {
   AttnDev d = make_dev(a);
   hipStream_t st = (hipStream_t)stream;
   int rc = 0;
+  if (a->operand_precision == 1) {
+    switch (a->d) {
+      case 16: rc = launch_bwd_h<16>(d, a->delta, st); break;
+      case 32: rc = launch_bwd_h<32>(d, a->delta, st); break;
+      case 40: rc = launch_bwd_h<40>(d, a->delta, st); break;
+      case 64: rc = launch_bwd_h<64>(d, a->delta, st); break;
+      case 80: rc = launch_bwd_h<80>(d, a->delta, st); break;
+      case 96: rc = launch_bwd_h<96>(d, a->delta, st); break;
+      case 128: rc = launch_bwd_h<128>(d, a->delta, st); break;
+      case 160: rc = launch_bwd_h<160>(d, a->delta, st); break;
+      case 192: rc = launch_bwd_h<192>(d, a->delta, st); break;
+      case 224: rc = launch_bwd_h<224>(d, a->delta, st); break;
+      default: rc = launch_bwd_h<256>(d, a->delta, st); break;
+    }
+    if (rc) return rc;
+    GAD_LAUNCH_CHECK("gad_attention_bwd(bf16)");
+    return 0;
+  }
   switch (a->d) {
     case 16: rc = launch_bwd<16>(d, a->delta, st); break;
     case 32: rc = launch_bwd<32>(d, a->delta, st); break;

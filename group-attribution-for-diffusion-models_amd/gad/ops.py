@@ -738,6 +738,7 @@ def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=Tru
     o = torch.empty((Bn, Tq, heads * d), device=q.device, dtype=torch.float32)
     lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
     a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv)
+    a.operand_precision = OPERAND_PRECISION[0]         # bf16 mode: bf16-operand instance of the fused kernel
     if PROFILER is not None:
         PROFILER.attention(_capi.load().gad_attention_fwd, a, "fwd")
     else:
@@ -760,7 +761,7 @@ class AttentionCoreFn(torch.autograd.Function):
         d = Cq // heads
         o, lse = attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, need_lse=True)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads = heads
+        ctx.heads, ctx.prec = heads, OPERAND_PRECISION[0]
         return o
 
     @staticmethod
@@ -778,6 +779,7 @@ class AttentionCoreFn(torch.autograd.Function):
         a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq
         a.stride_do = a.stride_dq = Tq * Cq
         a.stride_dk = a.stride_dv = Tk * Cq
+        a.operand_precision = ctx.prec                   # the precision the forward's LSE was computed in
         if PROFILER is not None:
             PROFILER.attention(_capi.load().gad_attention_bwd, a, "bwd")
         else:

@@ -189,7 +189,8 @@ typedef struct gad_attention_args {
   int32_t ldq, ldk, ldv, ldo, ld_do, ld_dq, ld_dk, ld_dv;           /* row strides (floats)  */
   int64_t stride_q, stride_k, stride_v, stride_o, stride_do, stride_dq, stride_dk, stride_dv;   /* batch strides */
   float scale;              /* 1/sqrt(d)                                                      */
-  int32_t operand_precision;/* 0: exact fp32 products (v_mfma_f32_16x16x4_f32); 1: reserved for bf16 operands */
+  int32_t operand_precision;/* 0: exact fp32 products (v_mfma_f32_16x16x4_f32); 1: operands rounded to bf16 (RNE), fp32
+                             * accumulation and softmax statistics (v_mfma_f32_16x16x32_bf16) - the autocast analogue */
 } gad_attention_args;
 int gad_attention_supported(int32_t d);      /* 1 if head dim d has a fused instance */
 int gad_attention_fwd(const gad_attention_args* a, void* stream);

@@ -123,3 +123,36 @@ def test_attention_argument_contract():
     a = ops._attention_args(q, q, q, q, None, 1, 1, 8, 8, 24, 24, 24, 24, 192, 192, 192)
     with pytest.raises(_capi.GadError, match="no instance"):
         _capi.check(_capi.load().gad_attention_fwd(_capi.C.byref(a), ops._stream()), "gad_attention_fwd")
+
+
+@pytest.mark.parametrize("B,Tq,Tk,heads,d", [(2, 256, 256, 1, 256), (2, 64, 64, 7, 32), (2, 256, 256, 8, 40), (2, 64, 77, 4, 40),
+                                           (1, 100, 77, 2, 80), (2, 64, 64, 2, 160), (1, 33, 95, 3, 16), (1, 130, 50, 2, 64),
+                                           (1, 64, 64, 1, 96), (1, 48, 48, 1, 128), (1, 256, 256, 1, 192), (1, 40, 40, 1, 224)])
+def test_fused_attention_bf16_operands(B, Tq, Tk, heads, d):
+    """operand_precision = 1: q (pre-scaled), k, v and the probabilities are rounded to bf16 (RNE), products exact,
+    fp32 accumulation and statistics.  Against fp64 attention of the bf16-rounded q, k, v the remaining differences are
+    the bf16 rounding of q * scale * log2(e) and of P (2^-9 relative each): 1.5e-2 on O(1) values; and the result stays
+    within bf16 distance of the fp32 kernel."""
+    from gad import ops
+    C = heads * d
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.7), rnd(B, Tk, C, seed=2, scale=0.7), rnd(B, Tk, C, seed=3)
+    r = lambda t: t.to(torch.bfloat16).double()
+    want = sdpa64(r(q), r(k), r(v), heads)
+    with torch.no_grad():
+        exact = ops.attention_core_fused(q.to(dev), k.to(dev), v.to(dev), heads)
+        with ops.operand_precision("bf16"):
+            got = ops.attention_core_fused(q.to(dev), k.to(dev), v.to(dev), heads)
+    assert (got.cpu().double() - want).abs().max().item() < 1.5e-2
+    d_ = (got - exact).abs().max().item()
+    assert 0 < d_ < 3e-2
+    # backward: gradients of the bf16-operand kernels against fp64 autograd through the bf16-rounded inputs; dS and P are
+    # rounded to bf16 before the last contraction: 2 % of each gradient's scale
+    qd, kd, vd = (r(t).requires_grad_(True) for t in (q, k, v))
+    do = rnd(B, Tq, C, seed=4)
+    sdpa64(qd, kd, vd, heads).backward(r(do))
+    gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    with ops.operand_precision("bf16"):
+        out = ops.attention_core_fused(gq, gk, gv, heads)
+        out.backward(do.to(dev))
+    for got_g, want_g in ((gq.grad, qd.grad), (gk.grad, kd.grad), (gv.grad, vd.grad)):
+        assert (got_g.cpu().double() - want_g).abs().max().item() < 2e-2 * max(1.0, want_g.abs().max().item())

@@ -8,6 +8,9 @@ import torch
 from gad import ops
 dev = torch.device("cuda:0")
 ROUNDS = int(sys.argv[1]) if len(sys.argv) > 1 else 5
+PREC = sys.argv[2] if len(sys.argv) > 2 else "f32"
+ops.set_operand_precision(PREC)
+print("operand precision", PREC, flush=True)
 SHAPES = [  # name, B, Tq, Tk, heads, d
     ("sd512 self 64x64", 16, 4096, 4096, 8, 40), ("sd512 cross 64x64", 16, 4096, 77, 8, 40),
     ("sd512 self 32x32", 16, 1024, 1024, 8, 80), ("sd512 self 16x16", 16, 256, 256, 8, 160),
