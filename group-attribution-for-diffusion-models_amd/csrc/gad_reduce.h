@@ -15,9 +15,18 @@ __global__ __launch_bounds__(NT) void colsum_part_vec(const float* __restrict__ 
                                                       int rows_per, int nparts) {
   __shared__ float red[NT * 4];
   const int seg = blockIdx.y, C4 = N >> 2;
-  const int lanes = NT / C4 > 0 ? NT / C4 : 1;           // row lanes (C4 <= 256 guaranteed by the host)
-  const int tid = threadIdx.x, lane = tid / C4, cq = tid - lane * C4;
   long r0 = (long)blockIdx.x * rows_per, r1 = r0 + rows_per < M ? r0 + rows_per : M;
+  if (C4 > NT) {                                          // wide rows (LayerNorm / GEGLU widths of the SD blocks): one
+    const f32x4* b = reinterpret_cast<const f32x4*>(x + (long)seg * M * N);   // row lane, threads stride the column quads
+    for (int cq = threadIdx.x; cq < C4; cq += NT) {
+      f32x4 s = {0.f, 0.f, 0.f, 0.f};
+      for (long r = r0; r < r1; ++r) s += b[r * C4 + cq];
+      *reinterpret_cast<f32x4*>(part + ((long)seg * nparts + blockIdx.x) * N + cq * 4) = s;
+    }
+    return;
+  }
+  const int lanes = NT / C4 > 0 ? NT / C4 : 1;           // row lanes
+  const int tid = threadIdx.x, lane = tid / C4, cq = tid - lane * C4;
   f32x4 s = {0.f, 0.f, 0.f, 0.f};
   if (lane < lanes) {
     const f32x4* b = reinterpret_cast<const f32x4*>(x + (long)seg * M * N) + cq;
@@ -91,7 +100,7 @@ static inline Plan plan(int S, long M, int N) {
   if (rp < 32) rp = 32;
   p.rows_per = (int)rp;
   p.nparts = (int)gad_ceil_div(M, rp);
-  p.vec = (N % 4 == 0) && (N / 4 <= NT);
+  p.vec = (N % 4 == 0);
   return p;
 }
 static inline int64_t ws_bytes(int S, long M, int N) { return (int64_t)S * plan(S, M, N).nparts * N * 4; }

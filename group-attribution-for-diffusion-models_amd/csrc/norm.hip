@@ -467,7 +467,7 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
 
 extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream) {
   if (check(a, "gad_groupnorm_silu_bwd")) return 1;
-  GAD_CHECK(a->dy && a->dgamma && a->dbeta && gad_aligned16(a->dy), "gad_groupnorm_silu_bwd: null/unaligned grad pointer");
+  GAD_CHECK(a->dy && gad_aligned16(a->dy) && ((a->dgamma == nullptr) == (a->dbeta == nullptr)), "gad_groupnorm_silu_bwd: null/unaligned grad pointer");
   Geo g = make_geo(a);
   hipStream_t st = (hipStream_t)stream;
   dim3 grid(a->B * g.nch), block(NT);
@@ -475,9 +475,12 @@ extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream)
   GAD_LAUNCH_CHECK("gn_bwd_stats");
   hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a->x, a->dy, a->y, a->gamma, a->beta, a->mean, a->rstd, (const float*)a->ws, g, a->silu);
   GAD_LAUNCH_CHECK("gn_bwd_apply");
-  // dbeta[c] = sum parts[.][c][0], dgamma[c] = sum parts[.][c][1]: a column sum of the [B*nch][2C] partials
-  float* ws2 = (float*)a->ws + (long)a->B * g.nch * a->C * 2;
-  gad_reduce::launch((const float*)a->ws, a->dbeta, a->dgamma, 1, (long)a->B * g.nch, 2 * a->C, ws2, st);
-  GAD_LAUNCH_CHECK("gn_bwd_param");
+  // dbeta[c] = sum parts[.][c][0], dgamma[c] = sum parts[.][c][1]: a column sum of the [B*nch][2C] partials -
+  // skipped when the caller wants no affine gradients (dgamma == dbeta == NULL: frozen norms of LoRA training)
+  if (a->dgamma) {
+    float* ws2 = (float*)a->ws + (long)a->B * g.nch * a->C * 2;
+    gad_reduce::launch((const float*)a->ws, a->dbeta, a->dgamma, 1, (long)a->B * g.nch, 2 * a->C, ws2, st);
+    GAD_LAUNCH_CHECK("gn_bwd_param");
+  }
   return 0;
 }

@@ -174,7 +174,7 @@ extern "C" int gad_layernorm_fwd(const float* x, float* y, const float* gamma, c
 extern "C" int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* mean,
                                  const float* rstd, float* dgamma_dbeta, int64_t rows, int32_t C, void* ws, int64_t ws_bytes,
                                  void* stream) {
-  GAD_CHECK(x && dy && dx && gamma && mean && rstd && dgamma_dbeta && rows > 0, "gad_layernorm_bwd: bad args");
+  GAD_CHECK(x && dy && dx && gamma && mean && rstd && rows > 0, "gad_layernorm_bwd: bad args");
   GAD_CHECK(C % 4 == 0 && C <= 2048 && gad_aligned16(x) && gad_aligned16(dy) && gad_aligned16(dx) && gad_aligned16(gamma),
             "gad_layernorm_bwd: needs C%%4==0, C<=2048, 16-B alignment (C=%d)", C);
   GAD_CHECK(ws && ws_bytes >= gad_layernorm_workspace_bytes(rows, C), "gad_layernorm_bwd: workspace too small");
@@ -182,8 +182,10 @@ extern "C" int gad_layernorm_bwd(const float* x, const float* dy, float* dx, con
   float* part = (float*)ws;
   hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, x, dy, dx, gamma, mean, rstd, part, (long)rows, C);
   GAD_LAUNCH_CHECK("gad_layernorm_bwd");
-  gad_reduce::launch(part, dgamma_dbeta, nullptr, 1, nb, 2 * C, part + (long)nb * 2 * C, (hipStream_t)stream);   // [2C] = dgamma | dbeta
-  GAD_LAUNCH_CHECK("gad_layernorm_bwd(reduce)");
+  if (dgamma_dbeta) {      // NULL: frozen affine parameters (LoRA training) - no reduction of the partials
+    gad_reduce::launch(part, dgamma_dbeta, nullptr, 1, nb, 2 * C, part + (long)nb * 2 * C, (hipStream_t)stream);   // [2C] = dgamma | dbeta
+    GAD_LAUNCH_CHECK("gad_layernorm_bwd(reduce)");
+  }
   return 0;
 }
 

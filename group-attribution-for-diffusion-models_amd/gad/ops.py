@@ -570,12 +570,16 @@ class GroupNormSiluFn(torch.autograd.Function):
         G, eps, silu = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
+        a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
+        a.dy = dy.data_ptr()
+        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):      # frozen norm (LoRA training): dx only
+            check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
+            return dx, None, None, None, None, None
         (sg, fg), (sb, fb) = _sink(gamma), _sink(beta)
         direct_g, direct_b = sg is not None and fg, sb is not None and fb
         dgamma = sg if direct_g else torch.empty_like(gamma)
         dbeta = sb if direct_b else torch.empty_like(beta)
-        a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
-        a.dy, a.dgamma, a.dbeta = dy.data_ptr(), dgamma.data_ptr(), dbeta.data_ptr()
+        a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
         check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
         if sg is not None:
             if not fg:
@@ -970,11 +974,14 @@ class LayerNormFn(torch.autograd.Function):
         C_ = x.shape[-1]
         rows = x.numel() // C_
         dx = torch.empty_like(x)
-        dgb = torch.empty(2 * C_, device=x.device, dtype=torch.float32)
+        want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]            # frozen LayerNorm (LoRA training): dx only
+        dgb = torch.empty(2 * C_, device=x.device, dtype=torch.float32) if want else None
         ws = workspace(x.device)
         check(_capi.load().gad_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                             rstd.data_ptr(), dgb.data_ptr(), rows, C_, ws.data_ptr(), ws.numel(),
+                                             rstd.data_ptr(), _ptr(dgb), rows, C_, ws.data_ptr(), ws.numel(),
                                              _stream()), "gad_layernorm_bwd")
+        if not want:
+            return dx, None, None, None
         return dx, _deliver(gamma, dgb[:C_]), _deliver(ctx.beta_ref, dgb[C_:]), None
 
 

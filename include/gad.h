@@ -143,7 +143,7 @@ typedef struct gad_groupnorm_args {
   float* mean;              /* [B][G]  (fwd: out, bwd: in)                                   */
   float* rstd;              /* [B][G]                                                        */
   const float* dy;          /* bwd only: [B][HW][C]                                          */
-  float* dgamma;            /* bwd only: [C] (overwritten)                                   */
+  float* dgamma;            /* bwd only: [C] (overwritten); NULL together with dbeta: no affine gradients */
   float* dbeta;             /* bwd only: [C] (overwritten)                                   */
   int32_t B, HW, C, G;
   float eps;
@@ -210,7 +210,7 @@ int gad_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, in
 /* ------------------------------------------------------------------------------
  * Transformer-block pieces of UNet2DConditionModel (Stable Diffusion; BasicTransformerBlock in diffusers,
  * reached from text_to_image/train_text_to_image_lora.py:1268-1270): LayerNorm over the last dim and GEGLU
- * (out = h[:, :F] * gelu(h[:, F:]), exact erf GELU).  dgamma_dbeta is [2C]: dgamma then dbeta.
+ * (out = h[:, :F] * gelu(h[:, F:]), exact erf GELU).  dgamma_dbeta is [2C]: dgamma then dbeta (NULL: not wanted).
  * ---------------------------------------------------------------------------- */
 int64_t gad_layernorm_workspace_bytes(int64_t rows, int32_t C);
 int gad_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,

@@ -279,6 +279,29 @@ def test_fused_lora_linear_forward_backward(ops, K, N, r, bias, res, rows):
             close(lin.weight.grad, W.grad, atol=1e-4)
 
 
+def test_norm_backward_with_frozen_affine_parameters_and_wide_column_sums(ops):
+    """LoRA training freezes every norm: GroupNorm / LayerNorm backward then return dx only and skip the reduction of
+    the dgamma / dbeta partials (NULL pointers through the ABI); dx is bit-identical to the trainable case.  Column sums
+    wider than 1024 (LayerNorm 2C = 2560, GEGLU 5120 / 10240) take the float4 path."""
+    x = rnd(3, 8, 8, 320, seed=1).to(dev)
+    dy = rnd(3, 8, 8, 320, seed=2).to(dev)
+    outs = []
+    for frozen in (False, True):
+        ga = (rnd(320, seed=3) * 0.3 + 1).to(dev).requires_grad_(not frozen)
+        be = (rnd(320, seed=4) * 0.2).to(dev).requires_grad_(not frozen)
+        gx = x.clone().requires_grad_(True)
+        ops.group_norm(gx, ga, be, 32, 1e-5, True).backward(dy)
+        lx = x.view(-1, 320).clone().requires_grad_(True)
+        ops.layer_norm(lx, ga, be, 1e-5).backward(dy.view(-1, 320))
+        outs.append((gx.grad.clone(), lx.grad.clone(), ga.grad))
+    assert torch.equal(outs[0][0], outs[1][0]) and torch.equal(outs[0][1], outs[1][1])
+    assert outs[0][2] is not None and outs[1][2] is None
+    for N in (2560, 5120, 1284, 1028):
+        m = rnd(700, N, seed=N).to(dev)
+        close(ops.colsum_raw(m, 1).view(-1), m.double().sum(0), atol=2e-4)
+        close(ops.colsum_raw(m, 7), m.double().view(7, 100, N).sum(1), atol=1e-4)
+
+
 # ------------------------------------------------------------------------ elementwise ----
 def test_timestep_embedding(ops):
     from oracle.diffusers_ref import get_timestep_embedding
