@@ -1,5 +1,5 @@
 """Dense GEMM tile sweep at the SD-1.x LoRA step's shapes (B=64 @ 32x32 latents): auto plan vs forced 128 / 64 tiles for
-the forward (nt), data-gradient (nn) and weight-gradient (tn) forms.  usage: python tools/sweep_gemm.py"""
+the forward (nt), data-gradient (nn) and weight-gradient (tn) forms.  usage: python tools/sweep_gemm.py [f32|bf16]"""
 import os, sys
 ROOT = os.path.dirname(os.path.dirname(os.path.abspath(__file__)))
 sys.path.insert(0, os.path.join(ROOT, "group-attribution-for-diffusion-models_amd")); sys.path.insert(0, ROOT)
@@ -8,6 +8,8 @@ import torch
 from gad import ops, _capi
 from gad._capi import A_KC, A_MC, B_KC, B_MC
 dev = torch.device("cuda:0")
+import gad
+gad.set_operand_precision("bf16" if "bf16" in sys.argv[1:] else "no")
 
 
 def timeit(fn, iters=10, warm=2):
