@@ -90,6 +90,7 @@ struct DevArgs {
   int ldr;
   float* ws;
   int tiles_m, tiles_n, splitk, ktiles_per_split;
+  int epi_vec;       // the output (and bias / rowadd / residual / workspace) can be written / read as aligned float4
 };
 
 __device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
@@ -598,13 +599,61 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 }
 
 // ------------------------------------------------------------------------------------
-// Epilogue shared by every contraction kernel: the 2x2-wave block's accumulators (C/D map: col = lane & 31,
+// Epilogue shared by every contraction kernel: the wave block's accumulators (C/D map: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) go to C with alpha, bias[n], rowadd[m / rows_per_group][n] and
 // residual[m][n] fused - or, for a split of a split-K launch (direct = false), raw to the workspace slab.
+//
+// The C/D map gives a lane ONE column and 16 rows, so stores straight from the accumulators are 64 dword wave-stores per
+// 32 x 128 block, and the epilogue's time is the count of those instructions (measured on the 36-step 3x3 tiles:
+// 124.7 TF/s as is, 134.8 without the epilogue, 133.4 with the same bytes as dwordx4 stores;
+// profiles/r02_resident_workgroups_experiment.txt).  So each 32 x 32 block is transposed through a wave-private
+// LDS scratch (the operand tiles are dead after the last K step's barrier): 16 ds_write_b32 at a 40-float row stride
+// (rows r and r + 4 of the two lane halves land on disjoint bank halves), 4 ds_read_b128 giving a lane 4 consecutive
+// columns of one row, and 4 dwordx4 stores of 8 rows x 128 B each; bias / rowadd / residual are read as float4 too.
+// Per element the arithmetic and its order are unchanged (bit-identical to the scalar form, which remains for outputs
+// that cannot take aligned float4: N % 4 != 0, odd leading dimensions).
 // ------------------------------------------------------------------------------------
+constexpr int EPI_LD = 40;                       // scratch row stride in floats
+constexpr int EPI_WAVE = 32 * EPI_LD;            // floats of scratch per wave (5 KB; 20 KB per workgroup)
+
 template <int TM, int TN, int BM, int BN, int WM = 2, int WN = 2>
 __device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc)[TM][TN], int row0, int col0, int wm, int wn,
-                                            int h, int l31, float* C, int ldc, const float* R, bool direct) {
+                                            int h, int l31, float* C, int ldc, const float* R, bool direct,
+                                            float* scratch = nullptr) {
+  if (scratch != nullptr && p.epi_vec) {
+    const int lane = l31 + 32 * h;
+    const int rr = lane >> 3, c4 = (lane & 7) * 4;
+#pragma unroll
+    for (int j = 0; j < TN; ++j) {
+      const int n = col0 + wn * (BN / WN) + j * 32 + c4;
+      const bool n_ok = n < p.N;                 // N % 4 == 0: the float4 is all inside or all outside
+      float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+      if (direct && p.bias && n_ok) {
+        const f32x4 t = ldg4(p.bias + n);
+        b0 = t[0]; b1 = t[1]; b2 = t[2]; b3 = t[3];
+      }
+#pragma unroll
+      for (int i = 0; i < TM; ++i) {
+#pragma unroll
+        for (int e = 0; e < 16; ++e) scratch[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + l31] = acc[i][j][e];
+#pragma unroll
+        for (int q = 0; q < 4; ++q) {
+          const int r = rr + 8 * q;
+          f32x4 v = *reinterpret_cast<const f32x4*>(scratch + r * EPI_LD + c4);
+          const int m = row0 + wm * (BM / WM) + i * 32 + r;
+          if (m >= p.M || !n_ok) continue;
+          if (direct) {
+            v = f32x4{__builtin_fmaf(v[0], p.alpha, b0), __builtin_fmaf(v[1], p.alpha, b1), __builtin_fmaf(v[2], p.alpha, b2),
+                      __builtin_fmaf(v[3], p.alpha, b3)};
+            if (p.rowadd) v += ldg4(p.rowadd + (long)p.fdRpg.div(m) * p.ld_rowadd + n);
+            if (R) v += ldg4(R + (long)m * p.ldr + n);
+          }
+          *reinterpret_cast<f32x4*>(C + (long)m * ldc + n) = v;
+        }
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int j = 0; j < TN; ++j) {
     int n = col0 + wn * (BN / WN) + j * 32 + l31;
@@ -618,7 +667,7 @@ __device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc
         if (m >= p.M) continue;
         float v = acc[i][j][e];
         if (direct) {
-          v = v * p.alpha + bias;
+          v = __builtin_fmaf(v, p.alpha, bias);
           if (p.rowadd) v += p.rowadd[(long)p.fdRpg.div(m) * p.ld_rowadd + n];
           if (R) v += R[(long)m * p.ldr + n];
         }
@@ -777,7 +826,7 @@ __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
   const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct);
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct, lds + (tid >> 6) * EPI_WAVE);
 }
 
 // ------------------------------------------------------------------------------------
@@ -935,7 +984,8 @@ __global__ __launch_bounds__(NTHREADS) void gemm_bf16_kernel(const DevArgs p) {
   float* C = direct ? p.C + z0 * p.sC0 + z1 * p.sC1 : p.ws + (long)zs * p.M * p.N;
   const float* R = (direct && p.residual) ? p.residual + z0 * p.sC0 + z1 * p.sC1 : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct);
+  static_assert(sizeof(lds) >= 4 * EPI_WAVE * sizeof(float), "epilogue scratch");
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, C, ldc, R, direct, reinterpret_cast<float*>(lds) + (tid >> 6) * EPI_WAVE);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1104,7 +1154,7 @@ __global__ __launch_bounds__(NTHREADS, (W == 64 || NI == 8) ? 2 : 3) void conv3x
     chunk = nchunk;
   }
 
-  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, p.C, p.ldc, p.residual, true);
+  store_block<TM, TN, BM, BN>(p, acc, row0, col0, wm, wn, h, l31, p.C, p.ldc, p.residual, true, reinterpret_cast<float*>(lds) + (tid >> 6) * EPI_WAVE);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1259,7 +1309,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
   const float* R = direct ? p.residual : nullptr;
   const int ldc = direct ? p.ldc : p.N;
-  store_block<TM, TN, BM, BN, WM, WN>(p, acc, row0, col0, wm, wn, h, l31, Cp, ldc, R, direct);
+  store_block<TM, TN, BM, BN, WM, WN>(p, acc, row0, col0, wm, wn, h, l31, Cp, ldc, R, direct, lds + wave * EPI_WAVE);
 }
 
 // ------------------------------------------------------------------------------------
@@ -1720,6 +1770,11 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   d.ld_rowadd = a->ld_rowadd; d.residual = a->residual; d.ldr = a->ldr;
   d.ws = (float*)a->ws;
   d.tiles_m = d.tiles_n = d.splitk = d.ktiles_per_split = 1;
+  // float4 epilogue: every tensor the epilogue touches can be addressed as aligned float4 at columns that are multiples of 4
+  d.epi_vec = (!(a->flags & GAD_GEMM_SCALAR_EPILOGUE) && gad_aligned16(a->C) && a->ldc % 4 == 0 && a->N % 4 == 0 &&
+               a->strideC0 % 4 == 0 && a->strideC1 % 4 == 0 && (!a->bias || gad_aligned16(a->bias)) &&
+               (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
+               (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0)) && (!a->ws || gad_aligned16(a->ws))) ? 1 : 0;
 
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");

@@ -715,3 +715,53 @@ def test_attention_fused_qkv_inference_path_is_bit_identical(ops, monkeypatch):
     with torch.no_grad():
         after = att(x)
     assert not torch.equal(before, after) and torch.equal(after, att(x).detach())
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_float4_epilogue_is_bit_identical_to_scalar_stores(ops, prec):
+    """The LDS-transposed float4 epilogue (csrc/gemm_f32.hip::store_block) against dword stores straight from the
+    accumulators (kernel_flags(scalar_epilogue=True)): same arithmetic per element, so the outputs must be equal bit
+    for bit - with bias, alpha, time-embedding row add and residual fused, ragged M (last tile partly outside), N that
+    is a multiple of 4 but not of the tile, split-K partials, batched outputs, 64- and 128-wide tiles, the 3x3 patch
+    kernels (forward with 96 / 128 / 160-channel tiles, data gradient).  N % 4 != 0 must take the scalar path either
+    way and still be right."""
+    from gad._capi import A_KC, B_KC
+    import gad
+    with gad.operand_precision(prec):
+        def both(fn):
+            outs = []
+            for flags in ({}, {"scalar_epilogue": True}):
+                with ops.kernel_flags(**flags):
+                    outs.append(fn().clone())
+            assert torch.equal(outs[0], outs[1])
+            return outs[0]
+
+        for (M, N, K, tile, sk) in ((1000, 100, 96, 0, 0), (777, 260, 160, 1, 0), (333, 68, 2048, 2, 4), (4096, 320, 320, 0, 0)):
+            x, w, b = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=0.1).to(dev), rnd(N, seed=3).to(dev)
+            r = rnd(M, N, seed=4).to(dev)
+            y = torch.empty(M, N, device=dev)
+            got = both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K, K, K, N, alpha=0.5, bias=b, residual=r, ldr=N,
+                                             tile_hint=tile, splitk_hint=sk), y)[1])
+            if prec == "f32":
+                close(got, 0.5 * (x.double() @ w.double().t()) + b.double() + r.double(), rtol=3e-4, atol=3e-4)
+        # N % 4 != 0: scalar path
+        M, N, K = 500, 77, 64
+        x, w = rnd(M, K, seed=5).to(dev), rnd(N, K, seed=6, scale=0.1).to(dev)
+        y = torch.empty(M, N, device=dev)
+        got = both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K, K, K, N), y)[1])
+        if prec == "f32":
+            close(got, x.double() @ w.double().t(), rtol=3e-4, atol=3e-4)
+        # batched output with strides
+        Bt, M, N, K = 6, 200, 72, 64
+        x, w = rnd(Bt, M, K, seed=7).to(dev), rnd(Bt, N, K, seed=8, scale=0.1).to(dev)
+        y = torch.empty(Bt, M, N, device=dev)
+        both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K, K, K, N, batch=Bt, sA=(M * K, 0), sB=(N * K, 0),
+                                   sC=(M * N, 0)), y)[1])
+        # 3x3 convolutions on the patch kernels, forward (+ temb + residual) and data gradient
+        for (Bn, Cin, Cout, H) in ((6, 64, 96, 32), (5, 96, 128, 16), (4, 64, 160, 32), (16, 64, 128, 8), (32, 64, 64, 4)):
+            x = rnd(Bn, H, H, Cin, seed=9).to(dev)
+            w = (rnd(Cout, Cin, 3, 3, seed=10, scale=0.05)).to(dev).contiguous(memory_format=torch.channels_last)
+            b, temb = rnd(Cout, seed=11).to(dev), rnd(Bn, Cout, seed=12).to(dev)
+            res, dy = rnd(Bn, H, H, Cout, seed=13).to(dev), rnd(Bn, H, H, Cout, seed=14).to(dev)
+            both(lambda: ops.conv2d_fwd_raw(x, w, b, rowadd=temb, residual=res))
+            both(lambda: ops.conv2d_dgrad_raw(dy, w, (Bn, H, H, Cin)))
