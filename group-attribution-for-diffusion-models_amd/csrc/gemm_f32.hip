@@ -1426,25 +1426,143 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
   }
 }
 
+// ------------------------------------------------------------------------------------
+// 3x3 / stride 1 / pad 1 convolution with FEW output channels (conv_out of the U-Nets: 128 -> 3, 224 -> 3, 320 -> 4).
+// On the MFMA kernels such a launch is >= 90 % padding (N = 3 in a 64-wide tile: 5 TF/s, 13x its HBM time); its
+// arithmetic (9 C N FMAs per pixel) fits the vector ALUs inside the time HBM needs to deliver the input once.  So: a
+// workgroup = 256 consecutive pixels (whole rows of one image), one thread per pixel; the halo'd input patch of a
+// 32-channel chunk lives in LDS exactly as in conv3x3_patch_f32_kernel (144-B pixel stride, next chunk prefetched
+// into registers); the weights are workgroup-uniform, so they arrive through the SCALAR cache as SGPR operands of the
+// FMAs (no LDS, no vector loads); a thread accumulates its pixel's NOUT outputs over all taps and channels
+// (channel-sequential within a chunk, chunk-major: a fixed order) and writes bias + alpha * sum.
+// ------------------------------------------------------------------------------------
+template <int W, int NOUT>
+__global__ __launch_bounds__(NTHREADS) void conv3x3_fewout_kernel(const DevArgs p) {
+  constexpr int TP = NTHREADS, TR = TP / W, PW = W + 2, PR = TR + 2, NPIX = PR * PW;
+  constexpr int PSL = (NPIX * 8 + NTHREADS - 1) / NTHREADS;
+  __shared__ __attribute__((aligned(16))) float patch[NPIX * PLD];
+
+  const int row0 = blockIdx.x * TP;
+  const int H = p.g.Ho, C = p.g.C;
+  const int img = row0 / (H * W), oh0 = (row0 - img * (H * W)) / W;
+  const int tid = threadIdx.x;
+
+  int poff[PSL];
+  unsigned pvalid = 0;
+#pragma unroll
+  for (int i = 0; i < PSL; ++i) {
+    int j = tid + NTHREADS * i;
+    int pp = j >> 3, q4 = (j & 7) * 4;
+    int pr = pp / PW, pc = pp - pr * PW;
+    int ih = oh0 + pr - 1, iw = pc - 1;
+    bool ok = pp < NPIX && ih >= 0 && ih < H && iw >= 0 && iw < W;
+    poff[i] = ok ? ((img * p.g.H + ih) * p.g.W + iw) * p.g.ldx + q4 : 0;
+    pvalid |= (unsigned)ok << i;
+  }
+  f32x4 rp[PSL];
+  auto fetch = [&](int chunk) {
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + chunk * BK, (pvalid >> i) & 1u));
+  };
+  auto commit = [&]() {
+#pragma unroll
+    for (int i = 0; i < PSL; ++i) {
+      int j = tid + NTHREADS * i;
+      if (j < NPIX * 8) *reinterpret_cast<f32x4*>(patch + (j >> 3) * PLD + (j & 7) * 4) = rp[i];
+    }
+  };
+
+  typedef float f32x2 __attribute__((ext_vector_type(2)));
+  f32x2 acc[NOUT];
+#pragma unroll
+  for (int n = 0; n < NOUT; ++n) acc[n] = f32x2{0.f, 0.f};
+  const float* px0 = patch + ((tid / W) * PW + (tid % W)) * PLD;
+
+  const int nchunks = C / BK;
+  fetch(0);
+  commit();
+  __syncthreads();
+  for (int chunk = 0; chunk < nchunks; ++chunk) {
+    if (chunk + 1 < nchunks) fetch(chunk + 1);
+    const float* wc = p.B + chunk * BK;                  // B[n][tap][c]: workgroup-uniform addresses -> scalar loads
+#pragma unroll 1
+    for (int tap = 0; tap < 9; ++tap) {
+      const float* px = px0 + ((tap / 3) * PW + (tap % 3)) * PLD;
+      const float* wt = wc + tap * C;
+#pragma unroll
+      for (int q = 0; q < 8; ++q) {
+        const f32x4 x = *reinterpret_cast<const f32x4*>(px + 4 * q);
+#pragma unroll
+        for (int n = 0; n < NOUT; ++n) {
+          const float* w = wt + (long)n * p.ldb + 4 * q;
+          acc[n] = f32x2{x[0], x[1]} * f32x2{w[0], w[1]} + acc[n];
+          acc[n] = f32x2{x[2], x[3]} * f32x2{w[2], w[3]} + acc[n];
+        }
+      }
+    }
+    __syncthreads();                                     // every thread is done with this chunk's patch
+    if (chunk + 1 < nchunks) {
+      commit();
+      __syncthreads();
+    }
+  }
+  const int m = row0 + tid;
+  if (m < p.M) {
+#pragma unroll
+    for (int n = 0; n < NOUT; ++n)
+      if (n < p.N) p.C[(long)m * p.ldc + n] = __builtin_fmaf(acc[n][0] + acc[n][1], p.alpha, p.bias ? p.bias[n] : 0.f);
+  }
+}
+
 // split-K: C = epilogue(sum_s ws[z][s][m][n])
 __global__ void splitk_reduce_kernel(const DevArgs p, int batch) {
-  long total = (long)batch * p.M * p.N;
+  const long mn = (long)p.M * p.N;
+  if (p.epi_vec) {
+    // float4 form (every tensor involved is 16-byte addressable at columns that are multiples of 4; N % 4 == 0): the
+    // same per-element sums in the same order as the scalar form below
+    const long total4 = (long)batch * mn / 4;
+    for (long i4 = (long)blockIdx.x * blockDim.x + threadIdx.x; i4 < total4; i4 += (long)gridDim.x * blockDim.x) {
+      const long idx = i4 * 4;
+      int z = 0;
+      long r = idx;
+      if (batch > 1) { z = (int)(idx / mn); r = idx - (long)z * mn; }
+      const int m = mn < (1L << 31) ? (int)((unsigned)r / (unsigned)p.N) : (int)(r / p.N);
+      const int n = (int)(r - (long)m * p.N);
+      const float* w = p.ws + (long)z * p.splitk * mn + r;
+      f32x4 v = zero4();
+      for (int s = 0; s < p.splitk; ++s) v += ldg4(w + (long)s * mn);
+      const f32x4 b = p.bias ? ldg4(p.bias + n) : zero4();
+      v = f32x4{__builtin_fmaf(v[0], p.alpha, b[0]), __builtin_fmaf(v[1], p.alpha, b[1]), __builtin_fmaf(v[2], p.alpha, b[2]),
+                __builtin_fmaf(v[3], p.alpha, b[3])};
+      if (p.rowadd) v += ldg4(p.rowadd + (long)p.fdRpg.div(m) * p.ld_rowadd + n);
+      const int z0 = z / p.batch_inner, z1 = z - z0 * p.batch_inner;
+      const long coff = z0 * p.sC0 + z1 * p.sC1;
+      if (p.residual) v += ldg4(p.residual + coff + (long)m * p.ldr + n);
+      *reinterpret_cast<f32x4*>(p.C + coff + (long)m * p.ldc + n) = v;
+    }
+    return;
+  }
+  long total = (long)batch * mn;
   for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < total; idx += (long)gridDim.x * blockDim.x) {
-    long mn = (long)p.M * p.N;
     int z = (int)(idx / mn);
     long r = idx - (long)z * mn;
     int m = (int)(r / p.N), n = (int)(r - (long)m * p.N);
     const float* w = p.ws + (long)z * p.splitk * mn + r;
     float v = 0.f;
     for (int s = 0; s < p.splitk; ++s) v += w[(long)s * mn];
-    v *= p.alpha;
-    if (p.bias) v += p.bias[n];
+    v = __builtin_fmaf(v, p.alpha, p.bias ? p.bias[n] : 0.f);
     if (p.rowadd) v += p.rowadd[(long)(m / p.rows_per_group) * p.ld_rowadd + n];
     int z0 = z / p.batch_inner, z1 = z - z0 * p.batch_inner;
     long coff = z0 * p.sC0 + z1 * p.sC1;
     if (p.residual) v += p.residual[coff + (long)m * p.ldr + n];
     p.C[coff + (long)m * p.ldc + n] = v;
   }
+}
+
+static void launch_splitk_reduce(const DevArgs& d, int batch, hipStream_t st) {
+  const long items = (long)batch * d.M * d.N / (d.epi_vec ? 4 : 1);
+  const int blocks = (int)(gad_ceil_div(items, 256) < 2048 ? gad_ceil_div(items, 256) : 2048);
+  hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, d, batch);
 }
 
 static FastDiv make_fastdiv(unsigned d) {
@@ -1614,6 +1732,16 @@ static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
   return pp->blocks >= 192;
 }
 
+// 3x3 / stride 1 / pad 1 forward conv with <= 4 output channels on whole 256-pixel row tiles: the vector-ALU kernel
+static bool use_fewout_conv(const gad_gemm_args* a) {
+  const gad_conv_geom& g = a->g;
+  return a->a_mode == GAD_A_CONV && a->b_mode == GAD_B_KC && a->N <= 4 && !a->A2 && !a->A_k2 && pick_vec(a) == 4 &&
+         g.KH == 3 && g.KW == 3 && g.stride == 1 && g.pad_t == 1 && g.pad_l == 1 && !g.upsample && g.Ho == g.H && g.Wo == g.W &&
+         (g.W == 64 || g.W == 32 || g.W == 16) && (g.H * g.W) % 256 == 0 && a->M % 256 == 0 && g.C % BK == 0 &&
+         a->batch <= 1 && !a->rowadd && !a->residual && a->tile_hint == 0 && a->splitk_hint <= 1 &&
+         (long)a->M * g.ldx < (1L << 31) && !(a->flags & GAD_GEMM_NO_PATCH);
+}
+
 // 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible)
 static int wgrad_patch_splits(const gad_gemm_args* a) {
   const gad_conv_geom& g = a->g;
@@ -1635,6 +1763,7 @@ extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf1
 
 extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
+  if (use_fewout_conv(a)) return 4;
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
   if (use_bf16(a)) return 1;
@@ -1646,7 +1775,10 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
   *vec = pick_vec(a);
   PatchPlan pp;
-  if (int sp = wgrad_patch_splits(a)) {          // patch weight gradient: 128 output channels x pixel splits
+  if (use_fewout_conv(a)) {                      // vector-ALU kernel: 256 pixels x all (<= 4) output channels
+    *tile = 256;
+    *splitk = 1;
+  } else if (int sp = wgrad_patch_splits(a)) {   // patch weight gradient: 128 output channels x pixel splits
     *tile = 128;
     *splitk = sp;
   } else if (!use_bf16(a) && use_patch_conv_f32(a, &pp)) {   // patch forward / dgrad: 128 pixels x bn channels
@@ -1661,6 +1793,7 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
 }
 
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
+  if (use_fewout_conv(a)) return 0;
   if (int sp = wgrad_patch_splits(a)) return sp > 1 ? (int64_t)sp * a->M * a->N * (int64_t)sizeof(float) : 0;
   {
     PatchPlan pp;
@@ -1779,6 +1912,20 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (use_fewout_conv(a)) {
+    dim3 grid((unsigned)(a->M / 256)), block(NTHREADS);
+#define GAD_FEWOUT(W_)                                                                          \
+    do {                                                                                        \
+      if (a->N <= 3) hipLaunchKernelGGL((conv3x3_fewout_kernel<W_, 3>), grid, block, 0, st, d); \
+      else hipLaunchKernelGGL((conv3x3_fewout_kernel<W_, 4>), grid, block, 0, st, d);           \
+    } while (0)
+    if (a->g.W == 64) GAD_FEWOUT(64);
+    else if (a->g.W == 32) GAD_FEWOUT(32);
+    else GAD_FEWOUT(16);
+#undef GAD_FEWOUT
+    GAD_LAUNCH_CHECK("gad_gemm(conv3x3 few outputs)");
+    return 0;
+  }
   if (int sp = wgrad_patch_splits(a)) {
     const long ksteps = a->K / BK;
     d.tiles_m = (int)gad_ceil_div(a->M, 128);
@@ -1794,9 +1941,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<8>), grid, block, 0, st, d);
     GAD_LAUNCH_CHECK("gad_gemm(wgrad3x3 patch)");
     if (d.splitk > 1) {
-      long total = (long)a->M * a->N;
-      int blocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, 1);
+      launch_splitk_reduce(d, 1, st);
       GAD_LAUNCH_CHECK("gad_gemm(wgrad splitk reduce)");
     }
     return 0;
@@ -1850,9 +1995,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 #undef GAD_PATCH
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 patch f32)");
     if (pp.splitk > 1) {
-      long total = (long)a->M * a->N;
-      int rblocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
-      hipLaunchKernelGGL(splitk_reduce_kernel, dim3(rblocks), dim3(256), 0, st, d, 1);
+      launch_splitk_reduce(d, 1, st);
       GAD_LAUNCH_CHECK("gad_gemm(patch splitk reduce)");
     }
     return 0;
@@ -1896,9 +2039,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 #undef GAD_CASE
   GAD_LAUNCH_CHECK("gad_gemm");
   if (pl.splitk > 1) {
-    long total = batch * (long)a->M * a->N;
-    int blocks = (int)(gad_ceil_div(total, 256) < 2048 ? gad_ceil_div(total, 256) : 2048);
-    hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks), dim3(256), 0, st, d, (int)batch);
+    launch_splitk_reduce(d, (int)batch, st);
     GAD_LAUNCH_CHECK("gad_gemm(splitk reduce)");
   }
   return 0;

@@ -765,3 +765,26 @@ def test_float4_epilogue_is_bit_identical_to_scalar_stores(ops, prec):
             res, dy = rnd(Bn, H, H, Cout, seed=13).to(dev), rnd(Bn, H, H, Cout, seed=14).to(dev)
             both(lambda: ops.conv2d_fwd_raw(x, w, b, rowadd=temb, residual=res))
             both(lambda: ops.conv2d_dgrad_raw(dy, w, (Bn, H, H, Cin)))
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(8, 128, 3, 32), (4, 224, 3, 64), (8, 320, 4, 32), (16, 64, 2, 16), (8, 96, 1, 32)])
+def test_conv3x3_few_output_channels_vector_alu_kernel(ops, B, Cin, Cout, H):
+    """conv_out of the U-Nets (128 -> 3, 224 -> 3, 320 -> 4; unconditional_generation/main.py:332 / UNet2DConditionModel
+    conv_out): `conv3x3_fewout_kernel` (vector ALUs, weights through the scalar cache) against an fp64 convolution and
+    against the MFMA engine on the same inputs; gad_gemm_kernel_id must say which one ran."""
+    x = rnd(B, H, H, Cin, seed=1).to(dev)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last)
+    b = rnd(Cout, seed=3).to(dev)
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        y = ops.conv2d_fwd_raw(x, w, b)
+        with ops.kernel_flags(no_patch=True):
+            y_mfma = ops.conv2d_fwd_raw(x, w, b)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    names = [k[0] for k in prof.summary()]
+    assert any("fewout_valu" in n for n in names) and any(n == "conv_fwd" for n in names), names
+    ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1)
+    close(y, ref, rtol=2e-5, atol=2e-5)
+    close(y, y_mfma, rtol=2e-5, atol=2e-5)

@@ -15,7 +15,7 @@ def timeit(fn, iters=10, warm=2):
     for _ in range(iters): fn()
     torch.cuda.synchronize(); return (time.time() - t0) / iters
 with torch.no_grad():
-    for B in (128, 256, 512, 640, 1024):
+    for B in (512, 1024, 2048):
         x = torch.randn(B, 32, 32, 3, device=dev); t = torch.randint(0, 1000, (B,), device=dev)
         ms = timeit(lambda: net.forward_nhwc(x, t)) * 1e3
         print(f"fwd B={B}: {ms:.2f} ms  {ms/B*1e3:.1f} us/img  {12.44e9*B/ms/1e9:.1f} TF/s", flush=True)
