@@ -1588,7 +1588,7 @@ static int pick_vec(const gad_gemm_args* a) {
 }
 
 struct Plan {
-  int bm, tiles_m, tiles_n, splitk, ktiles_per_split;
+  int bm, bn, tiles_m, tiles_n, splitk, ktiles_per_split;
   long nblocks;
 };
 
@@ -1596,6 +1596,11 @@ struct Plan {
 // sweep in tools/sweep_conv.py: a CU holds 2 (128x128) or 4 (64x64) workgroups whose waves share each
 // SIMD's matrix pipe; one K step costs conc*mfma + X cycles (X = load/barrier time that is not hidden);
 // split-K adds a reduction pass over (sk+1)*M*N floats.
+static bool dense_128x64_ok(const gad_gemm_args* a) {
+  const bool dense = (a->a_mode == GAD_A_KC || a->a_mode == GAD_A_MC) && (a->b_mode == GAD_B_KC || a->b_mode == GAD_B_MC) &&
+                     !(a->a_mode == GAD_A_MC && a->b_mode == GAD_B_KC);
+  return dense && !a->A_k2 && !a->A2 && pick_vec(a) == 4 && !(a->operand_precision == 1);
+}
 static Plan make_plan(const gad_gemm_args* a) {
   const long batch = a->batch > 0 ? a->batch : 1;
   const int kt = (int)gad_ceil_div(a->K, BK) > 0 ? (int)gad_ceil_div(a->K, BK) : 1;
@@ -1645,6 +1650,7 @@ static Plan make_plan(const gad_gemm_args* a) {
       if (us < best) {
         best = us;
         pl.bm = bm;
+        pl.bn = bm;
         pl.tiles_m = (int)gad_ceil_div(a->M, bm);
         pl.tiles_n = (int)gad_ceil_div(a->N, bm);
         pl.splitk = sk_eff;
@@ -1654,13 +1660,30 @@ static Plan make_plan(const gad_gemm_args* a) {
       if (a->splitk_hint > 0) break;
     }
   }
+  // 128 x 64 tiles (3 workgroups per CU, 1.5x the FLOPs per staged byte of 64 x 64, no padding for N = 320 / 640 / 192):
+  // where the model above prefers 64 x 64 without a split and there are rows enough for > 1 round of them, this shape
+  // measured +3..7 % on the forward / data-gradient forms (tools/sweep_gemm.py, profiles/r02_sd_gemm_tile_sweep.txt)
+  const bool auto_128x64 = a->tile_hint == 0 && a->splitk_hint <= 0 && pl.bm == 64 && pl.splitk == 1 && batch == 1 &&
+                           a->M >= 16384 && a->a_mode == GAD_A_KC;
+  if ((a->tile_hint == 3 || auto_128x64) && dense_128x64_ok(a)) {
+    pl.bm = 128; pl.bn = 64;
+    pl.tiles_m = (int)gad_ceil_div(a->M, 128);
+    pl.tiles_n = (int)gad_ceil_div(a->N, 64);
+    pl.splitk = 1;
+    pl.ktiles_per_split = kt;
+    pl.nblocks = (long)pl.tiles_m * pl.tiles_n * batch;
+  }
   return pl;
 }
 
 template <int AM, int BMODE, int VEC>
 static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
   dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
-  if (pl.bm == 128)
+  if (pl.bm == 128 && pl.bn == 64) {
+    if constexpr (VEC == 4 && (AM == GAD_A_KC || AM == GAD_A_MC) && (BMODE == GAD_B_KC || BMODE == GAD_B_MC) &&
+                  !(AM == GAD_A_MC && BMODE == GAD_B_KC))
+      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 64, VEC>), grid, block, 0, st, d);
+  } else if (pl.bm == 128)
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC>), grid, block, 0, st, d);
   else
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC>), grid, block, 0, st, d);

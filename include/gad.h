@@ -81,7 +81,7 @@ typedef struct gad_gemm_args {
   /* split-K workspace (caller owned). ws_bytes >= gad_gemm_workspace_bytes(args)            */
   void* ws;
   int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64                  */
+  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms) */
   int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
   /* 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products; the reference's default precision).
    * 1: A and B may be rounded to bf16 (RNE) in flight and multiplied on v_mfma_f32_32x32x16_bf16 with fp32

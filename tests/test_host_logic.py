@@ -132,7 +132,7 @@ def test_optimizer_state_round_trips_through_torch_adam():
     moments must import from it and export a dict torch.optim.Adam itself accepts, conv weights included
     (flat storage is [Cout,KH,KW,Cin], the state dict is logical [Cout,Cin,KH,KW])."""
     import torch
-    from gad.training import adam_state_from_torch, adam_state_to_torch, flat_views
+    from gad.training import _slot, adam_state_from_torch, adam_state_to_torch, flat_views
 
     torch.manual_seed(0)
     net = torch.nn.Sequential(torch.nn.Conv2d(3, 5, 3), torch.nn.Flatten(), torch.nn.Linear(5 * 36, 7))
@@ -143,7 +143,7 @@ def test_optimizer_state_round_trips_through_torch_adam():
         net(torch.randn(2, 3, 8, 8)).square().mean().backward()
         opt.step()
     sd = opt.state_dict()
-    total = sum((p.numel() + 3) // 4 * 4 for p in params)
+    total = sum(_slot(p.numel()) for p in params)              # the flat layout's 32-byte slots (flatten_params)
     m, v = torch.full((total,), 9.0), torch.full((total,), 9.0)
     assert adam_state_from_torch(sd, params, m, v) == 3
     for i, (a, b) in enumerate(zip(flat_views(params, m), flat_views(params, v))):

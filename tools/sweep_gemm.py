@@ -22,7 +22,7 @@ def timeit(fn, iters=10, warm=2):
     return s.elapsed_time(e) / iters
 
 
-SHAPES = [(65536, 320, 320), (65536, 256, 320), (65536, 320, 256), (65536, 2560, 320), (65536, 320, 1280),
+SHAPES = [(262144, 768, 256), (262144, 256, 256), (65536, 320, 320), (65536, 256, 320), (65536, 320, 256), (65536, 2560, 320), (65536, 320, 1280),
           (16384, 640, 640), (16384, 256, 640), (16384, 640, 256), (16384, 5120, 640), (16384, 640, 2560),
           (4096, 1280, 1280), (4096, 256, 1280), (4096, 1280, 256), (4096, 10240, 1280), (4096, 1280, 5120),
           (1024, 1280, 1280), (4928, 320, 768), (4928, 1280, 768), (4928, 256, 768)]
@@ -35,8 +35,8 @@ for M, N, K in SHAPES:
                      ("nn", lambda t: ops.gemm_raw(dy, w, dx, A_KC, B_MC, M, K, N, N, K, K, tile_hint=t)),
                      ("tn", lambda t: ops.gemm_raw(dy, x, dw, A_MC, B_MC, N, K, M, N, K, K, tile_hint=t))):
         r = []
-        for t in (0, 1, 2):
+        for t in (0, 1, 2, 3):
             ms = timeit(lambda: fn(t))
             r.append(f"{fl / ms / 1e9:5.1f}")
-        line += f"{form} auto/128/64 = {'/'.join(r)} TF/s | "
+        line += f"{form} auto/128/64/128x64 = {'/'.join(r)} TF/s | "
     print(line, flush=True)
