@@ -1599,7 +1599,7 @@ struct Plan {
 static bool dense_128x64_ok(const gad_gemm_args* a) {
   const bool dense = (a->a_mode == GAD_A_KC || a->a_mode == GAD_A_MC) && (a->b_mode == GAD_B_KC || a->b_mode == GAD_B_MC) &&
                      !(a->a_mode == GAD_A_MC && a->b_mode == GAD_B_KC);
-  return dense && !a->A_k2 && !a->A2 && pick_vec(a) == 4 && !(a->operand_precision == 1);
+  return dense && !a->A2 && pick_vec(a) == 4 && !(a->operand_precision == 1);     // incl. the K-concatenated (LoRA) forms
 }
 static Plan make_plan(const gad_gemm_args* a) {
   const long batch = a->batch > 0 ? a->batch : 1;
@@ -1680,8 +1680,9 @@ template <int AM, int BMODE, int VEC>
 static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
   dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
   if (pl.bm == 128 && pl.bn == 64) {
-    if constexpr (VEC == 4 && (AM == GAD_A_KC || AM == GAD_A_MC) && (BMODE == GAD_B_KC || BMODE == GAD_B_MC) &&
-                  !(AM == GAD_A_MC && BMODE == GAD_B_KC))
+    if constexpr (VEC == 4 && (((AM == GAD_A_KC || AM == GAD_A_MC) && (BMODE == GAD_B_KC || BMODE == GAD_B_MC) &&
+                                !(AM == GAD_A_MC && BMODE == GAD_B_KC)) ||
+                               (AM == A_KC2 && (BMODE == B_KC2 || BMODE == B_MC2))))
       hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 64, VEC>), grid, block, 0, st, d);
   } else if (pl.bm == 128)
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC>), grid, block, 0, st, d);

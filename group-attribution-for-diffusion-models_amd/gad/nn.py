@@ -149,7 +149,7 @@ class Attention(nn.Module):
         """[3C, C] weight and [3C] bias of the three projections, concatenated once and reused while the parameters are
         unchanged (sampling: thousands of forwards on fixed EMA weights)."""
         ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_q.bias, self.to_k.bias, self.to_v.bias)
-        key = (ops.WEIGHT_EPOCH[0],) + tuple((p.data_ptr(), p._version) for p in ps)   # raw optimizer kernels bump the epoch
+        key = tuple(ops.weight_key(p) for p in ps)           # incl. the epochs the raw optimizer kernels bump
         if getattr(self, "_qkv_key", None) != key:
             self._qkv_w = torch.cat([p.detach() for p in ps[:3]], 0).contiguous()
             self._qkv_b = torch.cat([p.detach() for p in ps[3:]], 0).contiguous()

@@ -304,7 +304,7 @@ def bf16_weight(w):
     home = getattr(w, "_gad_flat", None)
     if home is not None and w.data_ptr() == home[0].data_ptr() + 4 * home[1]:
         flat, off, n = home
-        key = (flat._version, WEIGHT_EPOCH[0])
+        key = (flat._version, WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
         cached = getattr(flat, "_gad_bf16", None)
         if cached is None or cached[0] != key:
             shadow = cached[1] if cached is not None else torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
@@ -313,11 +313,32 @@ def bf16_weight(w):
             flat._gad_bf16 = cached
         o, i, kh, kw = w.shape
         return cached[1][off:off + n].view(o, kh, kw, i)
-    key = (w.data_ptr(), w._version, WEIGHT_EPOCH[0])
+    key = weight_key(w)
     cached = getattr(w, "_gad_bf16", None)
     if cached is None or cached[0] != key:
         cached = (key, weight_krsc(w).detach().to(torch.bfloat16).contiguous())
         w._gad_bf16 = cached
+    return cached[1]
+
+
+def frozen_dgrad_as_forward(w, stride, pad, upsample) -> bool:
+    """A FROZEN 3x3 / stride-1 / pad-1 weight (the SD LoRA step: every convolution of the base U-Net) lets the data
+    gradient run as a FORWARD convolution of dy with the 180-degree-rotated, channel-transposed weight: the forward patch
+    kernels (4 x 1 waves, 96 / 128 / 160-channel tiles; in bf16 mode the LDS-DMA bf16 weight stream instead of the generic
+    bf16 kernel) are faster than the data-gradient instances, and the rotated copy is made once."""
+    return (not w.requires_grad and tuple(w.shape[2:]) == (3, 3) and stride == 1 and tuple(pad) == (1, 1, 1, 1)
+            and not upsample and w.shape[0] % 32 == 0 and w.shape[1] >= 64)
+
+
+def rotated_weight(w):
+    """W'[ci][2-r][2-s][co] = W[co][r][s][ci] as a conv parameter of logical shape [Cin, Cout, 3, 3] (storage
+    [Cin][3][3][Cout]), cached per weight version."""
+    key = weight_key(w)
+    cached = getattr(w, "_gad_rot", None)
+    if cached is None or cached[0] != key:
+        store = weight_krsc(w).detach().flip(1, 2).permute(3, 1, 2, 0).contiguous()      # [Cin][KH][KW][Cout]
+        cached = (key, store.permute(0, 3, 1, 2))
+        w._gad_rot = cached
     return cached[1]
 
 
@@ -429,7 +450,12 @@ class Conv2dFn(torch.autograd.Function):
         stride, pad, upsample, has_b, has_r, has_res = ctx.cfg
         dy = dy.contiguous()
         Bn, Ho, Wo, Cout = dy.shape
-        dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample) if ctx.needs_input_grad[0] else None
+        dx = None
+        if ctx.needs_input_grad[0]:
+            if frozen_dgrad_as_forward(w, stride, pad, upsample):
+                dx = conv2d_fwd_raw(dy, rotated_weight(w), None)
+            else:
+                dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample)
         dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o)) \
             if ctx.needs_input_grad[1] else None
         db = dr = None
@@ -930,11 +956,20 @@ def sumsq_raw(g, out=None):
 
 # Raw kernels update parameters through device pointers, which torch's per-tensor version counters do not see.  Anything
 # that caches a function of the weights (the fused q|k|v projection of the sampling path) keys on this epoch as well.
-WEIGHT_EPOCH = [0]
+WEIGHT_EPOCH = [0]            # rare events that rewrite arbitrary parameters behind torch's back (EMA copy_to / restore ...)
+
+
+def weight_key(w):
+    """Cache key of anything derived from parameter `w`: its address, torch's version counter, the global epoch, and -
+    for a parameter living in a flat buffer (training.flatten_params) - that buffer's own epoch, which the raw optimizer
+    kernel bumps every step.  Frozen parameters outside the buffer (the SD base U-Net under LoRA) therefore keep their
+    derived copies (bf16 casts, rotated convolution weights) across training steps."""
+    home = getattr(w, "_gad_flat", None)
+    return (w.data_ptr(), w._version, WEIGHT_EPOCH[0], getattr(home[0], "_gad_epoch", 0) if home is not None else 0)
 
 
 def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weight_decay, adamw, step, ema_decay):
-    WEIGHT_EPOCH[0] += 1
+    p._gad_epoch = getattr(p, "_gad_epoch", 0) + 1        # p is the flat parameter buffer: its residents changed
     a = AdamArgs()
     a.p, a.g, a.m, a.v, a.ema = p.data_ptr(), g.data_ptr(), m.data_ptr(), v.data_ptr(), _ptr(ema)
     a.n = p.numel()
@@ -946,7 +981,6 @@ def clip_adam_ema_raw(p, g, m, v, ema, sumsq, *, max_norm, lr, betas, eps, weigh
 
 
 def ema_update_raw(ema, p, decay: float):
-    WEIGHT_EPOCH[0] += 1
     check(_capi.load().gad_ema_update(ema.data_ptr(), p.data_ptr(), p.numel(), decay, _stream()), "gad_ema_update")
 
 

@@ -788,3 +788,32 @@ def test_conv3x3_few_output_channels_vector_alu_kernel(ops, B, Cin, Cout, H):
     ref = F.conv2d(x.permute(0, 3, 1, 2).double().cpu(), w.double().cpu(), b.double().cpu(), padding=1).permute(0, 2, 3, 1)
     close(y, ref, rtol=2e-5, atol=2e-5)
     close(y, y_mfma, rtol=2e-5, atol=2e-5)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+@pytest.mark.parametrize("B,Cin,Cout,H", [(4, 64, 96, 32), (3, 160, 64, 16), (16, 128, 128, 8)])
+def test_frozen_weight_data_gradient_runs_as_forward_conv(ops, prec, B, Cin, Cout, H):
+    """SD LoRA step: the base U-Net's convolutions are frozen (train_text_to_image_lora.py:776-784), so their data
+    gradient is a forward convolution of dy with the rotated / transposed weight (ops.rotated_weight).  Against the
+    data-gradient kernels on the same inputs and against fp64 autograd; a later in-place change of the weight must be seen."""
+    import gad
+    x = rnd(B, H, H, Cin, seed=1).to(dev).requires_grad_(True)
+    w = torch.nn.Parameter(rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last), requires_grad=False)
+    dy = rnd(B, H, H, Cout, seed=3).to(dev)
+    with gad.operand_precision(prec):
+        assert ops.frozen_dgrad_as_forward(w, 1, (1, 1, 1, 1), False)
+        y = ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), False)
+        y.backward(dy)
+        dx_direct = ops.conv2d_dgrad_raw(dy, w, x.shape)
+    xr = x.detach().permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+    F.conv2d(xr, w.detach().double().cpu(), padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+    want = xr.grad.permute(0, 2, 3, 1)
+    tol = 3e-5 if prec == "f32" else 2e-2
+    close(x.grad, want, rtol=tol, atol=tol)
+    close(x.grad, dx_direct, rtol=tol, atol=tol)
+    with torch.no_grad():
+        w.mul_(2.0)                                   # version bump: the cached rotated copy must be rebuilt
+    x.grad = None
+    with gad.operand_precision(prec):
+        ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), False).backward(dy)
+    close(x.grad, 2.0 * want, rtol=tol, atol=tol)
