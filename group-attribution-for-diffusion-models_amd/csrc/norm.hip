@@ -256,20 +256,19 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
 }
 
 // pick the channel slab; returns NV (0 = no one-pass plan: odd channels-per-group or too many pixels)
-static int make_slab(const gad_groupnorm_args* a, SlabGeo* out) {
+static int make_slab(const gad_groupnorm_args* a, SlabGeo* out, const int nth = NT, const int maxnv = 32) {
   const int cpg = a->C / a->G;
   if (cpg % 4 != 0) return 0;
   SlabGeo best{};
   int best_nv = 0;
   long best_score = -1;
-  const int maxnv = 32;
   for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
     int SC = k * cpg;
     if (a->C % SC != 0) continue;
     if ((SC * 4) % 128 != 0 && SC != a->C) continue;   // slab rows must be whole 128-B lines, or two workgroups fetch each line
     int qpr = SC / 4;
-    if (qpr > NT) break;
-    int PL = NT / qpr;
+    if (qpr > nth) break;
+    int PL = nth / qpr;
     int nv = (a->HW + PL - 1) / PL;
     if (nv > maxnv) continue;
     long blocks = (long)a->B * (a->C / SC);
@@ -294,6 +293,94 @@ __device__ __forceinline__ float act_grad(float dy, float z, int silu) {
   if (!silu) return dy;
   float s = 1.f / (1.f + expf(-z));
   return dy * s * (1.f + z * (1.f - s));
+}
+
+// ------------------------------------------------------ backward, one pass ----
+// The backward reads x and dy ONCE (12 B/elem instead of 20) when an (image, channel slab) fits in the registers of one
+// workgroup - the forward's slab plan with two float4 per slot (xhat, g), so 512 threads x 16 slots cover a
+// 32 x 32 x 32-channel slab.  Per-channel sums A_c = sum g, Bx_c = sum g xhat are reduced over the pixel lanes by a fixed
+// LDS tree (float4 wide), written as the (image, channel) partials of dgamma / dbeta, combined per group with gamma, and
+// dx = rstd (g gamma - m1 - xhat m2) comes from the registers.
+template <int NTH>
+__device__ __forceinline__ void slab_reduce4(f32x4* red, f32x4 val, const SlabGeo& s, int pl, bool act) {
+  red[threadIdx.x] = val;
+  for (int st = s.P2 >> 1; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (act && pl < st && pl + st < s.PL) red[threadIdx.x] += red[threadIdx.x + st * s.qpr];
+  }
+  __syncthreads();
+}
+
+template <int NV, int NTH>
+__global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ dy,
+                                                          float* __restrict__ dx, const float* __restrict__ gamma,
+                                                          const float* __restrict__ beta, const float* __restrict__ mean,
+                                                          const float* __restrict__ rstd, float* __restrict__ part,
+                                                          SlabGeo s, int silu) {
+  __shared__ f32x4 red_a[NTH], red_b[NTH];
+  __shared__ float s_m1[64], s_m2[64];
+  const int b = blockIdx.x / s.nslab, sl = blockIdx.x - b * s.nslab;
+  const int tid = threadIdx.x;
+  const int pl = tid / s.qpr, q = tid - pl * s.qpr;
+  const bool act = pl < s.PL;
+  const int c0 = sl * s.SC + (act ? q : 0) * 4;
+  const long base = ((long)b * s.HW) * s.C + c0;
+  const int grp = sl * s.gps + (act ? q / s.qpg : 0);
+  const float mu = mean[b * s.G + grp], rs = rstd[b * s.G + grp];
+  const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+  f32x4 xh[NV], ge[NV];
+  f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = pl + i * s.PL;
+    if (act && p < s.HW) {
+      const f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * s.C);
+      const f32x4 d = *reinterpret_cast<const f32x4*>(dy + base + (long)p * s.C);
+      xh[i] = (v - mu) * rs;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) ge[i][e] = act_grad(d[e], xh[i][e] * ga[e] + be[e], silu);
+      sa += ge[i];
+      sb += ge[i] * xh[i];
+    } else {
+      xh[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+      ge[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+    }
+  }
+  slab_reduce4<NTH>(red_a, sa, s, pl, act);
+  slab_reduce4<NTH>(red_b, sb, s, pl, act);
+  if (tid < s.qpr) {                                   // pixel lane 0 holds the sums of its channel quad
+    const int c = sl * s.SC + tid * 4;
+    float* o = part + ((long)b * s.C + c) * 2;
+    const f32x4 A = red_a[tid], Bx = red_b[tid];
+#pragma unroll
+    for (int e = 0; e < 4; ++e) { o[2 * e] = A[e]; o[2 * e + 1] = Bx[e]; }
+  }
+  if (tid < s.gps) {
+    const float inv_n = 1.f / (float)((long)s.HW * s.cpg);
+    float s1 = 0.f, s2 = 0.f;
+    for (int j = 0; j < s.qpg; ++j) {
+      const int qq = tid * s.qpg + j;
+      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + sl * s.SC + qq * 4);
+      const f32x4 A = red_a[qq], Bx = red_b[qq];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) { s1 += A[e] * g4[e]; s2 += Bx[e] * g4[e]; }
+    }
+    s_m1[tid] = s1 * inv_n;
+    s_m2[tid] = s2 * inv_n;
+  }
+  __syncthreads();
+  if (!act) return;
+  const float m1 = s_m1[q / s.qpg], m2 = s_m2[q / s.qpg];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    const int p = pl + i * s.PL;
+    if (p < s.HW) {
+      f32x4 o;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) o[e] = rs * (ge[i][e] * ga[e] - m1 - xh[i][e] * m2);
+      *reinterpret_cast<f32x4*>(dx + base + (long)p * s.C) = o;
+    }
+  }
 }
 
 __global__ __launch_bounds__(NT) void gn_bwd_stats_kernel(const float* __restrict__ x, const float* __restrict__ dy,
@@ -425,7 +512,9 @@ static int check(const gad_groupnorm_args* a, const char* who) {
 extern "C" int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a) {
   Geo g = make_geo(a);
   int64_t parts = (int64_t)a->B * g.nch * a->C * 2 * (int64_t)sizeof(float);  // covers fwd (G<=C) and bwd
-  return parts + gad_reduce::ws_bytes(1, (long)a->B * g.nch, 2 * a->C);       // + dgamma/dbeta reduction
+  const int64_t r1 = gad_reduce::ws_bytes(1, (long)a->B * g.nch, 2 * a->C);   // + dgamma/dbeta reduction (two-pass plan)
+  const int64_t r2 = gad_reduce::ws_bytes(1, (long)a->B, 2 * a->C);           //   (one-pass plan: one partial row per image)
+  return parts + (r1 > r2 ? r1 : r2);
 }
 
 extern "C" int gad_groupnorm_one_pass(const gad_groupnorm_args* a) {
@@ -470,6 +559,32 @@ extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream)
   GAD_CHECK(a->dy && gad_aligned16(a->dy) && ((a->dgamma == nullptr) == (a->dbeta == nullptr)), "gad_groupnorm_silu_bwd: null/unaligned grad pointer");
   Geo g = make_geo(a);
   hipStream_t st = (hipStream_t)stream;
+  if (!(a->flags & GAD_GN_TWO_PASS)) {
+    // one pass: a slab plan whose two float4 per slot fit the registers - 256 threads x <= 16 slots, else 512 x <= 16
+    SlabGeo sg;
+    int nth = NT, nv = make_slab(a, &sg, NT, 16);
+    if (!nv) { nth = 512; nv = make_slab(a, &sg, 512, 16); }
+    if (nv) {
+      float* part = (float*)a->ws;
+      dim3 sgrid(a->B * sg.nslab);
+#define GAD_GNB(NV_, NTH_) hipLaunchKernelGGL((gn_bwd_slab_kernel<NV_, NTH_>), sgrid, dim3(NTH_), 0, st, a->x, a->dy, a->y, a->gamma, \
+                                              a->beta, a->mean, a->rstd, part, sg, a->silu)
+      if (nth == NT) {              // (the 8-slot instance is not built: hipcc allocates it 256 registers + scratch)
+        if (nv <= 4) GAD_GNB(4, NT);
+        else GAD_GNB(16, NT);
+      } else {
+        GAD_GNB(16, 512);
+      }
+#undef GAD_GNB
+      GAD_LAUNCH_CHECK("gn_bwd_slab");
+      if (a->dgamma) {
+        float* ws2 = part + (long)a->B * a->C * 2;
+        gad_reduce::launch(part, a->dbeta, a->dgamma, 1, (long)a->B, 2 * a->C, ws2, st);
+        GAD_LAUNCH_CHECK("gn_bwd_param");
+      }
+      return 0;
+    }
+  }
   dim3 grid(a->B * g.nch), block(NT);
   hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, st, a->x, a->dy, a->gamma, a->beta, a->mean, a->rstd, (float*)a->ws, g, a->silu);
   GAD_LAUNCH_CHECK("gn_bwd_stats");
