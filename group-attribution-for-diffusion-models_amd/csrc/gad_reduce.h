@@ -107,6 +107,10 @@ static inline int64_t ws_bytes(int S, long M, int N) { return (int64_t)S * plan(
 
 // returns 0 on success (launch errors are checked by the caller)
 static inline void launch(const float* x, float* out0, float* out1, int S, long M, int N, float* ws, hipStream_t st) {
+  if (M <= 512) {      // few rows (per-image partials, [B, C] time-embedding gradients): the final stage alone, one launch
+    hipLaunchKernelGGL(colsum_final, dim3((N + FC - 1) / FC, S), dim3(NT), 0, st, x, out0, out1, (int)M, N);
+    return;
+  }
   Plan p = plan(S, M, N);
   if (p.vec && gad_aligned16(x))
     hipLaunchKernelGGL(colsum_part_vec, dim3(p.nparts, S), dim3(NT), 0, st, x, ws, M, N, p.rows_per, p.nparts);
