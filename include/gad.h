@@ -119,14 +119,17 @@ enum gad_gemm_flags {
 };
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
-/* which kernel instance gad_gemm would launch: block tile edge (128 or 64), split-K factor, vector width (4 or 1) */
+/* which kernel instance gad_gemm would launch: row extent of the block tile (128 or 64 for the generic engine - 128 also
+ * stands for its 128 x 64 form -, the channel tile 96 / 128 / 160 for the fp32 patch forward, 256 pixels for the vector-ALU
+ * conv_out kernel), split-K factor, vector width (4 or 1) */
 int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec);
 int gad_gemm(const gad_gemm_args* a, void* stream);
-int gad_gemm_uses_bf16(const gad_gemm_args* a);
+int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would multiply bf16-rounded operands */
 /* which kernel family gad_gemm(a) launches: 0 gemm_kernel (fp32, im2col-gather / dense loaders), 1 gemm_bf16_kernel,
- * 2 conv3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 forward convs whose 128-pixel tiles
- * are whole image rows: input patch resident in LDS) */
-int gad_gemm_kernel_id(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would multiply bf16-rounded operands */
+ * 2 conv3x3_patch_f32_kernel / wgrad3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 convs whose
+ * 128-pixel tiles are whole image rows: input patch resident in LDS), 4 conv3x3_fewout_kernel (<= 4 output channels:
+ * vector ALUs, weights through the scalar cache) */
+int gad_gemm_kernel_id(const gad_gemm_args* a);
 
 /* ------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in
