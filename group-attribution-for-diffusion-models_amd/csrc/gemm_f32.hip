@@ -107,6 +107,9 @@ __device__ __forceinline__ f32x4 keep_if(f32x4 v, bool ok) { return ok ? v : zer
 // KC-type: slot i = (row (tid>>3)+32 i, float4 column tid&7)
 // MC-type: slot i = (k row tid/F4 + (256/F4) i, float4 column tid%F4),  F4 = ROWS/4
 // ------------------------------------------------------------------------------------
+// the wave's index as a SCALAR: LDS-DMA destinations (M0) derived from it need no per-launch v_readfirstlane in the K loop
+__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
+
 template <int ROWS>
 struct KCSlots {
   static constexpr int NS = ROWS / 32;
@@ -115,7 +118,7 @@ struct KCSlots {
   // the DMA (physical chunk = lane & 7), so the swizzle is applied to what it loads
   // (row(i) >> 1) & 7 == (tid >> 4) & 7 for every slot i, so the column is slot independent
   __device__ static int kq4() { return ((threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7)) * 4; }
-  __device__ static float* dma_dst(float* tile, int i) { return tile + ((threadIdx.x >> 6) * 8 + 32 * i) * BK; }
+  __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * 8 + 32 * i) * BK; }
   __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -129,7 +132,7 @@ struct MCSlots {
   static constexpr int KSTEP = NTHREADS / F4;
   __device__ static int krow(int i) { return threadIdx.x / F4 + KSTEP * i; }
   __device__ static int rq4() { return (threadIdx.x % F4) * 4; }
-  __device__ static float* dma_dst(float* tile, int i) { return tile + ((threadIdx.x >> 6) * (KSTEP / 4) + KSTEP * i) * ROWS; }
+  __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * (KSTEP / 4) + KSTEP * i) * ROWS; }
   __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
 #pragma unroll
     for (int i = 0; i < NS; ++i)
@@ -294,6 +297,109 @@ struct LoadMCDense : MCSlots<ROWS> {
     v[i] = t;
     mask |= 1u << i;
   }
+};
+
+// ------------------------------------------------------------------------------------
+// Lean dense loaders (float4 path, K a multiple of 32 - checked on the host).  Every non-MFMA instruction of a K step
+// costs MFMA issue time (tools/micro/mfma_loop_model.hip: 64 full-rate VALU per 64 MFMAs = 3.5 %; a 64 x 64 tile has 16
+// MFMAs per wave and step), and the general loaders above spend ~9 VALU per DMA slot on validity selects against the
+// zero block and on rebuilding the address.  Here nothing needs masking: rows (or row quads) beyond the tensor are
+// CLAMPED to the last valid one - they only feed output rows / columns the epilogue never stores -, K has no tail,
+// and the stage fetched "past the end" (never consumed) re-reads the last step.  A slot's pointer is fixed per tile and
+// a step adds one wave-uniform offset: one 64-bit add per slot.
+// ------------------------------------------------------------------------------------
+template <int ROWS>
+struct LeanKC : KCSlots<ROWS> {                 // dense [row][k]
+  using S = KCSlots<ROWS>;
+  const float* ptr[S::NS];
+  int kend, koff;
+  __device__ void init(const float* b, int ld, int row0, int nrows, int kend_) {
+    kend = kend_;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int r = row0 + S::row(i);
+      r = r < nrows ? r : nrows - 1;
+      ptr[i] = b + (long)r * ld + S::kq4();
+    }
+  }
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) { koff = k0 < kend ? k0 : kend - BK; mask = 0; }
+  __device__ __forceinline__ const float* src(int i) const { return ptr[i] + koff; }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
+};
+template <int ROWS>
+struct LeanMC : MCSlots<ROWS> {                 // dense [k][row]
+  using S = MCSlots<ROWS>;
+  const float* ptr[S::NS];
+  int kend, ld;
+  long koff;
+  __device__ void init(const float* b, int ld_, int row0, int nrows, int kend_) {
+    kend = kend_;
+    ld = ld_;
+    int c0 = row0 + S::rq4();
+    c0 = c0 < nrows ? c0 : nrows - 4;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) ptr[i] = b + (long)S::krow(i) * ld + c0;
+  }
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) { koff = (long)(k0 < kend ? k0 : kend - BK) * ld; mask = 0; }
+  __device__ __forceinline__ const float* src(int i) const { return ptr[i] + koff; }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
+};
+template <int ROWS>
+struct LeanKC2 : KCSlots<ROWS> {                // dense [row][k], K continued in a second tensor at ksplit
+  using S = KCSlots<ROWS>;
+  const float* ptr[S::NS];
+  const float* ptr2[S::NS];
+  int kend, ksplit, koff;
+  bool second;
+  __device__ void init(const float* b, int ld, const float* b2, int ld2, int ksplit_, int row0, int nrows, int kend_) {
+    kend = kend_;
+    ksplit = ksplit_;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int r = row0 + S::row(i);
+      r = r < nrows ? r : nrows - 1;
+      ptr[i] = b + (long)r * ld + S::kq4();
+      ptr2[i] = b2 + (long)r * ld2 + S::kq4();
+    }
+  }
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) {
+    const int k = k0 < kend ? k0 : kend - BK;
+    second = k >= ksplit;
+    koff = second ? k - ksplit : k;
+    mask = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const { return (second ? ptr2[i] : ptr[i]) + koff; }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
+};
+template <int ROWS>
+struct LeanMC2 : MCSlots<ROWS> {                // dense [k][row] with the same K concatenation
+  using S = MCSlots<ROWS>;
+  const float* ptr[S::NS];
+  const float* ptr2[S::NS];
+  int kend, ksplit, ld, ld2;
+  long koff;
+  bool second;
+  __device__ void init(const float* b, int ld_, const float* b2, int ld2_, int ksplit_, int row0, int nrows, int kend_) {
+    kend = kend_;
+    ksplit = ksplit_;
+    ld = ld_;
+    ld2 = ld2_;
+    int c0 = row0 + S::rq4();
+    c0 = c0 < nrows ? c0 : nrows - 4;
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      ptr[i] = b + (long)S::krow(i) * ld + c0;
+      ptr2[i] = b2 + (long)S::krow(i) * ld2 + c0;
+    }
+  }
+  __device__ __forceinline__ void prep(int k0, unsigned& mask) {
+    const int k = k0 < kend ? k0 : kend - BK;
+    second = k >= ksplit;
+    koff = second ? (long)(k - ksplit) * ld2 : (long)k * ld;
+    mask = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const { return (second ? ptr2[i] : ptr[i]) + koff; }
+  __device__ __forceinline__ void slot(int, f32x4*, unsigned&) const {}
 };
 
 // im2col gather, rows = output pixels, k = (r, s, c).  TRANSPOSED = dgrad form:
@@ -552,9 +658,53 @@ struct ALoader<A_KC2, ROWS, VEC> : LoadKCDense2<ROWS> {
   }
 };
 
+// internal: the lean forms of the dense modes (K % 32 == 0, float4)
+constexpr int A_KC_L = 20, A_MC_L = 21, B_KC_L = 22, B_MC_L = 23, A_KC2_L = 24, B_KC2_L = 25, B_MC2_L = 26;
+template <int ROWS, int VEC>
+struct ALoader<A_KC_L, ROWS, VEC> : LeanKC<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.lda, row0, p.M, kend); }
+};
+template <int ROWS, int VEC>
+struct ALoader<A_MC_L, ROWS, VEC> : LeanMC<ROWS> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) { this->init(a, p.lda, row0, p.M, kend); }
+};
+template <int ROWS, int VEC>
+struct ALoader<A_KC2_L, ROWS, VEC> : LeanKC2<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* a, int row0, int kend) {
+    this->init(a, p.lda, p.Ak2, p.lda2, p.k_split, row0, p.M, kend);
+  }
+};
+
 template <int MODE, int ROWS, int VEC>
 struct BLoader;
 constexpr int B_KC2 = 18, B_MC2 = 19;   // internal: B_KC / B_MC with the same K concatenation
+template <int ROWS, int VEC>
+struct BLoader<B_KC_L, ROWS, VEC> : LeanKC<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
+};
+template <int ROWS, int VEC>
+struct BLoader<B_MC_L, ROWS, VEC> : LeanMC<ROWS> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p.ldb, col0, p.N, kend); }
+};
+template <int ROWS, int VEC>
+struct BLoader<B_KC2_L, ROWS, VEC> : LeanKC2<ROWS> {
+  static constexpr bool KC = true;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) {
+    this->init(b, p.ldb, p.Bk2, p.ldb2, p.k_split, col0, p.N, kend);
+  }
+};
+template <int ROWS, int VEC>
+struct BLoader<B_MC2_L, ROWS, VEC> : LeanMC2<ROWS> {
+  static constexpr bool KC = false;
+  __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) {
+    this->init(b, p.ldb, p.Bk2, p.ldb2, p.k_split, col0, p.N, kend);
+  }
+};
 template <int ROWS, int VEC>
 struct BLoader<B_KC2, ROWS, VEC> : LoadKCDense2<ROWS> {
   static constexpr bool KC = true;
@@ -1226,8 +1376,28 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   };
 
   BL bl;
-  bl.setup(p, p.B, col0, p.K);
   unsigned mb = 0;
+  if (DG) bl.setup(p, p.B, col0, p.K);
+  // Forward: a lean weight stream instead of the generic loader.  Every non-MFMA instruction of the K step costs MFMA issue
+  // time (tools/micro/mfma_loop_model.hip: 64 full-rate VALU per step = 3.5 %), and the generic loader spent ~9 VALU + a
+  // readfirstlane per DMA slot on validity selects and address rebuilds.  Here a slot's row pointer is fixed per tile
+  // (rows beyond N are clamped to N - 1: they only feed output columns the epilogue never stores; K is a multiple of 32,
+  // so there is no K tail), the K offset of a step is one wave-uniform scalar added per slot, and the LDS destination is
+  // scalar arithmetic on the wave index.
+  constexpr int NSB = BN / 32;
+  const float* bsrc[DG ? 1 : NSB];
+  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  if (!DG) {
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) {
+      int n = col0 + (tid >> 3) + 32 * q;
+      n = n < p.N ? n : p.N - 1;
+      bsrc[q] = p.B + (long)n * p.ldb + KCSlots<BN>::kq4();
+    }
+  }
+  auto stream_b = [&](int q, int k0, float* tile) {          // slot q of the K step starting at k0 -> tile
+    glds16(bsrc[q] + k0, tile + (wv * 8 + 32 * q) * BK);
+  };
 
   f32x16 acc[TM][TN];
 #pragma unroll
@@ -1245,9 +1415,14 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   }
 
   // prologue: patch of the first chunk and the weights of step 0
-  bl.prep(c_begin * BK, mb);
+  if (DG) {
+    bl.prep(c_begin * BK, mb);
 #pragma unroll
-  for (int q = 0; q < BL::NS; ++q) glds16(bl.src(q), BL::dma_dst(btile0, q));
+    for (int q = 0; q < BL::NS; ++q) glds16(bl.src(q), BL::dma_dst(btile0, q));
+  } else {
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) stream_b(q, c_begin * BK, btile0);
+  }
 #pragma unroll
   for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + c_begin * BK, (pvalid >> i) & 1u));
   commit_patch();
@@ -1260,7 +1435,9 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     float* nb = btile0 + ((st + 1) & 1) * B_TILE;
     int ntap = tap + 1, nchunk = chunk;
     if (ntap == 9) { ntap = 0; ++nchunk; }
-    bl.prep(st + 1 < nsteps ? ntap * C + nchunk * BK : p.K, mb);     // past the end: zeros
+    const bool more = st + 1 < nsteps;
+    const int knext = ntap * C + nchunk * BK;
+    if (DG) bl.prep(more ? knext : p.K, mb);     // past the end: zeros (forward: nothing is staged after the last step)
     const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
 #pragma unroll
     for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform: one float4 of the next chunk's patch per tap
@@ -1281,7 +1458,11 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
-        if (g * 4 + s < BL::NS) glds16(bl.src(g * 4 + s), BL::dma_dst(nb, g * 4 + s));
+        if (DG) {
+          if (g * 4 + s < BL::NS) glds16(bl.src(g * 4 + s), BL::dma_dst(nb, g * 4 + s));
+        } else {
+          if (g * 4 + s < NSB && more) stream_b(g * 4 + s, knext, nb);
+        }
         if (s == 1 && g < 3) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(pa + abase[i] + 8 * (g + 1));
@@ -1682,7 +1863,9 @@ static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
   if (pl.bm == 128 && pl.bn == 64) {
     if constexpr (VEC == 4 && (((AM == GAD_A_KC || AM == GAD_A_MC) && (BMODE == GAD_B_KC || BMODE == GAD_B_MC) &&
                                 !(AM == GAD_A_MC && BMODE == GAD_B_KC)) ||
-                               (AM == A_KC2 && (BMODE == B_KC2 || BMODE == B_MC2))))
+                               (AM == A_KC2 && (BMODE == B_KC2 || BMODE == B_MC2)) ||
+                               (AM == A_KC_L && (BMODE == B_KC_L || BMODE == B_MC_L)) || (AM == A_MC_L && BMODE == B_MC_L) ||
+                               (AM == A_KC2_L && (BMODE == B_KC2_L || BMODE == B_MC2_L))))
       hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 64, VEC>), grid, block, 0, st, d);
   } else if (pl.bm == 128)
     hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC>), grid, block, 0, st, d);
@@ -2036,13 +2219,22 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
     else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);
   } else if (ksplit2) {
+    const bool lean = !bf16 && vec == 4 && a->K % BK == 0 && a->k_split % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS);
     if (bmode == GAD_B_KC) {
       if (bf16) launch_bf16<A_KC2, B_KC2>(d, pl, st);
+      else if (lean) launch_mode<A_KC2_L, B_KC2_L, 4>(d, pl, st);
       else launch_mode<A_KC2, B_KC2, 4>(d, pl, st);
     } else {
       if (bf16) launch_bf16<A_KC2, B_MC2>(d, pl, st);
+      else if (lean) launch_mode<A_KC2_L, B_MC2_L, 4>(d, pl, st);
       else launch_mode<A_KC2, B_MC2, 4>(d, pl, st);
     }
+  } else if (!bf16 && vec == 4 && a->K % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS) &&
+             ((am == GAD_A_KC && (bmode == GAD_B_KC || bmode == GAD_B_MC)) || (am == GAD_A_MC && bmode == GAD_B_MC))) {
+    // dense operands without a K tail: the lean loaders (row clamp instead of masks, one add per DMA slot and step)
+    if (am == GAD_A_KC && bmode == GAD_B_KC) launch_mode<A_KC_L, B_KC_L, 4>(d, pl, st);
+    else if (am == GAD_A_KC) launch_mode<A_KC_L, B_MC_L, 4>(d, pl, st);
+    else launch_mode<A_MC_L, B_MC_L, 4>(d, pl, st);
   } else
 #define GAD_CASE(AMODE, BMODE_)                                                        \
   if (am == AMODE && bmode == BMODE_) {                                                \

@@ -66,7 +66,7 @@ class AdamArgs(C.Structure):
                 ("weight_decay", C.c_float), ("adamw", C.c_int32), ("step", C.c_int32), ("ema_decay", C.c_float)]
 
 
-GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GEMM_SCALAR_EPILOGUE, GN_TWO_PASS = 1, 2, 4, 1
+GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GEMM_SCALAR_EPILOGUE, GEMM_GENERAL_LOADERS, GN_TWO_PASS = 1, 2, 4, 8, 1
 A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
 B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 

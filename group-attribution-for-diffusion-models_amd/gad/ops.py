@@ -144,11 +144,12 @@ KERNEL_FLAGS = {"gemm": 0, "gn": 0}
 
 
 class kernel_flags:
-    """``with ops.kernel_flags(no_patch=True, tap_major_k=True, scalar_epilogue=True, gn_two_pass=True): ...``"""
+    """``with ops.kernel_flags(no_patch=True, tap_major_k=True, scalar_epilogue=True, general_loaders=True, gn_two_pass=True): ...``"""
 
-    def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False):
+    def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False):
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
-                     | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0))
+                     | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
+                     | (_capi.GEMM_GENERAL_LOADERS if general_loaders else 0))
         self.gn = _capi.GN_TWO_PASS if gn_two_pass else 0
 
     def __enter__(self):

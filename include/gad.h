@@ -115,7 +115,8 @@ typedef struct gad_gemm_args {
 enum gad_gemm_flags {
   GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
   GAD_GEMM_TAP_MAJOR_K = 2,   /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
-  GAD_GEMM_SCALAR_EPILOGUE = 4 /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */
+  GAD_GEMM_SCALAR_EPILOGUE = 4, /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */
+  GAD_GEMM_GENERAL_LOADERS = 8  /* dense operands with K % 32 == 0: the masking loaders instead of the lean (row-clamping) ones */
 };
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);

@@ -817,3 +817,49 @@ def test_frozen_weight_data_gradient_runs_as_forward_conv(ops, prec, B, Cin, Cou
     with gad.operand_precision(prec):
         ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), False).backward(dy)
     close(x.grad, 2.0 * want, rtol=tol, atol=tol)
+
+
+def test_lean_dense_loaders_are_bit_identical_to_the_masking_ones(ops):
+    """Dense GEMM operands with K % 32 == 0 take the lean loaders (rows beyond the tensor clamped instead of masked, one
+    add per DMA slot and K step; csrc/gemm_f32.hip LeanKC / LeanMC / LeanKC2 / LeanMC2); kernel_flags(general_loaders=True)
+    forces the masking loaders.  Same products in the same order: equal bit for bit - ragged M and N (last tiles partly
+    outside), all three layout pairs, split-K, batches, every tile shape, and the K-concatenated (LoRA) forms."""
+    from gad._capi import A_KC, A_MC, B_KC, B_MC
+
+    def both(fn):
+        outs = []
+        for flags in ({}, {"general_loaders": True}):
+            with ops.kernel_flags(**flags):
+                outs.append(fn().clone())
+        assert torch.equal(outs[0], outs[1])
+        return outs[0]
+
+    for (M, N, K, tile, sk) in ((1000, 100, 96, 0, 0), (777, 260, 160, 1, 0), (333, 68, 2048, 2, 4), (20000, 320, 320, 0, 0),
+                                (20000, 320, 320, 3, 0), (130, 132, 32, 0, 0)):
+        x, w = rnd(M, K, seed=1).to(dev), rnd(N, K, seed=2, scale=0.1).to(dev)
+        dy = rnd(M, N, seed=3).to(dev)
+        y, dx, dw = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev), torch.empty(N, K, device=dev)
+        got = both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K, K, K, N, tile_hint=tile, splitk_hint=sk), y)[1])
+        close(got, x.double() @ w.double().t(), rtol=3e-4, atol=3e-4)
+        got = both(lambda: (ops.gemm_raw(dy, w, dx, A_KC, B_MC, M, K, N, N, K, K, tile_hint=tile if N % 32 == 0 else 0), dx)[1])
+        close(got, dy.double() @ w.double(), rtol=3e-4, atol=3e-4)
+        if M % 32 == 0:
+            got = both(lambda: (ops.gemm_raw(dy, x, dw, A_MC, B_MC, N, K, M, N, K, K), dw)[1])
+            close(got, dy.double().t() @ x.double(), rtol=3e-4, atol=3e-4)
+    # batched, with strides
+    Bt, M, N, K = 6, 200, 72, 64
+    x, w = rnd(Bt, M, K, seed=7).to(dev), rnd(Bt, N, K, seed=8, scale=0.1).to(dev)
+    y = torch.empty(Bt, M, N, device=dev)
+    got = both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K, K, K, N, batch=Bt, sA=(M * K, 0), sB=(N * K, 0),
+                                     sC=(M * N, 0)), y)[1])
+    close(got, torch.einsum("bmk,bnk->bmn", x.double(), w.double()), rtol=3e-4, atol=3e-4)
+    # K-concatenated forms (fused LoRA): forward [x | mid] . [W | U]^T and data gradient [dy | dmid] . [W ; D]
+    M, N, K, r = 4100, 320, 320, 64
+    x, mid = rnd(M, K, seed=1).to(dev), rnd(M, r, seed=2).to(dev)
+    w, up, down = rnd(N, K, seed=3, scale=0.1).to(dev), rnd(N, r, seed=4, scale=0.1).to(dev), rnd(r, K, seed=5, scale=0.1).to(dev)
+    dy, dmid = rnd(M, N, seed=6).to(dev), rnd(M, r, seed=7).to(dev)
+    y, dx = torch.empty(M, N, device=dev), torch.empty(M, K, device=dev)
+    got = both(lambda: (ops.gemm_raw(x, w, y, A_KC, B_KC, M, N, K + r, K, K, N, A_k2=mid, B_k2=up, k_split=K), y)[1])
+    close(got, x.double() @ w.double().t() + mid.double() @ up.double().t(), rtol=3e-4, atol=3e-4)
+    got = both(lambda: (ops.gemm_raw(dy, w, dx, A_KC, B_MC, M, K, N + r, N, K, K, A_k2=dmid, B_k2=down, k_split=N), dx)[1])
+    close(got, dy.double() @ w.double() + dmid.double() @ down.double(), rtol=3e-4, atol=3e-4)

@@ -82,6 +82,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
   const float* pa = lds + (lane & 31) * 36 + (lane >> 5) * 4 + wave * 1152;
   const float* pb = lds + 7424 + (lane & 31) * 32 + (lane >> 5) * 4;
   f32x4 fa[2], fb[2][4], stg[4];
+  int junk[4] = {lane, lane + 1, lane + 2, lane + 3};
   auto rd = [&](int buf, int ks, int grp) {
     fa[buf] = *reinterpret_cast<const f32x4*>(pa + 8 * grp);
 #pragma unroll
@@ -91,7 +92,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
   rd(0, 0, 0);
   for (int ks = 0; ks < ksteps; ++ks) {
     float* nb = lds + 7424 + ((ks + 1) & 1) * 4096;
-    if (PIPE != 2 && ks > 0) rd(0, ks, 0);
+    if (PIPE != 2 && ks > 0) rd(0, ks, 0);   // (PIPE >= 10 behaves as PIPE 1)
 #pragma unroll
     for (int grp = 0; grp < 4; ++grp) {
 #pragma unroll
@@ -110,6 +111,10 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
           if (grp < 3) rd((grp + 1) & 1, ks, grp + 1);
           else if (PIPE == 2) rd(0, ks + 1, 0);
         }
+        if (PIPE >= 10) {           // PIPE - 10 dependent-free integer VALU operations per MFMA quartet (x16 per K step)
+#pragma unroll
+          for (int u = 0; u < PIPE - 10; ++u) junk[u & 3] = (junk[u & 3] ^ lane) + u;
+        }
         __builtin_amdgcn_sched_barrier(0);
       }
     }
@@ -119,7 +124,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
   float sum = 0.f;
   for (int t = 0; t < 4; ++t)
     for (int e = 0; e < 16; ++e) sum += acc[t][e];
-  if (sum == 123.456f) out[0] = sum;
+  if (sum == 123.456f || junk[0] + junk[1] + junk[2] + junk[3] == 12345) out[0] = sum;
 }
 
 template <int PIPE, bool B, bool D>
@@ -233,6 +238,9 @@ int main(int argc, char** argv) {
   runp<2, true, true>("  ... + DMA", out, src, ksteps, cus);
   runp<3, true, true>("real-kernel structure, DMA never waited for (timing only)", out, src, ksteps, cus);
   runp<5, true, true>("real-kernel structure, weights staged through registers + ds_write", out, src, ksteps, cus);
+  runp<12, true, true>("real-kernel structure + 32 x 2 full-rate integer VALU (xor, add) per K step", out, src, ksteps, cus);
+  runp<16, true, true>("real-kernel structure + 96 x 2 full-rate VALU per K step", out, src, ksteps, cus);
+  runp<22, true, true>("real-kernel structure + 192 x 2 full-rate VALU per K step", out, src, ksteps, cus);
   runw<true, false>("256-pixel tile (64 x 128 per wave): reads + barrier", out, src, ksteps / 2, cus);
   runw<true, true>("256-pixel tile: reads + barrier + DMA", out, src, ksteps / 2, cus);
   return 0;
