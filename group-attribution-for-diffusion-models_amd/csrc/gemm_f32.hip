@@ -1966,10 +1966,43 @@ static int wgrad_patch_splits(const gad_gemm_args* a) {
   return (int)sp;
 }
 
-extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) { return (a && use_bf16(a)) ? 1 : 0; }
+// 1x1 / stride 1 / pad 0 convolutions (ResNet shortcuts, attention projections of the LDM / SD blocks written as convs) are
+// dense GEMMs over the pixel rows - and a two-source one (the shortcut of an up block reading cat([h, skip])) is the
+// K-concatenated dense form.  Running them on the dense lean loaders instead of the im2col gather drops the per-slot
+// coordinate arithmetic from the K loop; same products in the same order (bit-identical).
+static bool as_dense_1x1(const gad_gemm_args* a, gad_gemm_args* out) {
+  if (!a || (a->flags & GAD_GEMM_GENERAL_LOADERS)) return false;
+  const gad_conv_geom& g = a->g;
+  if (a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A_k2) return false;
+  if (g.KH != 1 || g.KW != 1 || g.stride != 1 || g.pad_t != 0 || g.pad_l != 0 || g.upsample || g.Ho != g.H || g.Wo != g.W) return false;
+  if (a->K != g.C || a->K % 4 != 0 || g.ldx % 4 != 0 || a->batch > 1) return false;
+  if (a->A2) {
+    if (a->a_split <= 0 || a->a_split >= g.C || a->a_split % 32 != 0 || (g.C - a->a_split) % 4 != 0 || g.ldx < a->a_split ||
+        a->ldx2 < g.C - a->a_split || a->ldx2 % 4 != 0 || !gad_aligned16(a->A2))
+      return false;
+  } else if (g.ldx < g.C) return false;
+  *out = *a;
+  out->a_mode = GAD_A_KC;
+  out->lda = g.ldx;
+  if (a->A2) {
+    out->A_k2 = a->A2; out->lda_k2 = a->ldx2;
+    out->B_k2 = a->B + a->a_split; out->ldb_k2 = a->ldb;
+    out->k_split = a->a_split;
+    out->A2 = nullptr; out->a_split = 0;
+  }
+  return true;
+}
+#define GAD_CANON(a) gad_gemm_args canon_; if (as_dense_1x1((a), &canon_)) (a) = &canon_
+
+extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
+  if (!a) return 0;
+  GAD_CANON(a);
+  return use_bf16(a) ? 1 : 0;
+}
 
 extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
+  GAD_CANON(a);
   if (use_fewout_conv(a)) return 4;
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
@@ -1980,6 +2013,7 @@ extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
 
 extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* splitk, int32_t* vec) {
   GAD_CHECK(a && tile && splitk && vec, "gad_gemm_plan: null pointer");
+  GAD_CANON(a);
   *vec = pick_vec(a);
   PatchPlan pp;
   if (use_fewout_conv(a)) {                      // vector-ALU kernel: 256 pixels x all (<= 4) output channels
@@ -2000,6 +2034,7 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
 }
 
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
+  GAD_CANON(a);
   if (use_fewout_conv(a)) return 0;
   if (int sp = wgrad_patch_splits(a)) return sp > 1 ? (int64_t)sp * a->M * a->N * (int64_t)sizeof(float) : 0;
   {
@@ -2014,6 +2049,7 @@ extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
 
 extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   GAD_CHECK(a && a->A && a->B && a->C, "gad_gemm: null pointer");
+  GAD_CANON(a);
   GAD_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gad_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
   const int am = a->a_mode, bmode = a->b_mode;
   const bool convA = am == GAD_A_CONV || am == GAD_A_CONVT;

@@ -863,3 +863,14 @@ def test_lean_dense_loaders_are_bit_identical_to_the_masking_ones(ops):
     close(got, x.double() @ w.double().t() + mid.double() @ up.double().t(), rtol=3e-4, atol=3e-4)
     got = both(lambda: (ops.gemm_raw(dy, w, dx, A_KC, B_MC, M, K, N + r, N, K, K, A_k2=dmid, B_k2=down, k_split=N), dx)[1])
     close(got, dy.double() @ w.double() + dmid.double() @ down.double(), rtol=3e-4, atol=3e-4)
+    # 1x1 / stride 1 / pad 0 convolutions run as dense GEMMs over the pixel rows (two sources: the K-concatenated form);
+    # with the flag they stay on the im2col gather - same products, same order
+    for (Bn, C1, C2, Cout, H) in ((20, 128, 0, 128, 32), (70, 256, 128, 256, 16), (9, 64, 32, 96, 8)):
+        x = rnd(Bn, H, H, C1, seed=1).to(dev)
+        x2 = rnd(Bn, H, H, C2, seed=2).to(dev) if C2 else None
+        w = rnd(Cout, C1 + C2, 1, 1, seed=3, scale=0.1).to(dev).contiguous(memory_format=torch.channels_last)
+        b = rnd(Cout, seed=4).to(dev)
+        got = both(lambda: ops.conv2d_fwd_raw(x, w, b, pad=(0, 0, 0, 0), x2=x2))
+        xin = x if x2 is None else torch.cat([x, x2], -1)
+        want = xin.double().reshape(-1, C1 + C2) @ w.double().reshape(Cout, -1).t() + b.double()
+        close(got.reshape(-1, Cout), want, rtol=3e-4, atol=3e-4)
