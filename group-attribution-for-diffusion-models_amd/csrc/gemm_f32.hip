@@ -1375,18 +1375,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     }
   };
 
-  BL bl;
-  unsigned mb = 0;
-  if (DG) bl.setup(p, p.B, col0, p.K);
-  // Forward: a lean weight stream instead of the generic loader.  Every non-MFMA instruction of the K step costs MFMA issue
+  // A lean weight stream instead of the generic loaders.  Every non-MFMA instruction of the K step costs MFMA issue
   // time (tools/micro/mfma_loop_model.hip: 64 full-rate VALU per step = 3.5 %), and the generic loader spent ~9 VALU + a
   // readfirstlane per DMA slot on validity selects and address rebuilds.  Here a slot's row pointer is fixed per tile
   // (rows beyond N are clamped to N - 1: they only feed output columns the epilogue never stores; K is a multiple of 32,
   // so there is no K tail), the K offset of a step is one wave-uniform scalar added per slot, and the LDS destination is
   // scalar arithmetic on the wave index.
-  constexpr int NSB = BN / 32;
-  const float* bsrc[DG ? 1 : NSB];
-  const int wv = __builtin_amdgcn_readfirstlane(tid >> 6);
+  // Data gradient: the weights W[co][tap][ci] stream as [k = co of the chunk][n = ci] rows of one tap: slot pointer =
+  // W + (co_local * 9) * Cin + ci quad (quads beyond Cin clamped), step offset = ((chunk * 32) * 9 + tap) * Cin.
+  constexpr int NSB = BL::NS;
+  const float* bsrc[NSB];
   if (!DG) {
 #pragma unroll
     for (int q = 0; q < NSB; ++q) {
@@ -1394,9 +1392,19 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
       n = n < p.N ? n : p.N - 1;
       bsrc[q] = p.B + (long)n * p.ldb + KCSlots<BN>::kq4();
     }
+  } else {
+    int c0 = col0 + MCSlots<BN>::rq4();
+    c0 = c0 < p.N ? c0 : p.N - 4;
+#pragma unroll
+    for (int q = 0; q < NSB; ++q) bsrc[q] = p.B + (long)MCSlots<BN>::krow(q) * 9 * p.N + c0;
   }
-  auto stream_b = [&](int q, int k0, float* tile) {          // slot q of the K step starting at k0 -> tile
-    glds16(bsrc[q] + k0, tile + (wv * 8 + 32 * q) * BK);
+  auto b_offset = [&](int tp, int ch) -> long {               // wave-uniform: where the K step (tap tp, chunk ch) starts
+    return DG ? ((long)ch * BK * 9 + tp) * p.N : (long)tp * C + ch * BK;
+  };
+  const int wv = wave_id();
+  auto stream_b = [&](int q, long off, float* tile) {         // slot q of the K step at offset off -> tile
+    float* dst = BL::KC ? tile + (wv * 8 + 32 * q) * BK : tile + (wv * (MCSlots<BN>::KSTEP / 4) + MCSlots<BN>::KSTEP * q) * BN;
+    glds16(DG ? bsrc[q] + off : bsrc[q] + (int)off, dst);
   };
 
   f32x16 acc[TM][TN];
@@ -1415,14 +1423,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
   }
 
   // prologue: patch of the first chunk and the weights of step 0
-  if (DG) {
-    bl.prep(c_begin * BK, mb);
 #pragma unroll
-    for (int q = 0; q < BL::NS; ++q) glds16(bl.src(q), BL::dma_dst(btile0, q));
-  } else {
-#pragma unroll
-    for (int q = 0; q < NSB; ++q) stream_b(q, c_begin * BK, btile0);
-  }
+  for (int q = 0; q < NSB; ++q) stream_b(q, b_offset(0, c_begin), btile0);
 #pragma unroll
   for (int i = 0; i < PSLOTS; ++i) rp[i] = ldg4(sel_src(p.A, (long)poff[i] + c_begin * BK, (pvalid >> i) & 1u));
   commit_patch();
@@ -1435,9 +1437,8 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
     float* nb = btile0 + ((st + 1) & 1) * B_TILE;
     int ntap = tap + 1, nchunk = chunk;
     if (ntap == 9) { ntap = 0; ++nchunk; }
-    const bool more = st + 1 < nsteps;
-    const int knext = ntap * C + nchunk * BK;
-    if (DG) bl.prep(more ? knext : p.K, mb);     // past the end: zeros (forward: nothing is staged after the last step)
+    const bool more = st + 1 < nsteps;           // nothing is staged after the last step
+    const long onext = b_offset(ntap, nchunk);
     const int cnext = chunk + 1 < c_end ? chunk + 1 : chunk;
 #pragma unroll
     for (int i = 0; i < PSLOTS; ++i)      // tap is workgroup-uniform: one float4 of the next chunk's patch per tap
@@ -1458,11 +1459,7 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 #pragma unroll
           for (int j = 0; j < TN; ++j)
             acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][s], fb[g & 1][j][s], acc[i][j], 0, 0, 0);
-        if (DG) {
-          if (g * 4 + s < BL::NS) glds16(bl.src(g * 4 + s), BL::dma_dst(nb, g * 4 + s));
-        } else {
-          if (g * 4 + s < NSB && more) stream_b(g * 4 + s, knext, nb);
-        }
+        if (g * 4 + s < NSB && more) stream_b(g * 4 + s, onext, nb);
         if (s == 1 && g < 3) {
 #pragma unroll
           for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = *reinterpret_cast<const f32x4*>(pa + abase[i] + 8 * (g + 1));
