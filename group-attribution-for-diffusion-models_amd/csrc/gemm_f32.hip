@@ -1526,9 +1526,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
 
-  AL al;
-  al.setup(p, p.A, row0, kend);
-  unsigned ma = 0;
   // patch slots: slot i covers patch pixel i*32 + tid/8, float4 tid%8
   int prow[PSL], pcol[PSL];
 #pragma unroll
@@ -1544,9 +1541,41 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     long off = ((long)(img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + ci0 + (tid & 7) * 4;
     return sel_src(p.B, off, ok);
   };
-  auto stage = [&](int piece, int k0, float* ta, float* tp) {
-    if (piece < AL::NS) glds16(al.src(piece), AL::dma_dst(ta, piece));
-    else if (piece < AL::NS + PSL) glds16(patch_src(piece - AL::NS, k0), tp + ((piece - AL::NS) * 32 + wave * 8) * BK);
+  // Lean staging (see LeanKC above: every VALU instruction of the K step costs MFMA issue time; the general form spent ~200
+  // per step here, most of it on k0 / HW and rem / W per patch slot).  dy: fixed slot pointers (co quads beyond M clamped)
+  // plus one wave-uniform k offset.  x: a K step is ROWS whole rows of ONE image, so (image, first row) advance as scalars
+  // from step to step and a slot's address is a per-slot constant plus one uniform row offset; only the halo test
+  // (row inside the image) is per slot and step.  The fused-upsample geometry keeps the general form.
+  const int wv = wave_id();
+  const float* aptr[AL::NS];
+  {
+    int c0 = row0 + MCSlots<BM>::rq4();
+    c0 = c0 < p.M ? c0 : p.M - 4;
+#pragma unroll
+    for (int i = 0; i < AL::NS; ++i) aptr[i] = p.A + (long)MCSlots<BM>::krow(i) * p.lda + c0;
+  }
+  int xoff[PSL];               // (prow * W + pcol) * ldx + ci0 + float4 column: the slot's offset from the step's row base
+  unsigned colok = 0;          // slot's column inside the image (and the slot exists)
+#pragma unroll
+  for (int i = 0; i < PSL; ++i) {
+    xoff[i] = prow[i] >= 0 ? (prow[i] * W + pcol[i]) * p.g.ldx + ci0 + (tid & 7) * 4 : 0;
+    colok |= (unsigned)(prow[i] >= 0 && pcol[i] >= 0 && pcol[i] < W) << i;
+  }
+  auto stage = [&](int piece, int k0, int img, int oh, float* ta, float* tp) {
+    if (piece < AL::NS) {
+      glds16(aptr[piece] + (long)k0 * p.lda, ta + (wv * (MCSlots<BM>::KSTEP / 4) + MCSlots<BM>::KSTEP * piece) * BM);
+    } else if (piece < AL::NS + PSL) {
+      const int i = piece - AL::NS;
+      float* dst = tp + (i * 32 + wv * 8) * BK;
+      if (ups) {
+        glds16(patch_src(i, k0), dst);
+      } else {
+        const int ih = oh - 1 + prow[i];
+        const bool ok = ((colok >> i) & 1u) && ih >= 0 && ih < p.g.Ho;
+        const long rowbase = ((long)img * p.g.H + (oh - 1)) * W * p.g.ldx;     // wave-uniform
+        glds16(sel_src(p.B, rowbase + xoff[i], ok), dst);
+      }
+    }
   };
 
   f32x16 acc[9];
@@ -1555,10 +1584,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
+  int img = (kt0 * BK) / HW, oh = ((kt0 * BK) - img * HW) / W;      // the first step's image and first row (scalars)
   if (nkt > 0) {
-    al.prep(kt0 * BK, ma);
 #pragma unroll
-    for (int q = 0; q < AL::NS + PSL; ++q) stage(q, kt0 * BK, lds, lds + A_TILE);
+    for (int q = 0; q < AL::NS + PSL; ++q) stage(q, kt0 * BK, img, oh, lds, lds + A_TILE);
   }
   barrier_after_dma();
 
@@ -1567,8 +1596,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     const float* la = lds + (kt & 1) * (A_TILE + PSIZE);
     const float* lp = la + A_TILE;
     float* na = lds + ((kt + 1) & 1) * (A_TILE + PSIZE);
-    const int knext = (kt + 1 < nkt) ? (kt0 + kt + 1) * BK : p.K;   // past the end: zeros
-    al.prep(knext, ma);
+    const bool more = kt + 1 < nkt;                                  // nothing is staged after the last step
+    const int knext = (kt0 + kt + 1) * BK;
+    int nimg = img, noh = oh + ROWS;
+    if (noh >= p.g.Ho) { noh = 0; ++nimg; }
     float fa[2], fb[2][9];
     auto load_frags = [&](int j, int buf) {
       const int q = 2 * j + h;
@@ -1584,8 +1615,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
 #pragma unroll
       for (int t = 0; t < 9; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[j & 1][t], acc[t], 0, 0, 0);
-      stage(j, knext, na, na + A_TILE);     // one DMA slot per pixel pair (AL::NS + PSL <= 16)
+      if (more) stage(j, knext, nimg, noh, na, na + A_TILE);     // one DMA slot per pixel pair (AL::NS + PSL <= 16)
     }
+    img = nimg;
+    oh = noh;
     barrier_after_dma();
   }
 
