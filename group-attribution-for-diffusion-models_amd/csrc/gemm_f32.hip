@@ -2285,20 +2285,26 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     if (bf16) launch_bf16<A_CONV2, GAD_B_KC>(d, pl, st);
     else launch_mode<A_CONV2, GAD_B_KC, 4>(d, pl, st);
   } else if (ksplit2) {
-    const bool lean = !bf16 && vec == 4 && a->K % BK == 0 && a->k_split % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS);
+    const bool lean = vec == 4 && a->K % BK == 0 && a->k_split % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS);
     if (bmode == GAD_B_KC) {
-      if (bf16) launch_bf16<A_KC2, B_KC2>(d, pl, st);
+      if (bf16 && lean) launch_bf16<A_KC2_L, B_KC2_L>(d, pl, st);
+      else if (bf16) launch_bf16<A_KC2, B_KC2>(d, pl, st);
       else if (lean) launch_mode<A_KC2_L, B_KC2_L, 4>(d, pl, st);
       else launch_mode<A_KC2, B_KC2, 4>(d, pl, st);
     } else {
-      if (bf16) launch_bf16<A_KC2, B_MC2>(d, pl, st);
+      if (bf16 && lean) launch_bf16<A_KC2_L, B_MC2_L>(d, pl, st);
+      else if (bf16) launch_bf16<A_KC2, B_MC2>(d, pl, st);
       else if (lean) launch_mode<A_KC2_L, B_MC2_L, 4>(d, pl, st);
       else launch_mode<A_KC2, B_MC2, 4>(d, pl, st);
     }
-  } else if (!bf16 && vec == 4 && a->K % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS) &&
+  } else if (vec == 4 && a->K % BK == 0 && !(a->flags & GAD_GEMM_GENERAL_LOADERS) &&
              ((am == GAD_A_KC && (bmode == GAD_B_KC || bmode == GAD_B_MC)) || (am == GAD_A_MC && bmode == GAD_B_MC))) {
-    // dense operands without a K tail: the lean loaders (row clamp instead of masks, one add per DMA slot and step)
-    if (am == GAD_A_KC && bmode == GAD_B_KC) launch_mode<A_KC_L, B_KC_L, 4>(d, pl, st);
+    // dense operands without a K tail: the lean loaders (row clamp instead of masks, one add per slot and step)
+    if (bf16) {
+      if (am == GAD_A_KC && bmode == GAD_B_KC) launch_bf16<A_KC_L, B_KC_L>(d, pl, st);
+      else if (am == GAD_A_KC) launch_bf16<A_KC_L, B_MC_L>(d, pl, st);
+      else launch_bf16<A_MC_L, B_MC_L>(d, pl, st);
+    } else if (am == GAD_A_KC && bmode == GAD_B_KC) launch_mode<A_KC_L, B_KC_L, 4>(d, pl, st);
     else if (am == GAD_A_KC) launch_mode<A_KC_L, B_MC_L, 4>(d, pl, st);
     else launch_mode<A_MC_L, B_MC_L, 4>(d, pl, st);
   } else

@@ -83,6 +83,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
   const float* pb = lds + 7424 + (lane & 31) * 32 + (lane >> 5) * 4;
   f32x4 fa[2], fb[2][4], stg[4];
   int junk[4] = {lane, lane + 1, lane + 2, lane + 3};
+  int ujunk[4] = {ksteps, ksteps + 1, ksteps + 2, ksteps + 3};
   auto rd = [&](int buf, int ks, int grp) {
     fa[buf] = *reinterpret_cast<const f32x4*>(pa + 8 * grp);
 #pragma unroll
@@ -111,7 +112,10 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
           if (grp < 3) rd((grp + 1) & 1, ks, grp + 1);
           else if (PIPE == 2) rd(0, ks + 1, 0);
         }
-        if (PIPE >= 10) {           // PIPE - 10 dependent-free integer VALU operations per MFMA quartet (x16 per K step)
+        if (PIPE >= 40) {           // PIPE - 40 scalar (wave-uniform) integer operations per MFMA quartet
+#pragma unroll
+          for (int u = 0; u < PIPE - 40; ++u) ujunk[u & 3] = (ujunk[u & 3] ^ ks) + u + grp;
+        } else if (PIPE >= 10) {    // PIPE - 10 dependent-free integer VALU operations per MFMA quartet (x16 per K step)
 #pragma unroll
           for (int u = 0; u < PIPE - 10; ++u) junk[u & 3] = (junk[u & 3] ^ lane) + u;
         }
@@ -124,7 +128,7 @@ __global__ __launch_bounds__(256) void pipe_kernel(float* out, const float* src,
   float sum = 0.f;
   for (int t = 0; t < 4; ++t)
     for (int e = 0; e < 16; ++e) sum += acc[t][e];
-  if (sum == 123.456f || junk[0] + junk[1] + junk[2] + junk[3] == 12345) out[0] = sum;
+  if (sum == 123.456f || junk[0] + junk[1] + junk[2] + junk[3] == 12345 || ujunk[0] + ujunk[1] + ujunk[2] + ujunk[3] == 54321) out[0] = sum;
 }
 
 template <int PIPE, bool B, bool D>
@@ -241,6 +245,8 @@ int main(int argc, char** argv) {
   runp<12, true, true>("real-kernel structure + 32 x 2 full-rate integer VALU (xor, add) per K step", out, src, ksteps, cus);
   runp<16, true, true>("real-kernel structure + 96 x 2 full-rate VALU per K step", out, src, ksteps, cus);
   runp<22, true, true>("real-kernel structure + 192 x 2 full-rate VALU per K step", out, src, ksteps, cus);
+  runp<44, true, true>("real-kernel structure + 64 x 3 scalar integer ops per K step", out, src, ksteps, cus);
+  runp<48, true, true>("real-kernel structure + 128 x 3 scalar integer ops per K step", out, src, ksteps, cus);
   runw<true, false>("256-pixel tile (64 x 128 per wave): reads + barrier", out, src, ksteps / 2, cus);
   runw<true, true>("256-pixel tile: reads + barrier + DMA", out, src, ksteps / 2, cus);
   return 0;
