@@ -84,6 +84,47 @@ __device__ __forceinline__ void stage_tile(float* tile, const float* base, int l
   }
 }
 
+// Lean form of stage_tile for the K / V streams of a kernel's main loop (every vector-ALU instruction there costs MFMA issue
+// time, tools/micro/mfma_loop_model.hip; the general form spends ~12 per DMA piece on f / S, the validity test and a
+// 64-bit select against the zero block).  The piece -> (row, column) map of a lane is fixed for the workgroup: `plan`
+// keeps each piece's element offset (row * ld + column, or -1 for pad columns / the tail of the last piece, which stay on
+// the zero block); a tile whose rows are all inside T then needs one wave-uniform row offset per piece.  A ragged last
+// tile (Tk = 77) takes the general form.
+template <int D>
+struct TilePlan {
+  static constexpr int NP = (Cfg<D>::NPIECE + 3) / 4;
+  int off[NP];
+  __device__ __forceinline__ void init(int ld) {
+    using C = Cfg<D>;
+    const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63;
+#pragma unroll
+    for (int i = 0; i < NP; ++i) {
+      const int piece = wave + 4 * i;
+      const int f = (piece * 64 + lane) * 4;
+      const int row = f / C::S, col = f - row * C::S;
+      off[i] = (piece < C::NPIECE && row < KV && col < D) ? row * ld + col : -1;
+    }
+  }
+};
+template <int D>
+__device__ __forceinline__ void stage_tile_lean(float* tile, const float* base, int ld, int row0, int T, const TilePlan<D>& plan) {
+  using C = Cfg<D>;
+  if (row0 + KV > T) {             // ragged: rows past T must read zeros
+    stage_tile<D>(tile, base, ld, row0, T);
+    return;
+  }
+  const int wave = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  const float* rowbase = base + (long)row0 * ld;                 // wave-uniform
+#pragma unroll
+  for (int i = 0; i < TilePlan<D>::NP; ++i) {
+    const int piece = wave + 4 * i;
+    if (piece < C::NPIECE) {
+      const float* src = plan.off[i] >= 0 ? rowbase + plan.off[i] : (const float*)g_attn_zero;
+      glds16(src, tile + piece * 256);
+    }
+  }
+}
+
 // "row fragment": lanes along the tile's ROWS (lane l: row r0 + (l & 15), k slot g = l >> 4).  Step s = 4 grp + j uses
 // k = 16 grp + 4 g + j (float4 per group), the 8-wide tail k = 16 G16 + 2 g + j (float2).  The SAME k assignment is
 // used for both operands of a product, which is all a contraction needs.
@@ -136,6 +177,7 @@ __device__ __forceinline__ float xsum16_32(float v) {
 
 constexpr float LOG2E = 1.4426950408889634f;
 constexpr float NEG_BIG = -1.0e30f;
+constexpr float RESCALE_SLACK = 8.f;     // exp2 domain: the running reference may lag the running max by up to 8 (x256)
 
 // ------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = 64 NQ queries of one (b, h); wave w owns queries [q0 + 16 NQ w, + 16 NQ)
@@ -167,8 +209,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
   for (int t = 0; t < NQ; ++t) { m[t] = NEG_BIG; l[t] = 0.f; }
 
   const int ntiles = (p.Tk + KV - 1) / KV;
-  stage_tile<D>(lds, K, p.ldk, 0, p.Tk);
-  stage_tile<D>(lds + C::TILE, V, p.ldv, 0, p.Tk);
+  TilePlan<D> kplan, vplan;
+  kplan.init(p.ldk);
+  vplan.init(p.ldv);
+  stage_tile_lean<D>(lds, K, p.ldk, 0, p.Tk, kplan);
+  stage_tile_lean<D>(lds + C::TILE, V, p.ldv, 0, p.Tk, vplan);
   barrier_after_dma();
 
   for (int it = 0; it < ntiles; ++it) {
@@ -176,8 +221,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
     const float* vt_ = kt_ + C::TILE;
     if (it + 1 < ntiles) {            // the other buffer was last read before the barrier that ended iteration it-1
       float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk);
-      stage_tile<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk);
+      stage_tile_lean<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk, kplan);
+      stage_tile_lean<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, vplan);
     }
     // S^T[key][q] (exp2 domain), two key tiles of 16
     f32x4 s[2][NQ];
@@ -201,27 +246,34 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
 #pragma unroll
             for (int t = 0; t < NQ; ++t) s[kt][t][e] = -__builtin_inff();
     }
-    // online softmax; query = lane & 15 -> running max / sum / rescale factor are per-lane scalars
+    // online softmax; query = lane & 15 -> running reference / sum / rescale factor are per-lane scalars.  The reference
+    // m[t] is moved (and the accumulators rescaled - NDV accumulator tiles through the vector ALUs) only when some query
+    // of the wave has a score more than RESCALE_SLACK above it: probabilities are then at most 2^RESCALE_SLACK instead of
+    // 1, which fp32 carries without loss, and the softmax is the same function of the scores (LSE = m + log2 l as before).
 #pragma unroll
     for (int t = 0; t < NQ; ++t) {
       float mx = fmaxf(fmaxf(fmaxf(s[0][t][0], s[0][t][1]), fmaxf(s[0][t][2], s[0][t][3])),
                        fmaxf(fmaxf(s[1][t][0], s[1][t][1]), fmaxf(s[1][t][2], s[1][t][3])));
       mx = xmax16_32(mx);
-      const float mn = fmaxf(m[t], mx);
-      const float alpha = ex2(m[t] - mn);
-      m[t] = mn;
+      if (__builtin_amdgcn_ballot_w64(mx > m[t] + RESCALE_SLACK) != 0) {      // wave-uniform
+        const float mn = fmaxf(m[t], mx);
+        const float alpha = ex2(m[t] - mn);
+        m[t] = mn;
+        l[t] *= alpha;
+#pragma unroll
+        for (int i = 0; i < C::NDV; ++i) o[i][t] *= alpha;
+      }
+      const float mr = m[t];
       float ps = 0.f;
 #pragma unroll
       for (int kt = 0; kt < 2; ++kt)
 #pragma unroll
         for (int e = 0; e < 4; ++e) {
-          const float pe = ex2(s[kt][t][e] - mn);
+          const float pe = ex2(s[kt][t][e] - mr);
           s[kt][t][e] = pe;
           ps += pe;
         }
-      l[t] = l[t] * alpha + ps;       // per-lane partial sum (its 8 keys); the 4 partials of a query meet in the epilogue
-#pragma unroll
-      for (int i = 0; i < C::NDV; ++i) o[i][t] *= alpha;
+      l[t] += ps;                     // per-lane partial sum (its 8 keys); the 4 partials of a query meet in the epilogue
     }
     // O^T[dv][q] += V^T[dv][key] P^T[key][q]: B operand = the probability registers as they stand
 #pragma unroll
@@ -300,16 +352,19 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
   for (int i = 0; i < C::NDV; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
 
   const int ntiles = (p.Tk + KV - 1) / KV;
-  stage_tile<D>(lds, K, p.ldk, 0, p.Tk);
-  stage_tile<D>(lds + C::TILE, V, p.ldv, 0, p.Tk);
+  TilePlan<D> kplan, vplan;
+  kplan.init(p.ldk);
+  vplan.init(p.ldv);
+  stage_tile_lean<D>(lds, K, p.ldk, 0, p.Tk, kplan);
+  stage_tile_lean<D>(lds + C::TILE, V, p.ldv, 0, p.Tk, vplan);
   barrier_after_dma();
   for (int it = 0; it < ntiles; ++it) {
     const float* kt_ = lds + (it & 1) * (2 * C::TILE);
     const float* vt_ = kt_ + C::TILE;
     if (it + 1 < ntiles) {
       float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk);
-      stage_tile<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk);
+      stage_tile_lean<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk, kplan);
+      stage_tile_lean<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, vplan);
     }
     f32x4 ds[2];
 #pragma unroll
@@ -378,16 +433,19 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   const float* dlt = p.delta + (long)bh * p.Tq;
 
   const int ntiles = (p.Tq + KV - 1) / KV;
-  stage_tile<D>(lds, Q, p.ldq, 0, p.Tq);
-  stage_tile<D>(lds + C::TILE, DO, p.lddo, 0, p.Tq);
+  TilePlan<D> qplan, doplan;
+  qplan.init(p.ldq);
+  doplan.init(p.lddo);
+  stage_tile_lean<D>(lds, Q, p.ldq, 0, p.Tq, qplan);
+  stage_tile_lean<D>(lds + C::TILE, DO, p.lddo, 0, p.Tq, doplan);
   barrier_after_dma();
   for (int it = 0; it < ntiles; ++it) {
     const float* qt_ = lds + (it & 1) * (2 * C::TILE);
     const float* dot_ = qt_ + C::TILE;
     if (it + 1 < ntiles) {
       float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile<D>(nb, Q, p.ldq, (it + 1) * KV, p.Tq);
-      stage_tile<D>(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq);
+      stage_tile_lean<D>(nb, Q, p.ldq, (it + 1) * KV, p.Tq, qplan);
+      stage_tile_lean<D>(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq, doplan);
     }
     f32x4 pr[2], ds[2];
 #pragma unroll
