@@ -171,7 +171,22 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
 // sum of squares), LDS tree reductions in a fixed order (deterministic), then normalise + SiLU from registers.
 struct SlabGeo {
   int HW, C, G, cpg, SC, qpr, PL, P2, nslab, gps, qpg;   // qpr quads per slab row, PL pixel lanes, P2 = pow2 >= PL
+  int xgrp;   // slab rows are not whole 128-B lines: the slabs of one image go to ONE XCD (block ids 8 apart), so the
+              // lines two neighbouring slabs share are fetched from HBM once and found in that XCD's L2 by the second
 };
+// block id -> (image, slab).  Hardware deals consecutive block ids round-robin to the 8 XCDs.
+__device__ __forceinline__ void slab_of_block(const SlabGeo& s, int& b, int& sl) {
+  const int bid = blockIdx.x;
+  if (s.xgrp) {                        // B % 8 == 0 (host): image b = 8 b' + x owns block ids (b' nslab + j) 8 + x
+    const int x = bid & 7, r = bid >> 3;
+    const int bp = r / s.nslab;
+    sl = r - bp * s.nslab;
+    b = bp * 8 + x;
+  } else {
+    b = bid / s.nslab;
+    sl = bid - b * s.nslab;
+  }
+}
 
 // sum over the pixel lanes of each quad; result for quad q in red[q]
 __device__ __forceinline__ void slab_reduce(float* red, float val, const SlabGeo& s, int pl, bool act) {
@@ -183,17 +198,33 @@ __device__ __forceinline__ void slab_reduce(float* red, float val, const SlabGeo
   __syncthreads();
 }
 
+// the same over float4 (per-channel sums); result for quad q in red[q]
+template <int NTH>
+__device__ __forceinline__ void slab_reduce4(f32x4* red, f32x4 val, const SlabGeo& s, int pl, bool act) {
+  red[threadIdx.x] = val;
+  for (int st = s.P2 >> 1; st >= 1; st >>= 1) {
+    __syncthreads();
+    if (act && pl < st && pl + st < s.PL) red[threadIdx.x] += red[threadIdx.x + st * s.qpr];
+  }
+  __syncthreads();
+}
+
 // x2 != nullptr: channels [C1, C) of the (virtual) concatenation live in x2 ([B][HW][C-C1]); the source is chosen per
 // channel quad (C1 % 4 == 0), so a slab may straddle the split
-template <int NV>
+// PERCH = true: channels per group not a multiple of 4 (pruned widths 3 / 6 / 9, CelebA 7 ..., SD 10 ...): a thread's
+// float4 may straddle two groups, so the pixel-lane reductions run PER CHANNEL (float4 wide) and a group's moments are
+// sums over its cpg channel entries; mean / rstd are then per-channel values of the thread's quad.
+template <int NV, bool PERCH = false>
 __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
                                                      float* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      SlabGeo s, float eps, int silu) {
-  __shared__ float red[NT];
+  __shared__ float red[PERCH ? 4 : NT];
+  __shared__ f32x4 red4[PERCH ? NT : 1];
   __shared__ float s_mean[64], s_rstd[64];
-  const int b = blockIdx.x / s.nslab, sl = blockIdx.x - b * s.nslab;
+  int b, sl;
+  slab_of_block(s, b, sl);
   const int tid = threadIdx.x;
   const int pl = tid / s.qpr, q = tid - pl * s.qpr;
   const bool act = pl < s.PL;
@@ -211,15 +242,26 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   f32x4 acc = {0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NV; ++i) acc += v[i];
-  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
   const float inv_n = 1.f / (float)((long)s.HW * s.cpg);
+  const float* chan = reinterpret_cast<const float*>(red4);     // PERCH: per-channel sums of the slab, channel c at [c]
+  int gi[4] = {0, 0, 0, 0};                                        // PERCH: group (within the slab) of each channel of the quad
+  if (PERCH) {
+#pragma unroll
+    for (int e = 0; e < 4; ++e) gi[e] = act ? (q * 4 + e) / s.cpg : 0;
+    slab_reduce4<NT>(red4, acc, s, pl, act);
+  } else {
+    slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  }
   if (tid < s.gps) {
     float S = 0.f;
-    for (int j = 0; j < s.qpg; ++j) S += red[tid * s.qpg + j];
+    if (PERCH) for (int j = 0; j < s.cpg; ++j) S += chan[tid * s.cpg + j];
+    else for (int j = 0; j < s.qpg; ++j) S += red[tid * s.qpg + j];
     s_mean[tid] = S * inv_n;
   }
   __syncthreads();
-  const float mu = act ? s_mean[q / s.qpg] : 0.f;
+  f32x4 mu;
+  if (PERCH) mu = f32x4{s_mean[gi[0]], s_mean[gi[1]], s_mean[gi[2]], s_mean[gi[3]]};
+  else { const float m1 = act ? s_mean[q / s.qpg] : 0.f; mu = f32x4{m1, m1, m1, m1}; }
   acc = f32x4{0.f, 0.f, 0.f, 0.f};
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
@@ -227,10 +269,16 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
     f32x4 d = v[i] - mu;
     if (act && p < s.HW) acc += d * d;
   }
-  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  if (PERCH) {
+    __syncthreads();                       // every reader of the first reduction's sums is done
+    slab_reduce4<NT>(red4, acc, s, pl, act);
+  } else {
+    slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  }
   if (tid < s.gps) {
     float SS = 0.f;
-    for (int j = 0; j < s.qpg; ++j) SS += red[tid * s.qpg + j];
+    if (PERCH) for (int j = 0; j < s.cpg; ++j) SS += chan[tid * s.cpg + j];
+    else for (int j = 0; j < s.qpg; ++j) SS += red[tid * s.qpg + j];
     float rs = rsqrtf(SS * inv_n + eps);
     s_rstd[tid] = rs;
     mean_out[b * s.G + sl * s.gps + tid] = s_mean[tid];
@@ -238,7 +286,9 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   }
   __syncthreads();
   if (!act) return;
-  const float rs = s_rstd[q / s.qpg];
+  f32x4 rs;
+  if (PERCH) rs = f32x4{s_rstd[gi[0]], s_rstd[gi[1]], s_rstd[gi[2]], s_rstd[gi[3]]};
+  else { const float r1 = s_rstd[q / s.qpg]; rs = f32x4{r1, r1, r1, r1}; }
   f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
   f32x4 scale = ga * rs, shift = be - scale * mu;
 #pragma unroll
@@ -258,14 +308,16 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
 // pick the channel slab; returns NV (0 = no one-pass plan: odd channels-per-group or too many pixels)
 static int make_slab(const gad_groupnorm_args* a, SlabGeo* out, const int nth = NT, const int maxnv = 32) {
   const int cpg = a->C / a->G;
-  if (cpg % 4 != 0) return 0;
   SlabGeo best{};
   int best_nv = 0;
   long best_score = -1;
   for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
     int SC = k * cpg;
-    if (a->C % SC != 0) continue;
-    if ((SC * 4) % 128 != 0 && SC != a->C) continue;   // slab rows must be whole 128-B lines, or two workgroups fetch each line
+    if (a->C % SC != 0 || SC % 4 != 0) continue;       // whole groups, whole float4 quads
+    // slab rows should be whole 128-B lines, or two workgroups fetch each line; where no such slab fits the registers the
+    // slabs of an image are sent to one XCD instead (xgrp: needs B % 8 == 0) and share the line through its L2
+    const bool lines = (SC * 4) % 128 == 0 || SC == a->C;
+    if (!lines && a->B % 8 != 0) continue;
     int qpr = SC / 4;
     if (qpr > nth) break;
     int PL = nth / qpr;
@@ -273,13 +325,13 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out, const int nth = 
     if (nv > maxnv) continue;
     long blocks = (long)a->B * (a->C / SC);
     // enough workgroups for 256 CUs first, then the longest contiguous run per pixel
-    long score = (blocks >= 1024 ? (1L << 40) : blocks << 16) + SC;
+    long score = (blocks >= 1024 ? (1L << 40) : blocks << 16) + SC + (lines ? (1L << 41) : 0);   // whole-line plans first
     if (score > best_score) {
       best_score = score;
       best_nv = nv;
       int P2 = 1;
       while (P2 < PL) P2 <<= 1;
-      best = SlabGeo{a->HW, a->C, a->G, cpg, SC, qpr, PL, P2, a->C / SC, k, cpg / 4};
+      best = SlabGeo{a->HW, a->C, a->G, cpg, SC, qpr, PL, P2, a->C / SC, k, cpg / 4, lines ? 0 : 1};
     }
   }
   if (!best_nv) return 0;
@@ -301,16 +353,6 @@ __device__ __forceinline__ float act_grad(float dy, float z, int silu) {
 // 32 x 32 x 32-channel slab.  Per-channel sums A_c = sum g, Bx_c = sum g xhat are reduced over the pixel lanes by a fixed
 // LDS tree (float4 wide), written as the (image, channel) partials of dgamma / dbeta, combined per group with gamma, and
 // dx = rstd (g gamma - m1 - xhat m2) comes from the registers.
-template <int NTH>
-__device__ __forceinline__ void slab_reduce4(f32x4* red, f32x4 val, const SlabGeo& s, int pl, bool act) {
-  red[threadIdx.x] = val;
-  for (int st = s.P2 >> 1; st >= 1; st >>= 1) {
-    __syncthreads();
-    if (act && pl < st && pl + st < s.PL) red[threadIdx.x] += red[threadIdx.x + st * s.qpr];
-  }
-  __syncthreads();
-}
-
 template <int NV, int NTH>
 __global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                           float* __restrict__ dx, const float* __restrict__ gamma,
@@ -319,14 +361,21 @@ __global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restric
                                                           SlabGeo s, int silu) {
   __shared__ f32x4 red_a[NTH], red_b[NTH];
   __shared__ float s_m1[64], s_m2[64];
-  const int b = blockIdx.x / s.nslab, sl = blockIdx.x - b * s.nslab;
+  int b, sl;
+  slab_of_block(s, b, sl);
   const int tid = threadIdx.x;
   const int pl = tid / s.qpr, q = tid - pl * s.qpr;
   const bool act = pl < s.PL;
   const int c0 = sl * s.SC + (act ? q : 0) * 4;
   const long base = ((long)b * s.HW) * s.C + c0;
-  const int grp = sl * s.gps + (act ? q / s.qpg : 0);
-  const float mu = mean[b * s.G + grp], rs = rstd[b * s.G + grp];
+  int gi[4];                         // group (within the slab) of each channel of the quad: any channels-per-group
+  f32x4 mu, rs;
+#pragma unroll
+  for (int e = 0; e < 4; ++e) {
+    gi[e] = ((act ? q : 0) * 4 + e) / s.cpg;
+    mu[e] = mean[b * s.G + sl * s.gps + gi[e]];
+    rs[e] = rstd[b * s.G + sl * s.gps + gi[e]];
+  }
   const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
   f32x4 xh[NV], ge[NV];
   f32x4 sa = {0.f, 0.f, 0.f, 0.f}, sb = {0.f, 0.f, 0.f, 0.f};
@@ -357,27 +406,28 @@ __global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restric
   }
   if (tid < s.gps) {
     const float inv_n = 1.f / (float)((long)s.HW * s.cpg);
+    const float* ca = reinterpret_cast<const float*>(red_a);       // per-channel sums of the slab, channel c at [c]
+    const float* cb = reinterpret_cast<const float*>(red_b);
     float s1 = 0.f, s2 = 0.f;
-    for (int j = 0; j < s.qpg; ++j) {
-      const int qq = tid * s.qpg + j;
-      const f32x4 g4 = *reinterpret_cast<const f32x4*>(gamma + sl * s.SC + qq * 4);
-      const f32x4 A = red_a[qq], Bx = red_b[qq];
-#pragma unroll
-      for (int e = 0; e < 4; ++e) { s1 += A[e] * g4[e]; s2 += Bx[e] * g4[e]; }
+    for (int j = 0; j < s.cpg; ++j) {
+      const int c = tid * s.cpg + j;
+      const float gj = gamma[sl * s.SC + c];
+      s1 += ca[c] * gj;
+      s2 += cb[c] * gj;
     }
     s_m1[tid] = s1 * inv_n;
     s_m2[tid] = s2 * inv_n;
   }
   __syncthreads();
   if (!act) return;
-  const float m1 = s_m1[q / s.qpg], m2 = s_m2[q / s.qpg];
+  const f32x4 m1 = {s_m1[gi[0]], s_m1[gi[1]], s_m1[gi[2]], s_m1[gi[3]]}, m2 = {s_m2[gi[0]], s_m2[gi[1]], s_m2[gi[2]], s_m2[gi[3]]};
 #pragma unroll
   for (int i = 0; i < NV; ++i) {
     const int p = pl + i * s.PL;
     if (p < s.HW) {
       f32x4 o;
 #pragma unroll
-      for (int e = 0; e < 4; ++e) o[e] = rs * (ge[i][e] * ga[e] - m1 - xh[i][e] * m2);
+      for (int e = 0; e < 4; ++e) o[e] = rs[e] * (ge[i][e] * ga[e] - m1[e] - xh[i][e] * m2[e]);
       *reinterpret_cast<f32x4*>(dx + base + (long)p * s.C) = o;
     }
   }
@@ -536,12 +586,16 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
   if (nv) {
     const int c1 = a->x2 ? a->C1 : a->C;
     dim3 sgrid(a->B * sg.nslab), sblock(NT);
+    const bool perch = (a->C / a->G) % 4 != 0;
+#define GAD_GNF(NV_, P_) hipLaunchKernelGGL((gn_slab_kernel<NV_, P_>), sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, \
+                                            a->mean, a->rstd, sg, a->eps, a->silu)
     switch (nv) {
-      case 4: hipLaunchKernelGGL(gn_slab_kernel<4>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      case 8: hipLaunchKernelGGL(gn_slab_kernel<8>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      case 16: hipLaunchKernelGGL(gn_slab_kernel<16>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
-      default: hipLaunchKernelGGL(gn_slab_kernel<32>, sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu); break;
+      case 4: if (perch) GAD_GNF(4, true); else GAD_GNF(4, false); break;
+      case 8: if (perch) GAD_GNF(8, true); else GAD_GNF(8, false); break;
+      case 16: if (perch) GAD_GNF(16, true); else GAD_GNF(16, false); break;
+      default: if (perch) GAD_GNF(32, true); else GAD_GNF(32, false); break;
     }
+#undef GAD_GNF
     GAD_LAUNCH_CHECK("gn_slab");
     return 0;
   }

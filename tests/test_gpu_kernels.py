@@ -154,7 +154,13 @@ def test_conv_autograd_function(ops):
                                           (2, 512, 4, 32, True), (2, 224, 8, 32, False), (1, 896, 8, 32, True),
                                           (32, 128, 32, 32, True), (2, 1280, 8, 32, True), (1, 2560, 4, 32, True),
                                           (2, 384, 32, 32, True), (2, 96, 8, 32, True), (3, 256, 32, 32, False),
-                                          (2, 320, 64, 32, True)])
+                                          (2, 320, 64, 32, True),
+                                          # channels per group not a multiple of 4: the per-channel one-pass plan - pruned CIFAR
+                                          # widths (3, 6, 9 per group), CelebA (7), SD (10, 20); B % 8 == 0 lets slabs that are
+                                          # not whole 128-B lines go to one XCD per image
+                                          (8, 96, 32, 32, True), (16, 192, 16, 32, True), (8, 288, 16, 32, True),
+                                          (8, 288, 32, 32, True), (8, 224, 16, 32, False), (8, 320, 32, 32, True),
+                                          (8, 640, 16, 32, True), (3, 192, 8, 32, True), (8, 96, 16, 32, True)])
 @pytest.mark.parametrize("two_pass", [False, True])
 def test_groupnorm_fwd_bwd(ops, B, C, H, G, silu, two_pass):
     """Forward has two plans: one pass with the (image, channel slab) held in registers, or stats + apply passes
@@ -625,7 +631,8 @@ def test_conv_two_source_equals_concat(ops, C1, C2, H, k, prec):
 
 
 @pytest.mark.parametrize("B,C1,C2,H", [(3, 128, 128, 32), (2, 256, 256, 16), (2, 256, 256, 8), (2, 256, 256, 4), (2, 64, 64, 8),
-                                       (2, 256, 128, 16), (2, 128, 256, 8)])   # slabs of 96 channels straddle the split
+                                       (2, 256, 128, 16), (2, 128, 256, 8),    # slabs of 96 channels straddle the split
+                                       (8, 192, 96, 16), (8, 96, 96, 32), (8, 192, 192, 8)])   # pruned widths: 9 / 6 / 12 per group
 def test_groupnorm_two_source_equals_concat(ops, B, C1, C2, H):
     x, x2 = nhwc(rnd(B, C1, H, H, seed=1) + 0.5), nhwc(rnd(B, C2, H, H, seed=2) * 2)
     ga, be = (rnd(C1 + C2, seed=3) * 0.3 + 1).to(dev), rnd(C1 + C2, seed=4).to(dev)
