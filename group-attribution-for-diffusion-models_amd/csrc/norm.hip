@@ -317,7 +317,10 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out, const int nth = 
     // slab rows should be whole 128-B lines, or two workgroups fetch each line; where no such slab fits the registers the
     // slabs of an image are sent to one XCD instead (xgrp: needs B % 8 == 0) and share the line through its L2
     const bool lines = (SC * 4) % 128 == 0 || SC == a->C;
-    if (!lines && a->B % 8 != 0) continue;
+    // (only where the sharing can happen: a few slabs per image, and few enough workgroups that the slabs in flight on an
+    //  XCD fit its 4 MB L2 - measured: 4 slabs of 96 B at C = 96, B = 128: 31.9 -> 24.1 us; the same at B = 1024, or 16
+    //  slabs at C = 384: no better / slower than the two-pass plan, tools/gn_ab.py)
+    if (!lines && (a->B % 8 != 0 || a->C / SC > 8 || (long)a->B * (a->C / SC) > 1024)) continue;
     int qpr = SC / 4;
     if (qpr > nth) break;
     int PL = nth / qpr;

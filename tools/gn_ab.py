@@ -13,8 +13,8 @@ def timeit(fn, iters=20, warm=3):
     for _ in range(iters): fn()
     e.record(); torch.cuda.synchronize()
     return s.elapsed_time(e) / iters * 1e-3
-for B in (512, 128):
-    for C, H in ((128, 32), (256, 32), (384, 32), (256, 16), (384, 16), (512, 16), (256, 8), (512, 8), (256, 4)):
+for B in (1024, 128):
+    for C, H in ((128, 32), (256, 32), (384, 32), (256, 16), (384, 16), (512, 16), (256, 8), (512, 8), (256, 4), (96, 32), (192, 32), (288, 32), (192, 16), (288, 16)):
         x = torch.randn(B, H, H, C, device=dev); g = torch.randn(C, device=dev); b = torch.randn(C, device=dev)
         res = []
         ref = None
