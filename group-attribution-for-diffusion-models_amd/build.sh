@@ -10,7 +10,11 @@ pids=()
 for f in gemm_f32 attention norm elementwise optim transformer; do
   src="$HERE/csrc/$f.hip"; obj="$HERE/build/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/gad_common.h" -nt "$obj" ] || [ "$HERE/csrc/gad_reduce.h" -nt "$obj" ] || [ "$HERE/../include/gad.h" -nt "$obj" ]; then
-    $HIPCC $FLAGS -c "$src" -o "$obj" &
+    extra=""
+    # attention.hip: MFMA results feed the vector ALUs directly (softmax, dS), so keep them in VGPRs: with the default AGPR
+    # form hipcc moved every score / gradient tile through v_accvgpr_read / _write (50-150 instructions per K/V tile)
+    [ "$f" = attention ] && extra="-mllvm -amdgpu-mfma-vgpr-form=1"
+    $HIPCC $FLAGS $extra -c "$src" -o "$obj" &
     pids+=($!)
   fi
 done
