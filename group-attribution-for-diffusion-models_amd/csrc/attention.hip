@@ -382,11 +382,16 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
 #pragma unroll
         for (int st = 0; st < C::KS; ++st) dp = mfma16(vf[st], dof[st], dp);           // dP^T[key][q] = V dO^T
       }
+      if ((it + 1) * KV <= p.Tk) {        // whole tile inside Tk (wave-uniform): no key masks
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
-        const float pe = kok ? ex2(s[e] - L2) : 0.f;
-        ds[kt][e] = pe * (dp[e] - dl);
+        for (int e = 0; e < 4; ++e) ds[kt][e] = ex2(s[e] - L2) * (dp[e] - dl);
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
+          const float pe = kok ? ex2(s[e] - L2) : 0.f;
+          ds[kt][e] = pe * (dp[e] - dl);
+        }
       }
     }
 #pragma unroll
@@ -431,6 +436,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
   const float* lse = p.lse + (long)bh * p.Tq;
   const float* dlt = p.delta + (long)bh * p.Tq;
+  const bool vec_stats = p.Tq % 4 == 0 && (reinterpret_cast<uintptr_t>(p.lse) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.delta) & 15) == 0;
 
   const int ntiles = (p.Tq + KV - 1) / KV;
   TilePlan<D> qplan, doplan;
@@ -463,14 +469,26 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
 #pragma unroll
         for (int st = 0; st < C::KS; ++st) dp = mfma16(gf[st], vf[st], dp);            // dP[q][key] = dO V^T
       }
+      // the query of register e is row 4 g + e of the tile
+      if ((it + 1) * KV <= p.Tq && vec_stats) {     // whole tile inside Tq (wave-uniform): LSE / delta as one float4 each
+        const int q0 = it * KV + 16 * t + 4 * g;
+        const f32x4 L4 = *reinterpret_cast<const f32x4*>(lse + q0), d4 = *reinterpret_cast<const f32x4*>(dlt + q0);
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {       // the query of register e is row 4 g + e of the tile
-        const int qrow = it * KV + 16 * t + 4 * g + e;
-        const bool qok = qrow < p.Tq;
-        const float L2 = qok ? lse[qrow] : 0.f, dl = qok ? dlt[qrow] : 0.f;
-        const float pe = qok ? ex2(s[e] - L2) : 0.f;
-        pr[t][e] = pe;
-        ds[t][e] = pe * (dp[e] - dl);
+        for (int e = 0; e < 4; ++e) {
+          const float pe = ex2(s[e] - L4[e]);
+          pr[t][e] = pe;
+          ds[t][e] = pe * (dp[e] - d4[e]);
+        }
+      } else {
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const int qrow = it * KV + 16 * t + 4 * g + e;
+          const bool qok = qrow < p.Tq;
+          const float L2 = qok ? lse[qrow] : 0.f, dl = qok ? dlt[qrow] : 0.f;
+          const float pe = qok ? ex2(s[e] - L2) : 0.f;
+          pr[t][e] = pe;
+          ds[t][e] = pe * (dp[e] - dl);
+        }
       }
     }
 #pragma unroll
