@@ -331,25 +331,31 @@ __global__ void attn_delta_kernel(const AttnDev p, float* delta) {
 // ------------------------------------------------------------------------------------------------------------------
 // dQ: workgroup = 64 queries of one (b, h), wave w owns 16; streams K / V tiles
 // ------------------------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, int NQ = 1>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
+  // NQ query blocks of 16 per wave (workgroup = 64 NQ queries): a K / V fragment read from LDS, and every staged byte, feeds
+  // NQ times the MFMAs - at d = 40 one block per wave is 64 MFMAs against ~230 other instructions per tile
   using C = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
   const float* K = p.k + b * p.sk + h * D;
   const float* V = p.v + b * p.sv + h * D;
-  const int row = blockIdx.x * 64 + wave * 16 + c;
-  const bool rok = row < p.Tq;
-
-  float qf[C::KS], dof[C::KS];
-  row_frag_global<D>(p.q + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
-  row_frag_global<D>(p.d_o + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
-  const float L2 = rok ? p.lse[(long)bh * p.Tq + row] : 0.f;
-  const float dl = rok ? p.delta[(long)bh * p.Tq + row] : 0.f;
-  f32x4 dq[C::NDV];
+  int row[NQ];
+  bool rok[NQ];
+  float qf[NQ][C::KS], dof[NQ][C::KS], L2[NQ], dl[NQ];
+  f32x4 dq[NQ][C::NDV];
 #pragma unroll
-  for (int i = 0; i < C::NDV; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int t = 0; t < NQ; ++t) {
+    row[t] = blockIdx.x * (64 * NQ) + wave * (16 * NQ) + 16 * t + c;
+    rok[t] = row[t] < p.Tq;
+    row_frag_global<D>(p.q + b * p.sq + h * D, p.ldq, row[t], rok[t], p.scale * LOG2E, qf[t]);
+    row_frag_global<D>(p.d_o + b * p.sdo + h * D, p.lddo, row[t], rok[t], 1.f, dof[t]);
+    L2[t] = rok[t] ? p.lse[(long)bh * p.Tq + row[t]] : 0.f;
+    dl[t] = rok[t] ? p.delta[(long)bh * p.Tq + row[t]] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) dq[t][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   const int ntiles = (p.Tk + KV - 1) / KV;
   TilePlan<D> kplan, vplan;
@@ -366,32 +372,42 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
       stage_tile_lean<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk, kplan);
       stage_tile_lean<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, vplan);
     }
-    f32x4 ds[2];
+    f32x4 ds[2][NQ];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      f32x4 s[NQ], dp[NQ];
+#pragma unroll
+      for (int t = 0; t < NQ; ++t) { s[t] = f32x4{0.f, 0.f, 0.f, 0.f}; dp[t] = f32x4{0.f, 0.f, 0.f, 0.f}; }
       {
         float kf[C::KS];
         row_frag_lds<D>(kt_, 16 * kt, kf);
 #pragma unroll
-        for (int st = 0; st < C::KS; ++st) s = mfma16(kf[st], qf[st], s);              // S^T[key][q]
+        for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) s[t] = mfma16(kf[st], qf[t][st], s[t]);          // S^T[key][q]
       }
       {
         float vf[C::KS];
         row_frag_lds<D>(vt_, 16 * kt, vf);
 #pragma unroll
-        for (int st = 0; st < C::KS; ++st) dp = mfma16(vf[st], dof[st], dp);           // dP^T[key][q] = V dO^T
+        for (int st = 0; st < C::KS; ++st)
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) dp[t] = mfma16(vf[st], dof[t][st], dp[t]);       // dP^T[key][q] = V dO^T
       }
       if ((it + 1) * KV <= p.Tk) {        // whole tile inside Tk (wave-uniform): no key masks
 #pragma unroll
-        for (int e = 0; e < 4; ++e) ds[kt][e] = ex2(s[e] - L2) * (dp[e] - dl);
+        for (int t = 0; t < NQ; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) ds[kt][t][e] = ex2(s[t][e] - L2[t]) * (dp[t][e] - dl[t]);
       } else {
 #pragma unroll
-        for (int e = 0; e < 4; ++e) {
-          const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
-          const float pe = kok ? ex2(s[e] - L2) : 0.f;
-          ds[kt][e] = pe * (dp[e] - dl);
-        }
+        for (int t = 0; t < NQ; ++t)
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
+            const float pe = kok ? ex2(s[t][e] - L2[t]) : 0.f;
+            ds[kt][t][e] = pe * (dp[t][e] - dl[t]);
+          }
       }
     }
 #pragma unroll
@@ -400,18 +416,24 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
       for (int e = 0; e < 4; ++e) {
         const float* krow = kt_ + (16 * kt + 4 * g + e) * C::S + c;
 #pragma unroll
-        for (int i = 0; i < C::NDV; ++i) dq[i] = mfma16(krow[16 * i], ds[kt][e], dq[i]);   // dQ^T[k][q] += K^T dS^T
+        for (int i = 0; i < C::NDV; ++i) {
+          const float a = krow[16 * i];
+#pragma unroll
+          for (int t = 0; t < NQ; ++t) dq[t][i] = mfma16(a, ds[kt][t][e], dq[t][i]);   // dQ^T[k][q] += K^T dS^T
+        }
       }
     barrier_after_dma();
   }
-  if (rok) {
-    float* DQ = p.dq + b * p.sdq + h * D + (long)row * p.lddq;
 #pragma unroll
-    for (int i = 0; i < C::NDV; ++i) {
-      const int kk = 16 * i + 4 * g;
-      if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[i] * p.scale;
+  for (int t = 0; t < NQ; ++t)
+    if (rok[t]) {
+      float* DQ = p.dq + b * p.sdq + h * D + (long)row[t] * p.lddq;
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        const int kk = 16 * i + 4 * g;
+        if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[t][i] * p.scale;
+      }
     }
-  }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
@@ -970,10 +992,11 @@ static int launch_fwd_h(const AttnDev& d, hipStream_t st) {
 template <int D>
 static int launch_bwd(const AttnDev& d, float* delta, hipStream_t st) {
   const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
-  if (set_lds(attn_bwd_dq_f32_kernel<D>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_f32_kernel<D>, bytes, "gad_attention_bwd")) return 1;
+  constexpr int NQB = D <= 80 ? 2 : 1;      // query blocks per wave of the dQ kernel (registers allow two up to d = 80)
+  if (set_lds(attn_bwd_dq_f32_kernel<D, NQB>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_f32_kernel<D>, bytes, "gad_attention_bwd")) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
   hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
-  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tq, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D, NQB>), dim3((unsigned)gad_ceil_div(d.Tq, 64 * NQB), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
   hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
   return 0;
 }
