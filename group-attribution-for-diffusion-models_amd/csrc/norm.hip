@@ -214,14 +214,14 @@ __device__ __forceinline__ void slab_reduce4(f32x4* red, f32x4 val, const SlabGe
 // PERCH = true: channels per group not a multiple of 4 (pruned widths 3 / 6 / 9, CelebA 7 ..., SD 10 ...): a thread's
 // float4 may straddle two groups, so the pixel-lane reductions run PER CHANNEL (float4 wide) and a group's moments are
 // sums over its cpg channel entries; mean / rstd are then per-channel values of the thread's quad.
-template <int NV, bool PERCH = false>
-__global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
+template <int NV, bool PERCH = false, int NTH = NT>
+__global__ __launch_bounds__(NTH) void gn_slab_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
                                                      float* __restrict__ y,
                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
                                                      SlabGeo s, float eps, int silu) {
-  __shared__ float red[PERCH ? 4 : NT];
-  __shared__ f32x4 red4[PERCH ? NT : 1];
+  __shared__ float red[PERCH ? 4 : NTH];
+  __shared__ f32x4 red4[PERCH ? NTH : 1];
   __shared__ float s_mean[64], s_rstd[64];
   int b, sl;
   slab_of_block(s, b, sl);
@@ -248,7 +248,7 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   if (PERCH) {
 #pragma unroll
     for (int e = 0; e < 4; ++e) gi[e] = act ? (q * 4 + e) / s.cpg : 0;
-    slab_reduce4<NT>(red4, acc, s, pl, act);
+    slab_reduce4<NTH>(red4, acc, s, pl, act);
   } else {
     slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
   }
@@ -271,7 +271,7 @@ __global__ __launch_bounds__(NT) void gn_slab_kernel(const float* __restrict__ x
   }
   if (PERCH) {
     __syncthreads();                       // every reader of the first reduction's sums is done
-    slab_reduce4<NT>(red4, acc, s, pl, act);
+    slab_reduce4<NTH>(red4, acc, s, pl, act);
   } else {
     slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
   }
@@ -590,6 +590,17 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
     const int c1 = a->x2 ? a->C1 : a->C;
     dim3 sgrid(a->B * sg.nslab), sblock(NT);
     const bool perch = (a->C / a->G) % 4 != 0;
+    // 32 slots per thread (185 registers) leave room for two 4-wave workgroups per CU only: where a 512-thread x 16-slot
+    // plan covers the same slab (100 registers), more waves overlap their load / reduce / store phases - measured
+    // [1024, 32, 32, 128]: 243 -> 228 us (4.7 TB/s), [128, 32, 32, 256]: 54.8 -> 51.5 us (5.2 TB/s)
+    SlabGeo sgw;
+    if (nv == 32 && !perch && make_slab(a, &sgw, 512, 16) == 16 && sgw.SC == sg.SC) {
+      dim3 wgrid(a->B * sgw.nslab);
+      hipLaunchKernelGGL((gn_slab_kernel<16, false, 512>), wgrid, dim3(512), 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta,
+                         a->mean, a->rstd, sgw, a->eps, a->silu);
+      GAD_LAUNCH_CHECK("gn_slab(512)");
+      return 0;
+    }
 #define GAD_GNF(NV_, P_) hipLaunchKernelGGL((gn_slab_kernel<NV_, P_>), sgrid, sblock, 0, st, a->x, a->x2, c1, a->y, a->gamma, a->beta, \
                                             a->mean, a->rstd, sg, a->eps, a->silu)
     switch (nv) {
