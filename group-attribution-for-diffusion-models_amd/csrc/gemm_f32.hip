@@ -1939,22 +1939,13 @@ struct PatchPlan {
   int splitk, chunks_per_split, bn;
   long blocks;
 };
-// output-channel tile of the fp32 forward patch kernel: the one of {128, 160, 96} that pads N least (ties: the wider)
-static int patch_bn(int N) {
-  int best = 128;
-  long pad = gad_ceil_div(N, 128) * 128;
-  const int cand[2] = {160, 96};
-  for (int bn : cand) {
-    const long pd = gad_ceil_div(N, bn) * bn;
-    if (pd < pad) { pad = pd; best = bn; }
-  }
-  return best;
-}
-static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
-  if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true))) return false;
-  if (a->N < 64) return false;               // conv_out (3 output channels): a 128-wide tile would be 98 % padding
-  pp->bn = patch_conv_geom(a) ? patch_bn(a->N) : 128;
-  const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, pp->bn);
+// Plan of the fp32 patch kernels.  Forward: the output-channel tile is the one of {128, 160, 96} with the least modelled time =
+// rounds of 512 resident workgroups x K steps per workgroup x tile width - i.e. padding AND round quantisation count
+// (640 channels at 16x16, B = 64: five 128-wide tiles = 640 workgroups = two rounds, four 160-wide tiles = one round).
+// Small maps split K over the channel chunks until ~512 workgroups exist.
+static void patch_plan_for(const gad_gemm_args* a, int bn, PatchPlan* pp) {
+  pp->bn = bn;
+  const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, bn);
   const int nchunks = a->g.C / BK;
   long sk = 1;
   if (tiles < 384) {
@@ -1966,6 +1957,22 @@ static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
   pp->chunks_per_split = per;
   pp->splitk = (int)gad_ceil_div(nchunks, per);
   pp->blocks = tiles * pp->splitk;
+}
+static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
+  if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true))) return false;
+  if (a->N < 64) return false;               // conv_out (3 output channels): a 128-wide tile would be 98 % padding
+  patch_plan_for(a, 128, pp);
+  if (patch_conv_geom(a)) {                  // forward: three channel-tile widths (the data gradient streams 128 columns)
+    auto cost = [](const PatchPlan& q) { return (double)gad_ceil_div(q.blocks, 512) * q.chunks_per_split * q.bn; };
+    double best = cost(*pp);
+    const int cand[2] = {160, 96};
+    for (int bn : cand) {
+      PatchPlan q;
+      patch_plan_for(a, bn, &q);
+      const double c = cost(q);
+      if (c < best && q.blocks >= 192) { best = c; *pp = q; }
+    }
+  }
   return pp->blocks >= 192;
 }
 
