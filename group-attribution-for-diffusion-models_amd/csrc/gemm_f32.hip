@@ -1947,16 +1947,26 @@ static void patch_plan_for(const gad_gemm_args* a, int bn, PatchPlan* pp) {
   pp->bn = bn;
   const long tiles = gad_ceil_div(a->M, 128) * gad_ceil_div(a->N, bn);
   const int nchunks = a->g.C / BK;
-  long sk = 1;
-  if (tiles < 384) {
-    sk = gad_ceil_div(512, tiles);
-    if (sk > nchunks / 2) sk = nchunks / 2;      // >= 2 chunks (18 K steps) per workgroup
-    if (sk < 1) sk = 1;
+  pp->chunks_per_split = nchunks;
+  pp->splitk = 1;
+  pp->blocks = tiles;
+  if (tiles < 384) {           // split K: the split count just below or just above one round of workgroups, whichever is faster
+    double best = 1e30;
+    for (long sk0 = 512 / tiles; sk0 <= gad_ceil_div(512, tiles); ++sk0) {
+      long sk = sk0;
+      if (sk > nchunks / 2) sk = nchunks / 2;    // >= 2 chunks (18 K steps) per workgroup
+      if (sk < 1) sk = 1;
+      const int per = (int)gad_ceil_div(nchunks, sk);
+      const int ske = (int)gad_ceil_div(nchunks, per);
+      const double c = (double)gad_ceil_div(tiles * ske, 512) * per;
+      if (c < best) {
+        best = c;
+        pp->chunks_per_split = per;
+        pp->splitk = ske;
+        pp->blocks = tiles * ske;
+      }
+    }
   }
-  const int per = (int)gad_ceil_div(nchunks, sk);
-  pp->chunks_per_split = per;
-  pp->splitk = (int)gad_ceil_div(nchunks, per);
-  pp->blocks = tiles * pp->splitk;
 }
 static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
   if (use_bf16(a) || !(patch_conv_geom(a) || patch_conv_geom(a, true))) return false;
