@@ -3,7 +3,10 @@
 
     python bench.py --gpus N --steps K --warmup W            (N > 1: this process only launches the N ranks)
     python -m torch.distributed.run --nnodes=1 --nproc-per-node N ... bench.py --gpus N ...
-    python bench.py --workload cifar20-pruned | sd256 | sd512 [--precision bf16]     (separate, labelled lines)
+    python bench.py --workload cifar20-pruned | sd256 | sd512 | celeba | celeba-pruned [--precision bf16]   (one labelled line)
+With no --workload the line is the headline (cifar20) and, at N = 1, carries the other workloads of the path as
+`"secondary": {"cifar20-pruned": {...}, "sd512": {...}, "celeba": {...}, "celeba-pruned": {...}}`, each timed the same way
+(barrier-bracketed, HIP-event kernel brackets) with its own `roofline`; `--no-secondary` skips them.
 
 Workload (config.workload): one coalition of the reference's CIFAR-20 configuration =
 gd_steps=1000 fine-tuning steps at B=128 (noise, antithetic t, add_noise, U-Net fwd, MSE, bwd,
@@ -13,7 +16,10 @@ ONE BENCH STEP = 1/1000 of that coalition, in the coalition's own proportions:
     1 training step (B=128)  +  1 sampler step at B=1024 (= 32 reference batches x 32 images x 1 DDIM step).
 value = coalitions/hour summed over all ranks = K * world / 1000 / hours(max-over-ranks time of the K steps).
 The score tail (FID features + float64 Frechet, ~1 % of the FLOPs, once per coalition) is not part of a
-slice; `--full-coalition` runs one real, complete coalition (train -> EMA -> preview -> sample -> score) instead.
+slice; `--full-coalition` runs one real, complete coalition (train -> EMA -> preview -> sample -> score) instead - with
+the STAND-IN feature extractor (gad/scoring.py::FeatureNet, ~0.12 GFLOP/image): the reference's InceptionV3 (FID, IS) and
+VGG16 (P/R) passes over 10 240 images (fid_score.py:26-29, precision_recall.py:31,42-43; ~0.5 PFLOP = ~3 % of the
+17.6 PFLOP coalition) need URL-fetched weights and are NOT part of any number printed here (`config.score_tail`).
 Each rank works on its own coalition (removal_seed = rank); the only collective is the final all_gather of
 the per-rank records ("scaling": "weak").
 """
@@ -41,7 +47,12 @@ WORKLOADS = {
     "cifar20-pruned": dict(kind="cifar", widths=PRUNED_WIDTHS),
     "sd256": dict(kind="sd", latent=32, batch=64),
     "sd512": dict(kind="sd", latent=64, batch=16),
+    "celeba": dict(kind="ldm", pruned=False, batch=32),
+    "celeba-pruned": dict(kind="ldm", pruned=True, batch=32),
 }
+SECONDARY = ("cifar20-pruned", "sd512", "celeba", "celeba-pruned")     # timed after the headline by the default N = 1 run
+SCORE_TAIL = ("score tail outside the timed slice; --full-coalition runs it with the stand-in feature extractor - the "
+              "reference's InceptionV3 / VGG16 passes (~0.5 PFLOP, ~3 % of a 17.6 PFLOP coalition; URL-fetched weights) are not included")
 
 torch = None       # imported in main(): the launcher parent of `--gpus N` must not import it
 
@@ -55,10 +66,15 @@ def parse():
     ap.add_argument("--gpus", type=int, default=1)
     ap.add_argument("--steps", type=int, default=20)
     ap.add_argument("--warmup", type=int, default=3)
-    ap.add_argument("--workload", choices=list(WORKLOADS), default="cifar20",
+    ap.add_argument("--workload", choices=list(WORKLOADS), default=None,
                     help="cifar20 = BASELINE configs[1] (the headline); cifar20-pruned = the same cycle at the pruned widths "
                          "[96,192,192,192] that unlearn.py:363-367 actually fine-tunes; sd256 / sd512 = one SD-1.x LoRA (r=256) "
-                         "sFT training step at B=64 @ 32x32 / B=16 @ 64x64 latents (train_text_to_image_lora.py:1215-1311)")
+                         "sFT training step at B=64 @ 32x32 / B=16 @ 64x64 latents (train_text_to_image_lora.py:1215-1311); "
+                         "celeba / celeba-pruned = one CelebA-HQ LDM U-Net sFT training step at B=32 on 64x64 latents "
+                         "(ddpm_config.py:395-450), unpruned / head-grouped-pruned (prune.py:337-342).  Default: cifar20 + the "
+                         "others as `secondary` lines")
+    ap.add_argument("--no-secondary", action="store_true", help="headline only")
+    ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--widths", choices=["full", "pruned"], default=None, help="alias: --widths pruned = --workload cifar20-pruned")
     ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
@@ -77,6 +93,8 @@ def parse():
     a = ap.parse_args()
     if a.widths == "pruned":
         a.workload = "cifar20-pruned"
+    a.secondary = a.workload is None and not a.no_secondary and not a.full_coalition and not a.stub
+    a.workload = a.workload or "cifar20"
     return a
 
 
@@ -373,6 +391,202 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     return roof, table, all_fl
 
 
+class LDMRunner:
+    """One CelebA-HQ LDM U-Net sFT step per bench step (BASELINE configs[2]; unlearn.py:560-642 on `celeba_config`,
+    ddpm_config.py:395-450): B = 32 precomputed 3x64x64 VQ latents from the HBM-resident cache, noise, antithetic t,
+    add_noise, UNet2DModel [224, 448, 672, 896] (attention at 32x32 / 16x16 / 8x8, heads of dim 32) forward, MSE, backward,
+    clip 1.0, Adam, EMA.  `pruned`: the head-grouped magnitude-pruned network the sFT cycle actually fine-tunes
+    (prune.py:337-342 at ratio 0.3: widths [160, 320, 480, 640], the heads stay, head dim 32 -> 23)."""
+
+    def __init__(self, dev, pruned, batch, seed):
+        import gad
+        from gad.coalition import antithetic_timesteps, seed_everything
+        from src.ddpm_config import DDPMConfig
+        from unconditional_generation.prune import pruned_head_dim, pruned_width
+        seed_everything(seed)
+        cfg = DDPMConfig.celeba_config
+        ucfg = dict(cfg["unet_config"])
+        if pruned:
+            boc, hd, groups = list(ucfg["block_out_channels"]), ucfg["attention_head_dim"], ucfg["norm_num_groups"]
+            ucfg["attention_layout"] = [[w // hd, pruned_head_dim(w, hd, 0.3)] for w in boc]
+            ucfg["block_out_channels"] = [pruned_width(w, 0.3, groups) for w in boc]
+        self.ucfg = ucfg
+        with torch.device(dev):
+            self.model = gad.UNet2DModel(**ucfg)
+        self.model.to(dev)
+        keys = ("beta_start", "beta_end", "beta_schedule", "num_train_timesteps")
+        sched = gad.DDPMScheduler(**{k: v for k, v in cfg["scheduler_config"].items() if k in keys})
+        self.trainer = gad.FusedTrainer(self.model, sched, gad.EMAModel(self.model.parameters()), lr=1e-4, max_grad_norm=1.0)
+        g = torch.Generator(device=dev).manual_seed(seed)
+        self.latents = torch.randn(8 * batch, 3, 64, 64, device=dev, generator=g)       # vqvae_output.pt stand-in, resident
+        self.batch, self.dev, self.pos, self.antithetic = batch, dev, 0, antithetic_timesteps
+        self.n_params = sum(p.numel() for p in self.model.parameters())
+
+    def slice(self):
+        x0 = self.latents[self.pos:self.pos + self.batch]
+        self.pos = (self.pos + self.batch) % self.latents.shape[0]
+        return self.trainer.step(x0, torch.randn_like(x0), self.antithetic(1000, self.batch, self.dev))
+
+
+def measure(a, name, steps, warmup, env, headline):
+    """Build workload `name`, run `warmup` untimed and `steps` timed steps (barrier + synchronize on both sides) and
+    return rank 0's line for it (None on the other ranks)."""
+    import torch.distributed as dist
+    import gad
+    from gad import ops
+    from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
+    rank, world, dev, backend = env["rank"], env["world"], env["dev"], env["backend"]
+    wl = WORKLOADS[name]
+    peak_tf = F32_MFMA_PEAK_TF if a.precision == "f32" else BF16_MFMA_PEAK_TF
+    log(f"rank {rank}/{world} on {dev}: workload {name}, building")
+    engine = None
+    if wl["kind"] == "cifar":
+        over = dict(block_out_channels=tuple(wl["widths"])) if wl["widths"] else None
+        engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
+                                 sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS, unet_overrides=over)
+        n_groups = engine.n_groups
+    else:
+        if a.full_coalition:
+            print("bench.py: --full-coalition is a CIFAR-workload option", file=sys.stderr)
+            sys.exit(2)
+        n_groups = 258 if wl["kind"] == "sd" else 50            # artists / celebrities (src/ddpm_config.py: DatasetStats)
+
+    def barrier():
+        if world > 1:
+            dist.barrier()
+        torch.cuda.synchronize(dev)
+
+    prof, dt_train, n_tr, run = None, 0.0, 0, None
+    if a.full_coalition:
+        for i in range(warmup):
+            engine.run_coalition(10_000 + rank)
+        barrier()
+        t0 = time.time()
+        recs = [engine.run_coalition(rank + world * i, verbose=(rank == 0)) for i in range(steps)]
+        barrier()
+        dt = time.time() - t0
+        units = steps * world                                           # coalitions
+    else:
+        if wl["kind"] == "cifar":
+            run = SliceRunner(engine, removal_seed=rank)
+        elif wl["kind"] == "sd":
+            run = SDRunner(dev, wl["latent"], wl["batch"], seed=rank)
+        else:
+            run = LDMRunner(dev, wl["pruned"], wl["batch"], seed=rank)
+        log("runner ready; warm-up")
+        for _ in range(warmup):
+            run.slice()
+        log("timed region")
+        barrier()
+        if not a.no_kernel_timing:
+            prof = ops.GemmProfiler()
+            ops.PROFILER = prof
+        t0 = time.time()
+        for _ in range(steps):
+            loss = run.slice()
+        barrier()
+        dt = time.time() - t0
+        log(f"timed region done: {dt:.2f}s for {steps} steps")
+        ops.PROFILER = None
+        if wl["kind"] == "cifar":
+            units = steps * world / float(GD_STEPS)
+            # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
+            n_tr = 0 if a.no_train_rate else 10
+            barrier()
+            t1 = time.time()
+            for _ in range(n_tr):
+                run.train_step()
+            barrier()
+            dt_train = time.time() - t1
+            n_rem = len(run.loader.x)
+        else:
+            units = steps * world                                       # training steps
+            n_rem = run.latents.shape[0]
+        recs = [CoalitionRecord(rank, n_rem, 0, float("nan"), float(loss.item()), dt, dt, steps, [])]
+    # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
+    ranks_seen = [0]
+    if world > 1:
+        cdev = dev if backend == "nccl" else torch.device("cpu")
+        packed = gather_records([r.pack(n_groups) for r in recs], CoalitionRecord.NSCALAR + n_groups, cdev)
+        assert len(packed) == world * len(recs)
+        ids = [torch.zeros(1, device=cdev, dtype=torch.int64) for _ in range(world)]
+        dist.all_gather(ids, torch.tensor([rank], device=cdev, dtype=torch.int64))     # device all_gather of the rank ids
+        ranks_seen = sorted(int(i.item()) for i in ids)
+        tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
+        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+        dt = float(tmax.item())
+        if n_tr:
+            tmax.fill_(dt_train)
+            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
+            dt_train = float(tmax.item())
+    if rank != 0:
+        return None
+
+    f32 = a.precision == "f32"
+    dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
+    par = {"coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
+    if wl["kind"] == "cifar":
+        widths = list(wl["widths"]) if wl["widths"] else [128, 256, 256, 256]
+        nparam = sum(p.numel() for p in run.model.parameters()) if not a.full_coalition else None
+        out = {"metric": "shapley_coalitions_per_hour", "value": units / (dt / 3600.0), "unit": "coalitions/hour"}
+        workload = (f"CIFAR-20 DDPM sFT coalition (BASELINE configs[1]{'' if not wl['widths'] else ', PRUNED widths - the shape unlearn.py:363-367 fine-tunes'}): "
+                    f"gd_steps=1000 @B=128 + 10240 samples x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel widths {widths}"
+                    + (f" {nparam / 1e6:.2f}M params" if nparam else "") + " fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; "
+                    + ("step = one complete coalition" if a.full_coalition else "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"))
+        config = {"workload": workload, "score_tail": SCORE_TAIL, **par}
+    elif wl["kind"] == "sd":
+        out = {"metric": "sd_lora_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
+        config = {"workload": (f"SD-1.x LoRA sFT training step (BASELINE configs[3]/[4] body, train_text_to_image_lora.py:1215-1311): "
+                               f"B={wl['batch']} x 4x{wl['latent']}x{wl['latent']} latents ({8 * wl['latent']}x{8 * wl['latent']} images), ctx [B,77,768], "
+                               f"UNet2DConditionModel {run.n_base / 1e6:.1f}M frozen + LoRA r=256 on 32 attentions ({run.n_lora / 1e6:.1f}M trainable), "
+                               f"AdamW + clip, fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; step = one training step"),
+                  "images_per_s": units * wl["batch"] / dt, **par}
+    else:
+        out = {"metric": "ldm_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
+        lay = run.ucfg.get("attention_layout")
+        config = {"workload": (f"CelebA-HQ LDM sFT training step (BASELINE configs[2] body, unlearn.py:560-642 on celeba_config): "
+                               f"B={wl['batch']} x 3x64x64 latents, UNet2DModel widths {list(run.ucfg['block_out_channels'])} "
+                               + (f"head-grouped-pruned (prune.py:337-342, ratio 0.3), attention [heads, dim] per level {lay}, " if lay
+                                  else f"attention heads of dim {run.ucfg['attention_head_dim']}, ")
+                               + f"{run.n_params / 1e6:.1f}M params, Adam + clip + EMA, fp32" + ("" if f32 else " storage, bf16 MFMA operands")
+                               + "; step = one training step"),
+                  "images_per_s": units * wl["batch"] / dt, **par}
+    out.update({"n_gpus": dist.get_world_size() if world > 1 else 1, "steps": steps, "warmup": warmup,
+                "ms_per_step": dt / steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
+                "dtype": dtype, "data": "synthetic", "config": config})
+    if world > 1:
+        out["rccl_ranks_seen"] = ranks_seen                       # from the collective, not from the flag
+        out["dist_backend"] = dist.get_backend()
+    # published reference figures (BASELINE.md §1, empirical_verification.ipynb:128,132): 3.27 coalitions per GPU-hour
+    # (fp32, pruned CIFAR model, unnamed GPU); 0.74 SD LoRA steps/s at B=64 @256^2 (fp16, RTX 6000) -> per-GPU ratios
+    if wl["kind"] == "cifar" and f32:
+        out["vs_baseline"] = out["value"] / world / 3.27
+    if name == "sd256" and not f32:
+        out["vs_baseline"] = out["value"] / world / 0.74
+    if wl["kind"] == "cifar" and (a.gd_steps != GD_STEPS or a.n_samples != N_SAMPLES):      # a reduced workload is not the metric
+        config["workload"] += f" -- OVERRIDDEN: gd_steps={a.gd_steps}, n_samples={a.n_samples} (not the BASELINE workload)"
+        out["vs_baseline"] = None
+    if prof is not None:
+        torch.cuda.synchronize(dev)
+        out["roofline"], out["contraction_kernels"], all_fl = kernel_report(prof, dt, peak_tf, a.precision, name)
+        out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs of every contraction / attention launch
+        out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
+    elif name == "cifar20" and not a.full_coalition:
+        fl = (3 * UNET_GFLOP_PER_IMG * TRAIN_B + UNET_GFLOP_PER_IMG * N_SAMPLES * DDIM_STEPS / GD_STEPS) * 1e9
+        out["unet_tflops_per_gpu"] = fl * steps / dt / 1e12
+        out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf
+    if n_tr:
+        out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
+                                         "ms_per_step": dt_train / n_tr * 1e3, "reference": 3.81,   # BASELINE.md: 3.81 steps/s, 1 GPU
+                                         "meaning": ("one model, one GPU" if world == 1 else
+                                                     f"{world} INDEPENDENT replicas (one coalition's model per GPU, no gradient "
+                                                     f"exchange), summed - not a data-parallel rate")}
+    if headline and world == 1 and not a.no_cpu_baseline:
+        out["cpu_baseline"] = cpu_baseline(engine) if wl["kind"] == "cifar" else cpu_baseline_sd(wl["latent"], wl["batch"]) \
+            if wl["kind"] == "sd" else None
+    return out
+
+
 def main():
     a = parse()
     if "WORLD_SIZE" not in os.environ and a.gpus > 1:
@@ -410,137 +624,24 @@ def main():
     torch.cuda.set_device(dev)
 
     import gad
-    from gad import ops
-    from gad.coalition import CoalitionEngine, CoalitionRecord, gather_records
-
-    wl = WORKLOADS[a.workload]
     gad.set_operand_precision(a.precision)
-    peak_tf = F32_MFMA_PEAK_TF if a.precision == "f32" else BF16_MFMA_PEAK_TF
-    log(f"rank {rank}/{world} on {dev}: workload {a.workload}, building")
-    engine = None
-    if wl["kind"] == "cifar":
-        over = dict(block_out_channels=tuple(wl["widths"])) if wl["widths"] else None
-        engine = CoalitionEngine("cifar100", device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
-                                 sample_batch=SAMPLE_B, fuse=FUSE, num_inference_steps=DDIM_STEPS, unet_overrides=over)
-        n_groups = engine.n_groups
-    else:
-        if a.full_coalition:
-            print("bench.py: --full-coalition is a CIFAR-workload option", file=sys.stderr)
-            sys.exit(2)
-        n_groups = 258                                                  # artists (src/ddpm_config.py: DatasetStats)
-
-    def barrier():
-        if world > 1:
-            dist.barrier()
-        torch.cuda.synchronize(dev)
-
-    prof, dt_train, n_tr = None, 0.0, 0
-    if a.full_coalition:
-        for i in range(a.warmup):
-            engine.run_coalition(10_000 + rank)
-        barrier()
-        t0 = time.time()
-        recs = [engine.run_coalition(rank + world * i, verbose=(rank == 0)) for i in range(a.steps)]
-        barrier()
-        dt = time.time() - t0
-        units = a.steps * world                                         # coalitions
-    else:
-        run = SliceRunner(engine, removal_seed=rank) if wl["kind"] == "cifar" else SDRunner(dev, wl["latent"], wl["batch"], seed=rank)
-        log("runner ready; warm-up")
-        for _ in range(a.warmup):
-            run.slice()
-        log("timed region")
-        barrier()
-        if not a.no_kernel_timing:
-            prof = ops.GemmProfiler()
-            ops.PROFILER = prof
-        t0 = time.time()
-        for _ in range(a.steps):
-            loss = run.slice()
-        barrier()
-        dt = time.time() - t0
-        log(f"timed region done: {dt:.2f}s for {a.steps} steps")
-        ops.PROFILER = None
-        if wl["kind"] == "cifar":
-            units = a.steps * world / float(GD_STEPS)
-            # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
-            n_tr = 0 if a.no_train_rate else 10
-            barrier()
-            t1 = time.time()
-            for _ in range(n_tr):
-                run.train_step()
-            barrier()
-            dt_train = time.time() - t1
-            n_rem = len(run.loader.x)
-        else:
-            units = a.steps * world                                     # LoRA training steps
-            n_rem = run.latents.shape[0]
-        recs = [CoalitionRecord(rank, n_rem, 0, float("nan"), float(loss.item()), dt, dt, a.steps, [])]
-    # the single data-path collective: per-coalition records to every rank (rank 0 would write the jsonl)
-    ranks_seen = [0]
-    if world > 1:
-        cdev = dev if backend == "nccl" else torch.device("cpu")
-        packed = gather_records([r.pack(n_groups) for r in recs], CoalitionRecord.NSCALAR + n_groups, cdev)
-        assert len(packed) == world * len(recs)
-        ids = [torch.zeros(1, device=cdev, dtype=torch.int64) for _ in range(world)]
-        dist.all_gather(ids, torch.tensor([rank], device=cdev, dtype=torch.int64))     # device all_gather of the rank ids
-        ranks_seen = sorted(int(i.item()) for i in ids)
-        tmax = torch.tensor([dt], device=cdev, dtype=torch.float64)
-        dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-        dt = float(tmax.item())
-        if n_tr:
-            tmax.fill_(dt_train)
-            dist.all_reduce(tmax, op=dist.ReduceOp.MAX)
-            dt_train = float(tmax.item())
-
+    env = dict(rank=rank, world=world, dev=dev, backend=backend)
+    out = measure(a, a.workload, a.steps, a.warmup, env, headline=True)
+    if a.secondary and world == 1:
+        # the other workloads of the path, timed the same way after the headline (N = 1 only: the N > 1 runs stay short)
+        import gc
+        out["secondary"] = {}
+        for name in SECONDARY:
+            gc.collect()
+            torch.cuda.empty_cache()
+            try:
+                sec = measure(a, name, a.secondary_steps, min(a.warmup, 2), env, headline=False)
+                sec.pop("contraction_kernels", None)                    # the per-instance table of the headline is enough
+                out["secondary"][name] = sec
+            except Exception as e:                                      # a secondary line never costs the headline
+                out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"secondary workload {name} failed: {type(e).__name__}: {e}")
     if rank == 0:
-        f32 = a.precision == "f32"
-        dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
-        if wl["kind"] == "cifar":
-            widths = list(wl["widths"]) if wl["widths"] else [128, 256, 256, 256]
-            nparam = sum(p.numel() for p in run.model.parameters()) if not a.full_coalition else None
-            out = {"metric": "shapley_coalitions_per_hour", "value": units / (dt / 3600.0), "unit": "coalitions/hour"}
-            workload = (f"CIFAR-20 DDPM sFT coalition (BASELINE configs[1]{'' if not wl['widths'] else ', PRUNED widths - the shape unlearn.py:363-367 fine-tunes'}): "
-                        f"gd_steps=1000 @B=128 + 10240 samples x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel widths {widths}"
-                        + (f" {nparam / 1e6:.2f}M params" if nparam else "") + " fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; "
-                        + ("step = one complete coalition" if a.full_coalition else "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"))
-            config = {"workload": workload, "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
-        else:
-            out = {"metric": "sd_lora_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
-            config = {"workload": (f"SD-1.x LoRA sFT training step (BASELINE configs[3]/[4] body, train_text_to_image_lora.py:1215-1311): "
-                                   f"B={wl['batch']} x 4x{wl['latent']}x{wl['latent']} latents ({8 * wl['latent']}x{8 * wl['latent']} images), ctx [B,77,768], "
-                                   f"UNet2DConditionModel {run.n_base / 1e6:.1f}M frozen + LoRA r=256 on 32 attentions ({run.n_lora / 1e6:.1f}M trainable), "
-                                   f"AdamW + clip, fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; step = one training step"),
-                      "images_per_s": units * wl["batch"] / dt, "coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
-        out.update({"n_gpus": dist.get_world_size() if world > 1 else 1, "steps": a.steps, "warmup": a.warmup,
-                    "ms_per_step": dt / a.steps * 1e3, "higher_is_better": True, "scaling": "weak", "vs_baseline": None,
-                    "dtype": dtype, "data": "synthetic", "config": config})
-        if world > 1:
-            out["rccl_ranks_seen"] = ranks_seen                       # from the collective, not from the flag
-            out["dist_backend"] = dist.get_backend()
-        # published reference figures (empirical_verification.ipynb:128,132): 3.27 coalitions per GPU-hour
-        # (fp32, pruned CIFAR model, unnamed GPU); 0.74 SD LoRA steps/s at B=64 @256^2 (fp16, RTX 6000) -> per-GPU ratios
-        if wl["kind"] == "cifar" and f32:
-            out["vs_baseline"] = out["value"] / world / 3.27
-        if a.workload == "sd256" and not f32:
-            out["vs_baseline"] = out["value"] / world / 0.74
-        if wl["kind"] == "cifar" and (a.gd_steps != GD_STEPS or a.n_samples != N_SAMPLES):      # a reduced workload is not the metric
-            config["workload"] += f" -- OVERRIDDEN: gd_steps={a.gd_steps}, n_samples={a.n_samples} (not the BASELINE workload)"
-            out["vs_baseline"] = None
-        if prof is not None:
-            torch.cuda.synchronize(dev)
-            out["roofline"], out["contraction_kernels"], all_fl = kernel_report(prof, dt, peak_tf, a.precision, a.workload)
-            out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs of every contraction / attention launch
-            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
-        elif a.workload == "cifar20" and not a.full_coalition:
-            fl = (3 * UNET_GFLOP_PER_IMG * TRAIN_B + UNET_GFLOP_PER_IMG * N_SAMPLES * DDIM_STEPS / GD_STEPS) * 1e9
-            out["unet_tflops_per_gpu"] = fl * a.steps / dt / 1e12
-            out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf
-        if n_tr:
-            out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
-                                             "ms_per_step": dt_train / n_tr * 1e3, "reference": 3.81}   # 3.81 steps/s, 1 GPU
-        if world == 1 and not a.no_cpu_baseline:
-            out["cpu_baseline"] = cpu_baseline(engine) if wl["kind"] == "cifar" else cpu_baseline_sd(wl["latent"], wl["batch"])
         print(json.dumps(out), flush=True)
     if world > 1:
         dist.destroy_process_group()

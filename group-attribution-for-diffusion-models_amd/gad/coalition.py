@@ -270,9 +270,9 @@ class CoalitionEngine:
         return rec
 
     def jsonl_row(self, rec: CoalitionRecord, extra: Optional[dict] = None) -> dict:
-        from .scoring import extractor_tag
         """Keys lds.py reads (lds.py:203-257): dataset, removal_dist, method, exp_name, removal_seed,
         remaining_idx, fid_value, gd_steps, total_steps_time, total_sampling_time."""
+        from .scoring import extractor_tag
         remaining_idx, removed_idx = self.coalition(rec.removal_seed)
         row = dict(dataset=self.dataset_name, method="gd", removal_dist="shapley", removal_seed=rec.removal_seed,
                    datamodel_alpha=None, exp_name=f"gd_shapley_seed_{rec.removal_seed}", gd_steps=self.gd_steps,
@@ -361,55 +361,77 @@ def finished_seeds(db_path: Optional[str]) -> set:
     return done
 
 
-def merge_shards(db_path: str, extra_rows: Sequence[dict] = ()) -> List[int]:
-    """Rank 0's consolidation: rows of `extra_rows` (records that arrived through the all_gather) and of every
-    rank shard that are not in the db yet are appended in seed order; then the shards are removed.  Returns the
-    seeds appended."""
+def merge_shards(db_path: str, extra_rows: Sequence[dict] = (), keep_ranks: Sequence[int] = ()) -> List[int]:
+    """Rank 0's consolidation: rows of every rank shard and of `extra_rows` (records that arrived through the
+    all_gather) that are not in the db yet are appended in seed order; then the shards are removed.  A row the owning
+    rank wrote itself (its shard) wins over one rebuilt from the gathered scalars.  A shard is renamed before it is read
+    (a writer that is still alive re-creates `<db>.rank<r>` and loses nothing); shards of `keep_ranks` - ranks that did
+    not reach the rendezvous and are not known to be dead - are read but left in place.  Returns the seeds appended."""
     have = {int(r["removal_seed"]) for r in _read_rows(db_path)}
-    new, keep = {}, set()
+    keep_paths = {_rank_shard(db_path, r) for r in keep_ranks}
+    new, consumed = {}, []
     for path in _shard_paths(db_path):
+        src = path
+        if path not in keep_paths:
+            src = f"{path}.merging{os.getpid()}"
+            os.rename(path, src)
         bad = []
-        for r in _read_rows(path, bad):
+        for r in _read_rows(src, bad):
             new.setdefault(int(r["removal_seed"]), r)
         if bad:                                            # never drop lines this function could not account for
-            keep.add(path)
-            print(f"[merge_shards] {path}: {len(bad)} unreadable line(s) left in place", flush=True)
-    for r in extra_rows:                                   # gathered records win: they are this run's data path
-        new[int(r["removal_seed"])] = r
+            print(f"[merge_shards] {path}: {len(bad)} unreadable line(s) kept in {src}", flush=True)
+        elif src != path:
+            consumed.append(src)
+    for r in extra_rows:
+        new.setdefault(int(r["removal_seed"]), r)
     seeds = sorted(s for s in new if s not in have)
     for s in seeds:
         _append_row(db_path, new[s])
-    for path in _shard_paths(db_path):
-        if path not in keep:
-            os.remove(path)
+    for src in consumed:
+        os.remove(src)
     return seeds
 
 
-def _wait_for_ranks(db_path: Optional[str], tag: str, timeout_s: float) -> List[int]:
-    """Rendezvous ahead of the final collective that cannot hang on a dead rank: every rank posts a key in the
-    process group's store; a rank the launcher has declared dead (tombstone file `<db>.rank<r>.dead`, written by
-    gad.launch when a child exits non-zero) is not waited for.  Returns the ranks that did NOT arrive (empty = all
-    alive, the collective is safe)."""
+def _rendezvous(db_path: Optional[str], tag: str, timeout_s: float):
+    """Rendezvous ahead of the final collective that cannot hang on a dead rank and cannot split the ranks: every rank
+    posts an arrival key in the process group's store; RANK 0 ALONE decides - it waits for every arrival, not waiting
+    for a rank the launcher has declared dead (tombstone `<db>.rank<r>.dead`, written by gad.launch when a child exits
+    non-zero) nor past `timeout_s` - and publishes the decision under `gad/<tag>/go` ("gather" or "skip:<missing ranks>");
+    every other rank polls that one key.  The store is polled with the non-blocking `check` (False = not there yet; an
+    exception = the store is gone, i.e. rank 0, which hosts it, died: skip the collective) and a sleep between polls.
+    Returns (gather: bool, missing ranks)."""
     import torch.distributed as dist
-    from datetime import timedelta
 
     rank, world = dist.get_rank(), dist.get_world_size()
     store = dist.distributed_c10d._get_default_store()
-    store.set(f"gad/{tag}/{rank}", "1")
-    missing = []
+
+    def dead(r):
+        return bool(db_path) and os.path.exists(f"{_rank_shard(db_path, r)}.dead")
+
     t0 = time.time()
-    for r in range(world):
-        key = f"gad/{tag}/{r}"
-        while True:
-            try:
-                store.wait([key], timedelta(seconds=0.5))
-                break
-            except Exception:                                  # not there yet (timeout) - dead, or still working?
-                dead = bool(db_path) and os.path.exists(f"{_rank_shard(db_path, r)}.dead")
-                if dead or time.time() - t0 > timeout_s:
-                    missing.append(r)
-                    break
-    return missing
+    try:
+        store.set(f"gad/{tag}/{rank}", "1")
+        if rank == 0:
+            missing = []
+            for r in range(1, world):
+                while not store.check([f"gad/{tag}/{r}"]):
+                    if dead(r) or time.time() - t0 > timeout_s:
+                        missing.append(r)
+                        break
+                    time.sleep(0.2)
+            store.set(f"gad/{tag}/go", "gather" if not missing else "skip:" + ",".join(map(str, missing)))
+            return not missing, missing
+        while not store.check([f"gad/{tag}/go"]):
+            if dead(0) or time.time() - t0 > 2 * timeout_s:         # rank 0 decides within timeout_s if it is alive
+                return False, [0]
+            time.sleep(0.2)
+        go = store.get(f"gad/{tag}/go").decode()
+    except (RuntimeError, OSError) as e:                            # DistStoreError / DistNetworkError: the store's host is gone
+        print(f"[rank {rank}] rendezvous store unreachable ({type(e).__name__}: {e}): skipping the collective", flush=True)
+        return False, [0]
+    if go == "gather":
+        return True, []
+    return False, [int(r) for r in go.split(":", 1)[1].split(",")]
 
 
 def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, verbose=False, retries: int = 1,
@@ -426,8 +448,9 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
       times after the rank's other seeds, with freshly built model / optimizer state (run_coalition builds them per
       call); what still fails is left for the next entry (a requeued launch);
     * the only data-path collective is one all_gather of the fixed-size records at the end, entered only when every
-      rank is known to have arrived (`_wait_for_ranks`); rank 0 then appends the rows to the db in seed order and
-      removes the shards.  If a rank is missing, the survivors skip the collective and rank 0 merges from the shards.
+      rank is known to have arrived - decided once, by rank 0, and published to all (`_rendezvous`); rank 0 then appends
+      the rows to the db in seed order and removes the shards.  If a rank is missing, every survivor skips the collective
+      and rank 0 merges from the shards (a missing rank that is not known to be dead keeps its shard).
     Returns the records every rank knows at the end (all of this run's when the gather ran, else its own)."""
     import traceback
     import torch.distributed as dist
@@ -461,13 +484,12 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
     n_extra = len(getattr(engine, "extra_keys", ()))
     width = CoalitionRecord.NSCALAR + n_extra + engine.n_groups
     packed = [r.pack(engine.n_groups, n_extra) for r in recs]
-    gathered = True
+    gathered, missing = True, []
     if dist_on:
-        timeout = rendezvous_timeout_s if rendezvous_timeout_s is not None else float(os.environ.get("GAD_SHARD_TIMEOUT", 24 * 3600))
+        timeout = rendezvous_timeout_s if rendezvous_timeout_s is not None else float(os.environ.get("GAD_SHARD_TIMEOUT", 2 * 3600))
         _RDV[0] += 1
-        missing = _wait_for_ranks(db_path, f"sharded{_RDV[0]}", timeout)
-        if missing:
-            gathered = False
+        gathered, missing = _rendezvous(db_path, f"sharded{_RDV[0]}", timeout)
+        if not gathered:
             print(f"[rank {rank}] ranks {missing} did not reach the final all_gather: merging from the rank shards",
                   flush=True)
         else:
@@ -478,7 +500,8 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
         # rows carry more than the record (entry-point cycles: per-image behaviours, args) answers None for coalitions it
         # did not run itself - those rows come from the owning rank's shard
         rows = [engine.jsonl_row(r) for r in all_recs] if (gathered and dist_on) else []
-        merge_shards(db_path, [r for r in rows if r is not None])
+        maybe_alive = [r for r in (missing if dist_on else []) if not os.path.exists(f"{_rank_shard(db_path, r)}.dead")]
+        merge_shards(db_path, [r for r in rows if r is not None], keep_ranks=maybe_alive)
     if failed and verbose:
         print(f"[rank {rank}] seeds still failing after {retries} retries: {failed}", flush=True)
     return all_recs

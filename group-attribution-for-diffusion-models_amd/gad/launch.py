@@ -43,10 +43,16 @@ def clear_tombstones(db_path: Optional[str], world: int):
 
 
 def spawn_workers(cmd: Sequence[str], nprocs: int, extra_env: Optional[Dict[str, str]] = None,
-                  db_path: Optional[str] = None, poll_s: float = 0.2) -> List[int]:
+                  db_path: Optional[str] = None, poll_s: float = 0.2, grace_s: Optional[float] = None) -> List[int]:
     """Start `cmd` nprocs times as fresh child processes (rank r: RANK = LOCAL_RANK = r), wait for all of them and
     return their exit codes.  Children inherit stdout / stderr, so rank 0's JSON line is the parent's.  A child that
-    exits non-zero while others are still running is marked dead for them (tombstone)."""
+    exits non-zero while others are still running is marked dead for them (tombstone).  The survivors keep working -
+    their coalitions are hours of useful work and the final rendezvous does not wait for a tombstoned rank - for at
+    most `grace_s` seconds after the first death (default: GAD_SURVIVOR_GRACE, unset = unbounded); then they are
+    terminated, killed if they ignore that, and reported with their (negative) signal codes, so a requeue entry
+    starts fresh children instead of waiting on a hung rank."""
+    if grace_s is None and os.environ.get("GAD_SURVIVOR_GRACE"):
+        grace_s = float(os.environ["GAD_SURVIVOR_GRACE"])
     env0 = dict(os.environ)
     env0.setdefault("HSA_ENABLE_IPC_MODE_LEGACY", "0")            # dmabuf IPC: RCCL across processes needs it on this pool
     env0.update(MASTER_ADDR="127.0.0.1", MASTER_PORT=str(free_port()), WORLD_SIZE=str(nprocs),
@@ -59,15 +65,25 @@ def spawn_workers(cmd: Sequence[str], nprocs: int, extra_env: Optional[Dict[str,
         env = dict(env0, RANK=str(r), LOCAL_RANK=str(r))
         procs.append(subprocess.Popen(list(cmd), env=env))
     codes: List[Optional[int]] = [None] * nprocs
+    first_death, stage = None, 0
     while any(c is None for c in codes):
         for r, p in enumerate(procs):
             if codes[r] is None:
                 rc = p.poll()
                 if rc is not None:
                     codes[r] = rc
-                    if rc != 0 and db_path:
-                        with open(tombstone(db_path, r), "w") as f:
-                            f.write(f"exit code {rc}\n")
+                    if rc != 0:
+                        first_death = first_death or time.time()
+                        if db_path:
+                            with open(tombstone(db_path, r), "w") as f:
+                                f.write(f"exit code {rc}\n")
+        if grace_s is not None and first_death is not None:
+            late = time.time() - first_death - grace_s
+            if late > 0 and stage == 0 or late > 10 and stage == 1:
+                for r, p in enumerate(procs):
+                    if codes[r] is None:
+                        (p.terminate if stage == 0 else p.kill)()
+                stage += 1
         time.sleep(poll_s)
     return [int(c) for c in codes]
 
@@ -122,10 +138,13 @@ def worker(a) -> int:
     dev = torch.device(f"cuda:{local}")
     torch.cuda.set_device(dev)
     if world > 1:
+        from datetime import timedelta
+        # bounded: a rank that died before / during the rendezvous must not leave the others blocked in it forever
+        tmo = timedelta(seconds=float(os.environ.get("GAD_INIT_TIMEOUT", 600)))
         if a.backend == "nccl":
-            dist.init_process_group("nccl", device_id=dev)
+            dist.init_process_group("nccl", device_id=dev, timeout=tmo)
         else:
-            dist.init_process_group("gloo")
+            dist.init_process_group("gloo", timeout=tmo)
     gad.set_operand_precision(a.mixed_precision)
     if a.cycle == "cifar":
         engine = CoalitionEngine(a.dataset, device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,

@@ -310,8 +310,13 @@ def bf16_weight(w):
         if cached is None or cached[0] != key:
             shadow = cached[1] if cached is not None else torch.empty(flat.numel(), device=flat.device, dtype=torch.bfloat16)
             shadow.copy_(flat.detach())
-            cached = (key, shadow)
+            # A resident parameter written through torch (load_state_dict, p.copy_(), a torch.optim step) bumps only ITS
+            # version counter, not the buffer's: remember every resident's version as of this cast ...
+            cached = (key, shadow, {o_: p_._version for p_, o_, _ in getattr(flat, "_gad_params", ())})
             flat._gad_bf16 = cached
+        if cached[2].get(off, w._version) != w._version:          # ... and re-cast the slice of one that moved since
+            cached[1][off:off + n].copy_(flat.detach()[off:off + n])
+            cached[2][off] = w._version
         o, i, kh, kw = w.shape
         return cached[1][off:off + n].view(o, kh, kw, i)
     key = weight_key(w)

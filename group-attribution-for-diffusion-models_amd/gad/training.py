@@ -43,6 +43,7 @@ def flatten_params(params):
             p._gad_sink_epoch = -1
             p._gad_flat = (flat, off, n)                 # where the parameter lives (one bf16 cast serves all of them)
             off += sz
+    flat._gad_params = [(p, p._gad_flat[1], p._gad_flat[2]) for p in params]     # ops.bf16_weight snapshots their versions
     return flat, gflat
 
 

@@ -610,6 +610,36 @@ def test_unet_forward_backward_bf16_close_to_fp32(ops):
     assert cos > 0.999, cos
 
 
+def test_bf16_shadow_follows_parameters_written_through_torch(ops):
+    """A parameter living in the flat buffer (training.flatten_params) and rewritten THROUGH TORCH - load_state_dict,
+    p.copy_(), a torch.optim step - bumps its own version counter, not the buffer's: the bf16 shadow of the buffer must
+    re-cast that slice (a stale shadow would silently sample / train with the old weights).  flatten, bf16 forward,
+    load new weights, forward again, compare with an unflattened model holding the new weights."""
+    import gad
+    from gad.training import flatten_params
+    from src.ddpm_config import DDPMConfig
+    cfg = dict(DDPMConfig.cifar100_config["unet_config"], block_out_channels=[32, 64, 64, 64], norm_num_groups=8)
+    torch.manual_seed(0)
+    net, other, plain = (gad.UNet2DModel(**cfg).to(dev) for _ in range(3))
+    with torch.no_grad():
+        for p in other.parameters():
+            p.mul_(1.5).add_(0.01)
+    plain.load_state_dict(other.state_dict())
+    flatten_params(list(net.parameters()))
+    x, t = rnd(2, 3, 32, 32, seed=1).to(dev), torch.tensor([3, 900], device=dev)
+    with torch.no_grad(), ops.operand_precision("bf16"):
+        y_old = net(x, t).sample.clone()
+        net.load_state_dict(other.state_dict())                    # writes the flat storage through the parameters
+        y_new = net(x, t).sample
+        want = plain(x, t).sample
+        assert (y_new - y_old).abs().max().item() > 1e-3           # the weights did change
+        assert torch.equal(y_new, want), (y_new - want).abs().max().item()
+        w0 = next(p for p in net.parameters() if p.ndim == 4 and p.shape[1] % 32 == 0)
+        w0.copy_(w0 * 0.5)                                         # a single parameter, in place
+        plain.load_state_dict(net.state_dict())
+        assert torch.equal(net(x, t).sample, plain(x, t).sample)
+
+
 # -------------------------------------------------- channel concat read in place (up blocks) ----
 @pytest.mark.parametrize("C1,C2,H,k", [(128, 128, 16, 1), (256, 128, 8, 1), (64, 32, 8, 3), (256, 256, 4, 3)])
 @pytest.mark.parametrize("prec", ["f32", "bf16"])

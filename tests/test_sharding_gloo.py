@@ -79,6 +79,7 @@ def test_two_rank_gloo_all_gather_and_merge(tmp_path):
 # ---- durability / failure handling of the scheduler (reference: per-job `open(db, "a+")` rows,
 # ---- unlearn.job `--requeue`, setup_unlearn_commands.py:133-154 re-entry) -------------------------------------
 import subprocess  # noqa: E402
+import time  # noqa: E402
 
 from gad import launch  # noqa: E402
 from gad.coalition import finished_seeds  # noqa: E402
@@ -127,6 +128,46 @@ def test_rank_dying_mid_run_keeps_finished_rows_and_requeue_completes(tmp_path):
     assert codes == [0, 0]
     assert sorted(r["removal_seed"] for r in _rows(db)) == list(range(8))
     assert len({r["removal_seed"] for r in _rows(db)}) == 8                            # no duplicates
+
+
+@pytest.mark.timeout(180)
+def test_rank0_dying_does_not_hang_or_spin_the_survivor(tmp_path):
+    """rank 0 hosts the process group's store: when it is killed the survivor's rendezvous sees the store fail (or the
+    tombstone), skips the collective and exits cleanly with its rows durable in its own shard; the requeued entry
+    merges that shard and finishes rank 0's seeds."""
+    db = str(tmp_path / "db.jsonl")
+    t0 = time.time()
+    codes = launch.spawn_workers([sys.executable, WORKER, db, "8", "die:4"], 2, db_path=db)
+    assert codes[0] == 17 and codes[1] == 0 and time.time() - t0 < 60
+    assert finished_seeds(db) == {0, 2, 1, 3, 5, 7}                                    # nobody merged: rows sit in the shards
+    codes = launch.spawn_workers([sys.executable, WORKER, db, "8", "ok"], 2, db_path=db)
+    assert codes == [0, 0]
+    assert sorted(r["removal_seed"] for r in _rows(db)) == list(range(8))
+
+
+def test_merge_keeps_the_shard_of_a_rank_that_may_still_be_alive(tmp_path):
+    """A rank that missed the rendezvous by timeout (no tombstone) may still be appending: its rows are copied into the
+    db, its shard stays; a consumed shard is renamed before it is read."""
+    from gad.coalition import merge_shards
+    db = str(tmp_path / "db.jsonl")
+    for r, seeds in ((0, [0, 2]), (1, [1, 3])):
+        with open(f"{db}.rank{r}", "w") as f:
+            for s in seeds:
+                f.write(json.dumps({"removal_seed": s, "fid_value": float(s), "device": f"cuda:{r}"}) + "\n")
+    gathered = [{"removal_seed": 1, "fid_value": 1.0, "device": "cuda:0"}]             # rebuilt by rank 0: must not win
+    assert merge_shards(db, gathered, keep_ranks=[1]) == [0, 1, 2, 3]
+    assert os.path.exists(f"{db}.rank1") and not os.path.exists(f"{db}.rank0")
+    assert {r["removal_seed"]: r["device"] for r in _rows(db)} == {0: "cuda:0", 1: "cuda:1", 2: "cuda:0", 3: "cuda:1"}
+    assert merge_shards(db, keep_ranks=[]) == [] and not os.path.exists(f"{db}.rank1")   # later entry: nothing new, consumed
+
+
+@pytest.mark.timeout(120)
+def test_survivors_are_stopped_after_the_grace_period(tmp_path):
+    """spawn_workers(grace_s=...): once a rank has died the others get a bounded time, then terminate() / kill()."""
+    prog = "import os, sys, time\nif os.environ['RANK'] == '1': sys.exit(3)\ntime.sleep(600)\n"
+    t0 = time.time()
+    codes = launch.spawn_workers([sys.executable, "-c", prog], 2, grace_s=1.0)
+    assert codes[1] == 3 and codes[0] < 0 and time.time() - t0 < 60
 
 
 @pytest.mark.timeout(180)
