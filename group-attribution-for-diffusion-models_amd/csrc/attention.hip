@@ -60,6 +60,8 @@ struct AttnDev {
   const float* q; const float* k; const float* v; float* o; float* lse;
   const float* d_o; const float* delta; float* dq; float* dk; float* dv;
   int B, heads, Tq, Tk;
+  int d;                                                 // the head dim itself (<= the instance's D; < D only in RG kernels)
+  int nblk;                                              // query / key blocks per (b, h): blockIdx.x = blk + nblk * (b * heads + h)
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;       // row strides (floats)
   long sq, sk, sv, so, sdo, sdq, sdk, sdv;              // batch strides (floats)
   float scale;                                           // 1/sqrt(d)
@@ -125,6 +127,87 @@ __device__ __forceinline__ void stage_tile_lean(float* tile, const float* base, 
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// RG ("ragged") instances: any head dim d <= D and any alignment - the head-grouped-pruned CelebA model keeps its heads
+// and shrinks the head dim 32 -> 23 (reference unconditional_generation/prune.py:337-342): rows of 14 x 23 = 322 floats,
+// heads starting at odd offsets, nothing float4-aligned.  The kernels are the same; what changes is how operands reach
+// them: streamed tiles go global -> registers (dword loads, issued before the tile's MFMAs) -> ds_write_b32 (after them)
+// into the same [KV][S] image, columns d .. S-1 zeroed once; loop-invariant row fragments and the outputs use dword
+// accesses masked at d.  `Stream<D, RG>` hides the difference from the kernel bodies.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, bool RG>
+struct Stream;
+template <int D>
+struct Stream<D, false> {
+  TilePlan<D> plan;
+  __device__ __forceinline__ void init(int ld) { plan.init(ld); }
+  __device__ __forceinline__ void issue(float* tile, const float* base, int ld, int row0, int T, int) {
+    stage_tile_lean<D>(tile, base, ld, row0, T, plan);
+  }
+  __device__ __forceinline__ void commit(float*) {}
+};
+template <int D>
+struct Stream<D, true> {
+  static constexpr int NE = (KV * D + NT - 1) / NT;
+  // up to D = 96 the next tile's elements wait in registers while the current tile is computed on; wider heads have no
+  // registers to spare (dK/dV at D = 256 holds 128 accumulator registers + 128 of fragments), so they fetch and write
+  // after the MFMAs - a correct, slower form for shapes no reference model has
+  static constexpr bool HOLD = D <= 96;
+  float r[HOLD ? NE : 1];
+  const float* src_;
+  int ld_, row0_, T_, d_;
+  __device__ __forceinline__ void init(int) {}
+  __device__ __forceinline__ float fetch(int i, const float* base, int ld, int row0, int T, int d) const {
+    const int e = threadIdx.x + NT * i;
+    const int row = e / D, col = e - row * D;
+    const bool ok = e < KV * D && row0 + row < T && col < d;
+    return ok ? base[(long)(row0 + row) * ld + col] : 0.f;
+  }
+  __device__ __forceinline__ void issue(float*, const float* base, int ld, int row0, int T, int d) {
+    if (HOLD) {
+#pragma unroll
+      for (int i = 0; i < NE; ++i) r[i] = fetch(i, base, ld, row0, T, d);
+    } else {
+      src_ = base; ld_ = ld; row0_ = row0; T_ = T; d_ = d;
+    }
+  }
+  __device__ __forceinline__ void commit(float* tile) {
+#pragma unroll
+    for (int i = 0; i < NE; ++i) {
+      const int e = threadIdx.x + NT * i;
+      const int row = e / D, col = e - row * D;
+      const float v = HOLD ? r[HOLD ? i : 0] : fetch(i, src_, ld_, row0_, T_, d_);
+      if (e < KV * D) tile[row * Cfg<D>::S + col] = v;
+    }
+  }
+};
+// first tiles of the two streams into buffer 0 (RG: the whole LDS is zeroed first - pad columns stay zero for good)
+template <int D, bool RG>
+__device__ __forceinline__ void stream_prologue(float* lds, Stream<D, RG>& a, Stream<D, RG>& b, const float* A, int lda,
+                                                const float* Bp, int ldb, int T, int d) {
+  using C = Cfg<D>;
+  if (RG) {
+    for (int i = threadIdx.x * 4; i < 4 * C::TILE; i += NT * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+    __syncthreads();
+  }
+  a.issue(lds, A, lda, 0, T, d);
+  b.issue(lds + C::TILE, Bp, ldb, 0, T, d);
+  a.commit(lds);
+  b.commit(lds + C::TILE);
+  barrier_after_dma();
+}
+// four consecutive head-dim columns col0 .. col0+3 of one output row (col0 % 4 == 0)
+template <int D, bool RG>
+__device__ __forceinline__ void store_cols(float* rowptr, int col0, const f32x4& v, int d) {
+  if (!RG) {
+    if (col0 < D) *reinterpret_cast<f32x4*>(rowptr + col0) = v;
+  } else {
+#pragma unroll
+    for (int j = 0; j < 4; ++j)
+      if (col0 + j < d) rowptr[col0 + j] = v[j];
+  }
+}
+
 // "row fragment": lanes along the tile's ROWS (lane l: row r0 + (l & 15), k slot g = l >> 4).  Step s = 4 grp + j uses
 // k = 16 grp + 4 g + j (float4 per group), the 8-wide tail k = 16 G16 + 2 g + j (float2).  The SAME k assignment is
 // used for both operands of a product, which is all a contraction needs.
@@ -146,11 +229,28 @@ __device__ __forceinline__ void row_frag_lds(const float* tile, int r0, float (&
   }
 }
 // the same fragment straight from global memory (loop-invariant operands: one load per workgroup lifetime)
-template <int D>
-__device__ __forceinline__ void row_frag_global(const float* base, int ld, int row, bool ok, float mul, float (&f)[Cfg<D>::KS]) {
+template <int D, bool RG = false>
+__device__ __forceinline__ void row_frag_global(const float* base, int ld, int row, bool ok, float mul, float (&f)[Cfg<D>::KS], int d = D) {
   using C = Cfg<D>;
   const int g = (threadIdx.x & 63) >> 4;
   const float* p = base + (long)(ok ? row : 0) * ld;
+  if (RG) {                      // dword loads, zero at and beyond d
+#pragma unroll
+    for (int grp = 0; grp < C::G16; ++grp)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) {
+        const int col = 16 * grp + 4 * g + j;
+        f[4 * grp + j] = (ok && col < d) ? p[col] * mul : 0.f;
+      }
+    if (C::TAIL8) {
+#pragma unroll
+      for (int j = 0; j < 2; ++j) {
+        const int col = 16 * C::G16 + 2 * g + j;
+        f[4 * C::G16 + j] = (ok && col < d) ? p[col] * mul : 0.f;
+      }
+    }
+    return;
+  }
 #pragma unroll
   for (int grp = 0; grp < C::G16; ++grp) {
     f32x4 v = *reinterpret_cast<const f32x4*>(p + 16 * grp + 4 * g);
@@ -182,22 +282,22 @@ constexpr float RESCALE_SLACK = 8.f;     // exp2 domain: the running reference m
 // ------------------------------------------------------------------------------------------------------------------
 // forward: workgroup = 64 NQ queries of one (b, h); wave w owns queries [q0 + 16 NQ w, + 16 NQ)
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int NQ>
+template <int D, int NQ, bool RG = false>
 __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
   using C = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][K tile | V tile]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const float* Q = p.q + b * p.sq + h * D;
-  const float* K = p.k + b * p.sk + h * D;
-  const float* V = p.v + b * p.sv + h * D;
-  const int qw = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * p.d;
+  const float* K = p.k + b * p.sk + h * p.d;
+  const float* V = p.v + b * p.sv + h * p.d;
+  const int qw = blk * (64 * NQ) + wave * (16 * NQ);
 
   float qf[NQ][C::KS];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     const int row = qw + 16 * t + c;
-    row_frag_global<D>(Q, p.ldq, row, row < p.Tq, p.scale * LOG2E, qf[t]);     // scores in the exp2 domain
+    row_frag_global<D, RG>(Q, p.ldq, row, row < p.Tq, p.scale * LOG2E, qf[t], p.d);     // scores in the exp2 domain
   }
   f32x4 o[C::NDV][NQ];
 #pragma unroll
@@ -209,20 +309,19 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
   for (int t = 0; t < NQ; ++t) { m[t] = NEG_BIG; l[t] = 0.f; }
 
   const int ntiles = (p.Tk + KV - 1) / KV;
-  TilePlan<D> kplan, vplan;
-  kplan.init(p.ldk);
-  vplan.init(p.ldv);
-  stage_tile_lean<D>(lds, K, p.ldk, 0, p.Tk, kplan);
-  stage_tile_lean<D>(lds + C::TILE, V, p.ldv, 0, p.Tk, vplan);
-  barrier_after_dma();
+  Stream<D, RG> ks, vs;
+  ks.init(p.ldk);
+  vs.init(p.ldv);
+  stream_prologue<D, RG>(lds, ks, vs, K, p.ldk, V, p.ldv, p.Tk, p.d);
 
   for (int it = 0; it < ntiles; ++it) {
     const float* kt_ = lds + (it & 1) * (2 * C::TILE);
     const float* vt_ = kt_ + C::TILE;
-    if (it + 1 < ntiles) {            // the other buffer was last read before the barrier that ended iteration it-1
-      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile_lean<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk, kplan);
-      stage_tile_lean<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, vplan);
+    float* const nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+    const bool more = it + 1 < ntiles;
+    if (more) {                       // the other buffer was last read before the barrier that ended iteration it-1
+      ks.issue(nb, K, p.ldk, (it + 1) * KV, p.Tk, p.d);
+      vs.issue(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, p.d);
     }
     // S^T[key][q] (exp2 domain), two key tiles of 16
     f32x4 s[2][NQ];
@@ -288,10 +387,14 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
           for (int t = 0; t < NQ; ++t) o[i][t] = mfma16(a, s[kt][t][e], o[i][t]);
         }
       }
+    if (RG && more) {
+      ks.commit(nb);
+      vs.commit(nb + C::TILE);
+    }
     barrier_after_dma();              // next tiles landed; every wave is done with this buffer
   }
 
-  float* O = p.o + b * p.so + h * D;
+  float* O = p.o + b * p.so + h * p.d;
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     const float lt = xsum16_32(l[t]);
@@ -299,17 +402,14 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
     const int row = qw + 16 * t + c;
     if (row < p.Tq) {
 #pragma unroll
-      for (int i = 0; i < C::NDV; ++i) {
-        const int dv = 16 * i + 4 * g;
-        if (dv < D) *reinterpret_cast<f32x4*>(O + (long)row * p.ldo + dv) = o[i][t] * inv;
-      }
+      for (int i = 0; i < C::NDV; ++i) store_cols<D, RG>(O + (long)row * p.ldo, 16 * i + 4 * g, o[i][t] * inv, p.d);
       if (g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m[t] + __builtin_amdgcn_logf(lt);   // v_log_f32 = log2
     }
   }
 }
 
 // delta[b, h, q] = sum_dv dO[b, q, h, dv] * O[b, q, h, dv]
-template <int D>
+template <int D, bool RG = false>
 __global__ void attn_delta_kernel(const AttnDev p, float* delta) {
   const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   const long total = (long)p.B * p.Tq * p.heads;
@@ -317,13 +417,17 @@ __global__ void attn_delta_kernel(const AttnDev p, float* delta) {
   const int h = (int)(idx % p.heads);
   const long bq = idx / p.heads;
   const int q = (int)(bq % p.Tq), b = (int)(bq / p.Tq);
-  const float* o = p.o + b * p.so + (long)q * p.ldo + h * D;
-  const float* g = p.d_o + b * p.sdo + (long)q * p.lddo + h * D;
+  const float* o = p.o + b * p.so + (long)q * p.ldo + h * p.d;
+  const float* g = p.d_o + b * p.sdo + (long)q * p.lddo + h * p.d;
   float acc = 0.f;
+  if (RG) {
+    for (int i = 0; i < p.d; ++i) acc += o[i] * g[i];
+  } else {
 #pragma unroll
-  for (int i = 0; i < D; i += 4) {
-    const f32x4 a = *reinterpret_cast<const f32x4*>(o + i), d = *reinterpret_cast<const f32x4*>(g + i);
-    acc += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+    for (int i = 0; i < D; i += 4) {
+      const f32x4 a = *reinterpret_cast<const f32x4*>(o + i), d = *reinterpret_cast<const f32x4*>(g + i);
+      acc += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+    }
   }
   delta[((long)b * p.heads + h) * p.Tq + q] = acc;
 }
@@ -331,26 +435,26 @@ __global__ void attn_delta_kernel(const AttnDev p, float* delta) {
 // ------------------------------------------------------------------------------------------------------------------
 // dQ: workgroup = 64 queries of one (b, h), wave w owns 16; streams K / V tiles
 // ------------------------------------------------------------------------------------------------------------------
-template <int D, int NQ = 1>
+template <int D, int NQ = 1, bool RG = false>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
   // NQ query blocks of 16 per wave (workgroup = 64 NQ queries): a K / V fragment read from LDS, and every staged byte, feeds
   // NQ times the MFMAs - at d = 40 one block per wave is 64 MFMAs against ~230 other instructions per tile
   using C = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const float* K = p.k + b * p.sk + h * D;
-  const float* V = p.v + b * p.sv + h * D;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
+  const float* K = p.k + b * p.sk + h * p.d;
+  const float* V = p.v + b * p.sv + h * p.d;
   int row[NQ];
   bool rok[NQ];
   float qf[NQ][C::KS], dof[NQ][C::KS], L2[NQ], dl[NQ];
   f32x4 dq[NQ][C::NDV];
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
-    row[t] = blockIdx.x * (64 * NQ) + wave * (16 * NQ) + 16 * t + c;
+    row[t] = blk * (64 * NQ) + wave * (16 * NQ) + 16 * t + c;
     rok[t] = row[t] < p.Tq;
-    row_frag_global<D>(p.q + b * p.sq + h * D, p.ldq, row[t], rok[t], p.scale * LOG2E, qf[t]);
-    row_frag_global<D>(p.d_o + b * p.sdo + h * D, p.lddo, row[t], rok[t], 1.f, dof[t]);
+    row_frag_global<D, RG>(p.q + b * p.sq + h * p.d, p.ldq, row[t], rok[t], p.scale * LOG2E, qf[t], p.d);
+    row_frag_global<D, RG>(p.d_o + b * p.sdo + h * p.d, p.lddo, row[t], rok[t], 1.f, dof[t], p.d);
     L2[t] = rok[t] ? p.lse[(long)bh * p.Tq + row[t]] : 0.f;
     dl[t] = rok[t] ? p.delta[(long)bh * p.Tq + row[t]] : 0.f;
 #pragma unroll
@@ -358,19 +462,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
   }
 
   const int ntiles = (p.Tk + KV - 1) / KV;
-  TilePlan<D> kplan, vplan;
-  kplan.init(p.ldk);
-  vplan.init(p.ldv);
-  stage_tile_lean<D>(lds, K, p.ldk, 0, p.Tk, kplan);
-  stage_tile_lean<D>(lds + C::TILE, V, p.ldv, 0, p.Tk, vplan);
-  barrier_after_dma();
+  Stream<D, RG> ks, vs;
+  ks.init(p.ldk);
+  vs.init(p.ldv);
+  stream_prologue<D, RG>(lds, ks, vs, K, p.ldk, V, p.ldv, p.Tk, p.d);
   for (int it = 0; it < ntiles; ++it) {
     const float* kt_ = lds + (it & 1) * (2 * C::TILE);
     const float* vt_ = kt_ + C::TILE;
-    if (it + 1 < ntiles) {
-      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile_lean<D>(nb, K, p.ldk, (it + 1) * KV, p.Tk, kplan);
-      stage_tile_lean<D>(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, vplan);
+    float* const nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      ks.issue(nb, K, p.ldk, (it + 1) * KV, p.Tk, p.d);
+      vs.issue(nb + C::TILE, V, p.ldv, (it + 1) * KV, p.Tk, p.d);
     }
     f32x4 ds[2][NQ];
 #pragma unroll
@@ -422,37 +525,38 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_f32_kernel(const AttnDev p) {
           for (int t = 0; t < NQ; ++t) dq[t][i] = mfma16(a, ds[kt][t][e], dq[t][i]);   // dQ^T[k][q] += K^T dS^T
         }
       }
+    if (RG && more) {
+      ks.commit(nb);
+      vs.commit(nb + C::TILE);
+    }
     barrier_after_dma();
   }
 #pragma unroll
   for (int t = 0; t < NQ; ++t)
     if (rok[t]) {
-      float* DQ = p.dq + b * p.sdq + h * D + (long)row[t] * p.lddq;
+      float* DQ = p.dq + b * p.sdq + h * p.d + (long)row[t] * p.lddq;
 #pragma unroll
-      for (int i = 0; i < C::NDV; ++i) {
-        const int kk = 16 * i + 4 * g;
-        if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[t][i] * p.scale;
-      }
+      for (int i = 0; i < C::NDV; ++i) store_cols<D, RG>(DQ, 16 * i + 4 * g, dq[t][i] * p.scale, p.d);
     }
 }
 
 // ------------------------------------------------------------------------------------------------------------------
 // dK / dV: workgroup = 64 keys of one (b, h), wave w owns 16; streams Q / dO tiles (+ LSE, delta of their rows)
 // ------------------------------------------------------------------------------------------------------------------
-template <int D>
+template <int D, bool RG = false>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   using C = Cfg<D>;
   extern __shared__ __attribute__((aligned(16))) float lds[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
-  const float* Q = p.q + b * p.sq + h * D;
-  const float* DO = p.d_o + b * p.sdo + h * D;
-  const int key = blockIdx.x * 64 + wave * 16 + c;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * p.d;
+  const float* DO = p.d_o + b * p.sdo + h * p.d;
+  const int key = blk * 64 + wave * 16 + c;
   const bool kok = key < p.Tk;
 
   float kf[C::KS], vf[C::KS];
-  row_frag_global<D>(p.k + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
-  row_frag_global<D>(p.v + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
+  row_frag_global<D, RG>(p.k + b * p.sk + h * p.d, p.ldk, key, kok, p.scale * LOG2E, kf, p.d);
+  row_frag_global<D, RG>(p.v + b * p.sv + h * p.d, p.ldv, key, kok, 1.f, vf, p.d);
   f32x4 dk[C::NDV], dv[C::NDV];
 #pragma unroll
   for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -461,19 +565,18 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   const bool vec_stats = p.Tq % 4 == 0 && (reinterpret_cast<uintptr_t>(p.lse) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.delta) & 15) == 0;
 
   const int ntiles = (p.Tq + KV - 1) / KV;
-  TilePlan<D> qplan, doplan;
-  qplan.init(p.ldq);
-  doplan.init(p.lddo);
-  stage_tile_lean<D>(lds, Q, p.ldq, 0, p.Tq, qplan);
-  stage_tile_lean<D>(lds + C::TILE, DO, p.lddo, 0, p.Tq, doplan);
-  barrier_after_dma();
+  Stream<D, RG> qs, gs;
+  qs.init(p.ldq);
+  gs.init(p.lddo);
+  stream_prologue<D, RG>(lds, qs, gs, Q, p.ldq, DO, p.lddo, p.Tq, p.d);
   for (int it = 0; it < ntiles; ++it) {
     const float* qt_ = lds + (it & 1) * (2 * C::TILE);
     const float* dot_ = qt_ + C::TILE;
-    if (it + 1 < ntiles) {
-      float* nb = lds + ((it + 1) & 1) * (2 * C::TILE);
-      stage_tile_lean<D>(nb, Q, p.ldq, (it + 1) * KV, p.Tq, qplan);
-      stage_tile_lean<D>(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq, doplan);
+    float* const nb = lds + ((it + 1) & 1) * (2 * C::TILE);
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      qs.issue(nb, Q, p.ldq, (it + 1) * KV, p.Tq, p.d);
+      gs.issue(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq, p.d);
     }
     f32x4 pr[2], ds[2];
 #pragma unroll
@@ -525,18 +628,19 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
           dk[i] = mfma16(qrow[16 * i], ds[t][e], dk[i]);      // dK^T[k][key]  += Q^T[k][q]  dS[q][key]
         }
       }
+    if (RG && more) {
+      qs.commit(nb);
+      gs.commit(nb + C::TILE);
+    }
     barrier_after_dma();
   }
   if (kok) {
-    float* DK = p.dk + b * p.sdk + h * D + (long)key * p.lddk;
-    float* DV = p.dv + b * p.sdv + h * D + (long)key * p.lddv;
+    float* DK = p.dk + b * p.sdk + h * p.d + (long)key * p.lddk;
+    float* DV = p.dv + b * p.sdv + h * p.d + (long)key * p.lddv;
 #pragma unroll
     for (int i = 0; i < C::NDV; ++i) {
-      const int kk = 16 * i + 4 * g;
-      if (kk < D) {
-        *reinterpret_cast<f32x4*>(DK + kk) = dk[i] * p.scale;
-        *reinterpret_cast<f32x4*>(DV + kk) = dv[i];
-      }
+      store_cols<D, RG>(DK, 16 * i + 4 * g, dk[i] * p.scale, p.d);
+      store_cols<D, RG>(DV, 16 * i + 4 * g, dv[i], p.d);
     }
   }
 }
@@ -649,11 +753,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
   constexpr int KIMG = KV * C::SK, VIMG = KV * C::SV, BUF = (KIMG + VIMG + 7) / 8 * 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
   const float* Q = p.q + b * p.sq + h * D;
   const float* K = p.k + b * p.sk + h * D;
   const float* V = p.v + b * p.sv + h * D;
-  const int qw = blockIdx.x * (64 * NQ) + wave * (16 * NQ);
+  const int qw = blk * (64 * NQ) + wave * (16 * NQ);
 
   bf16x8_t qf[NQ][C::KS];
 #pragma unroll
@@ -769,10 +873,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
   constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image] + tail pad
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
   const float* K = p.k + b * p.sk + h * D;
   const float* V = p.v + b * p.sv + h * D;
-  const int row = blockIdx.x * 64 + wave * 16 + c;
+  const int row = blk * 64 + wave * 16 + c;
   const bool rok = row < p.Tq;
   bf16x8_t qf[C::KS], dof[C::KS];
   row_frag_global_h<D>(p.q + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
@@ -844,10 +948,10 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
   constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
-  const int bh = blockIdx.y, b = bh / p.heads, h = bh - b * p.heads;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
   const float* Q = p.q + b * p.sq + h * D;
   const float* DO = p.d_o + b * p.sdo + h * D;
-  const int key = blockIdx.x * 64 + wave * 16 + c;
+  const int key = blk * 64 + wave * 16 + c;
   const bool kok = key < p.Tk;
   bf16x8_t kf[C::KS], vf[C::KS];
   row_frag_global_h<D>(p.k + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
@@ -921,37 +1025,58 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
   }
 }
 
+// Kernels that want more than 64 KiB of dynamic LDS need the attribute once per kernel instance and device - not per
+// launch (a driver call on the sampling / training hot path, and one made inside hipGraph captures of the U-Net).
 template <typename F>
-static int set_lds(F kernel, int bytes, const char* what) {
-  if (bytes > 64 * 1024) {
-    hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
-    if (e != hipSuccess) {
-      gad_set_error("%s: cannot reserve %d bytes of LDS: %s", what, bytes, hipGetErrorString(e));
-      return 1;
-    }
+static int set_lds(F kernel, int bytes, const char* what, unsigned* done_mask) {
+  if (bytes <= 64 * 1024) return 0;
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  const unsigned bit = 1u << (dev & 31);
+  if (__atomic_load_n(done_mask, __ATOMIC_ACQUIRE) & bit) return 0;
+  hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(kernel), hipFuncAttributeMaxDynamicSharedMemorySize, bytes);
+  if (e != hipSuccess) {
+    gad_set_error("%s: cannot reserve %d bytes of LDS: %s", what, bytes, hipGetErrorString(e));
+    return 1;
   }
+  __atomic_fetch_or(done_mask, bit, __ATOMIC_RELEASE);
   return 0;
 }
 
-}  // namespace
-extern "C" int gad_attention_supported(int32_t d) {
-  switch (d) {
-    case 16: case 32: case 40: case 64: case 80: case 96: case 128: case 160: case 192: case 224: case 256: return 1;
-    default: return 0;
-  }
+// head dims with an instance; any other d <= 256 runs the next larger one in its RG form
+#define GAD_ATTN_DIMS(X) X(16) X(24) X(32) X(40) X(48) X(64) X(80) X(96) X(128) X(160) X(192) X(224) X(256)
+static int instance_dim(int d) {
+#define X(DIM) if (d <= DIM) return DIM;
+  GAD_ATTN_DIMS(X)
+#undef X
+  return 0;
 }
+static bool exact_instance(int d) { return d > 0 && instance_dim(d) == d; }
+
+}  // namespace
+extern "C" int gad_attention_supported(int32_t d) { return d >= 1 && d <= 256; }
 namespace {
+
+// Does this launch meet the float4 / LDS-DMA contract (an exact instance, every row and batch stride a multiple of 4
+// floats, every pointer 16-byte aligned)?  If not it runs the RG instance (dword staging, any d <= 256, any alignment).
+static bool fast_contract(const gad_attention_args* a, bool bwd) {
+  bool ok = exact_instance(a->d) && a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0 &&
+            a->stride_q % 4 == 0 && a->stride_k % 4 == 0 && a->stride_v % 4 == 0 && a->stride_o % 4 == 0 &&
+            gad_aligned16(a->q) && gad_aligned16(a->k) && gad_aligned16(a->v) && gad_aligned16(a->o);
+  if (bwd)
+    ok = ok && a->ld_do % 4 == 0 && a->ld_dq % 4 == 0 && a->ld_dk % 4 == 0 && a->ld_dv % 4 == 0 && a->stride_do % 4 == 0 &&
+         a->stride_dq % 4 == 0 && a->stride_dk % 4 == 0 && a->stride_dv % 4 == 0 && gad_aligned16(a->d_o) &&
+         gad_aligned16(a->dq) && gad_aligned16(a->dk) && gad_aligned16(a->dv);
+  return ok;
+}
 
 static int check_common(const gad_attention_args* a, const char* who) {
   GAD_CHECK(a && a->q && a->k && a->v && a->o, "%s: null pointer", who);
   GAD_CHECK(a->B > 0 && a->heads > 0 && a->Tq > 0 && a->Tk > 0, "%s: bad shape B=%d heads=%d Tq=%d Tk=%d", who, a->B, a->heads, a->Tq, a->Tk);
-  GAD_CHECK(gad_attention_supported(a->d), "%s: head dim %d has no instance (16, 32, 40, 64, 80, 96, 128, 160, 192, 224, 256)", who, a->d);
+  GAD_CHECK(gad_attention_supported(a->d), "%s: head dim %d is outside 1..256", who, a->d);
   const int w = a->heads * a->d;
   GAD_CHECK(a->ldq >= w && a->ldk >= w && a->ldv >= w && a->ldo >= w, "%s: a row stride is smaller than heads*d = %d", who, w);
-  GAD_CHECK(a->ldq % 4 == 0 && a->ldk % 4 == 0 && a->ldv % 4 == 0 && a->ldo % 4 == 0, "%s: row strides must be multiples of 4 floats", who);
-  GAD_CHECK(a->stride_q % 4 == 0 && a->stride_k % 4 == 0 && a->stride_v % 4 == 0 && a->stride_o % 4 == 0, "%s: batch strides must be multiples of 4 floats", who);
-  GAD_CHECK(gad_aligned16(a->q) && gad_aligned16(a->k) && gad_aligned16(a->v) && gad_aligned16(a->o), "%s: q/k/v/o must be 16-byte aligned", who);
-  GAD_CHECK((long)a->B * a->heads < 65536, "%s: B*heads = %ld exceeds the grid's y range", who, (long)a->B * a->heads);
+  GAD_CHECK((long)a->B * a->heads * gad_ceil_div(a->Tq > a->Tk ? a->Tq : a->Tk, 64) < (1L << 31), "%s: B*heads*blocks exceeds the grid", who);
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "%s: operand_precision must be 0 or 1", who);
   return 0;
 }
@@ -961,7 +1086,7 @@ static AttnDev make_dev(const gad_attention_args* a) {
   memset(&d, 0, sizeof(d));
   d.q = a->q; d.k = a->k; d.v = a->v; d.o = a->o; d.lse = a->lse;
   d.d_o = a->d_o; d.delta = a->delta; d.dq = a->dq; d.dk = a->dk; d.dv = a->dv;
-  d.B = a->B; d.heads = a->heads; d.Tq = a->Tq; d.Tk = a->Tk;
+  d.B = a->B; d.heads = a->heads; d.Tq = a->Tq; d.Tk = a->Tk; d.d = a->d;
   d.ldq = a->ldq; d.ldk = a->ldk; d.ldv = a->ldv; d.ldo = a->ldo;
   d.lddo = a->ld_do; d.lddq = a->ld_dq; d.lddk = a->ld_dk; d.lddv = a->ld_dv;
   d.sq = a->stride_q; d.sk = a->stride_k; d.sv = a->stride_v; d.so = a->stride_o;
@@ -970,88 +1095,101 @@ static AttnDev make_dev(const gad_attention_args* a) {
   return d;
 }
 
-template <int D, int NQ>
-static int launch_fwd(const AttnDev& d, hipStream_t st) {
+static dim3 grid_of(AttnDev& d, int rows, int rows_per_block) {
+  d.nblk = (int)gad_ceil_div(rows, rows_per_block);
+  return dim3((unsigned)((long)d.nblk * d.B * d.heads));
+}
+
+template <int D, int NQ, bool RG>
+static int launch_fwd(AttnDev d, hipStream_t st) {
+  static unsigned lds_set = 0;
   const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
-  if (set_lds(attn_fwd_f32_kernel<D, NQ>, bytes, "gad_attention_fwd")) return 1;
-  dim3 grid((unsigned)gad_ceil_div(d.Tq, 64 * NQ), (unsigned)(d.B * d.heads));
-  hipLaunchKernelGGL((attn_fwd_f32_kernel<D, NQ>), grid, dim3(NT), bytes, st, d);
+  if (set_lds(attn_fwd_f32_kernel<D, NQ, RG>, bytes, "gad_attention_fwd", &lds_set)) return 1;
+  const dim3 grid = grid_of(d, d.Tq, 64 * NQ);
+  hipLaunchKernelGGL((attn_fwd_f32_kernel<D, NQ, RG>), grid, dim3(NT), bytes, st, d);
   return 0;
 }
 
 template <int D, int NQ>
-static int launch_fwd_h(const AttnDev& d, hipStream_t st) {
+static int launch_fwd_h(AttnDev d, hipStream_t st) {
   using C = CfgH<D>;
+  static unsigned lds_set = 0;
   const int bytes = 2 * ((KV * C::SK + KV * C::SV + 7) / 8 * 8) * (int)sizeof(unsigned short);
-  if (set_lds(attn_fwd_bf16_kernel<D, NQ>, bytes, "gad_attention_fwd")) return 1;
-  dim3 grid((unsigned)gad_ceil_div(d.Tq, 64 * NQ), (unsigned)(d.B * d.heads));
+  if (set_lds(attn_fwd_bf16_kernel<D, NQ>, bytes, "gad_attention_fwd", &lds_set)) return 1;
+  const dim3 grid = grid_of(d, d.Tq, 64 * NQ);
   hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, NQ>), grid, dim3(NT), bytes, st, d);
   return 0;
 }
 
-template <int D>
-static int launch_bwd(const AttnDev& d, float* delta, hipStream_t st) {
+template <int D, bool RG>
+static int launch_bwd(AttnDev d, float* delta, hipStream_t st) {
+  static unsigned lds_set_q = 0, lds_set_kv = 0;
   const int bytes = 4 * Cfg<D>::TILE * (int)sizeof(float);
-  constexpr int NQB = D <= 80 ? 2 : 1;      // query blocks per wave of the dQ kernel (registers allow two up to d = 80)
-  if (set_lds(attn_bwd_dq_f32_kernel<D, NQB>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_f32_kernel<D>, bytes, "gad_attention_bwd")) return 1;
+  constexpr int NQB = (D <= 80 && !RG) ? 2 : 1;      // query blocks per wave of the dQ kernel (registers allow two up to d = 80)
+  if (set_lds(attn_bwd_dq_f32_kernel<D, NQB, RG>, bytes, "gad_attention_bwd", &lds_set_q) ||
+      set_lds(attn_bwd_dkv_f32_kernel<D, RG>, bytes, "gad_attention_bwd", &lds_set_kv)) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
-  hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
-  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D, NQB>), dim3((unsigned)gad_ceil_div(d.Tq, 64 * NQB), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
-  hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  hipLaunchKernelGGL((attn_delta_kernel<D, RG>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
+  dim3 grid = grid_of(d, d.Tq, 64 * NQB);
+  hipLaunchKernelGGL((attn_bwd_dq_f32_kernel<D, NQB, RG>), grid, dim3(NT), bytes, st, d);
+  grid = grid_of(d, d.Tk, 64);
+  hipLaunchKernelGGL((attn_bwd_dkv_f32_kernel<D, RG>), grid, dim3(NT), bytes, st, d);
   return 0;
 }
 
 template <int D>
-static int launch_bwd_h(const AttnDev& d, float* delta, hipStream_t st) {
+static int launch_bwd_h(AttnDev d, float* delta, hipStream_t st) {
   using C = CfgH<D>;
+  static unsigned lds_set_q = 0, lds_set_kv = 0;
   const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short);
-  if (set_lds(attn_bwd_dq_bf16_kernel<D>, bytes, "gad_attention_bwd") || set_lds(attn_bwd_dkv_bf16_kernel<D>, bytes, "gad_attention_bwd")) return 1;
+  if (set_lds(attn_bwd_dq_bf16_kernel<D>, bytes, "gad_attention_bwd", &lds_set_q) ||
+      set_lds(attn_bwd_dkv_bf16_kernel<D>, bytes, "gad_attention_bwd", &lds_set_kv)) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
   hipLaunchKernelGGL((attn_delta_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
-  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tq, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
-  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D>), dim3((unsigned)gad_ceil_div(d.Tk, 64), (unsigned)(d.B * d.heads)), dim3(NT), bytes, st, d);
+  dim3 grid = grid_of(d, d.Tq, 64);
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D>), grid, dim3(NT), bytes, st, d);
+  grid = grid_of(d, d.Tk, 64);
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D>), grid, dim3(NT), bytes, st, d);
   return 0;
+}
+
+// one instance dim: pick the form (RG / bf16 / f32, queries per workgroup)
+template <int D>
+static int fwd_dim(const AttnDev& d, hipStream_t st, bool rg, bool bf16, bool wide) {
+  if (rg) return launch_fwd<D, 1, true>(d, st);
+  if (bf16) {
+    if constexpr (D <= 96) { if (wide) return launch_fwd_h<D, 2>(d, st); }
+    return launch_fwd_h<D, 1>(d, st);
+  }
+  if constexpr (D <= 80) { if (wide) return launch_fwd<D, 2, false>(d, st); }
+  return launch_fwd<D, 1, false>(d, st);
+}
+template <int D>
+static int bwd_dim(const AttnDev& d, float* delta, hipStream_t st, bool rg, bool bf16) {
+  if (rg) return launch_bwd<D, true>(d, delta, st);
+  if (bf16) return launch_bwd_h<D>(d, delta, st);
+  return launch_bwd<D, false>(d, delta, st);
 }
 
 }  // namespace
 
+// 1 if this launch runs bf16-operand kernels (operand_precision = 1 AND the float4 contract holds; RG launches are fp32)
+extern "C" int gad_attention_uses_bf16(const gad_attention_args* a, int32_t backward) {
+  return a && a->operand_precision == 1 && fast_contract(a, backward != 0);
+}
+
 extern "C" int gad_attention_fwd(const gad_attention_args* a, void* stream) {
   if (check_common(a, "gad_attention_fwd")) return 1;
-  AttnDev d = make_dev(a);
+  const AttnDev d = make_dev(a);
   hipStream_t st = (hipStream_t)stream;
-  int rc = 0;
+  const bool rg = !fast_contract(a, false), bf16 = a->operand_precision == 1;
   // queries per workgroup: 128 while the (b, h, block) grid still fills the chip twice over, else 64
   const bool wide = gad_ceil_div(a->Tq, 128) * a->B * a->heads >= 512;
-  if (a->operand_precision == 1) {
-    switch (a->d) {
-      case 16: rc = wide ? launch_fwd_h<16, 2>(d, st) : launch_fwd_h<16, 1>(d, st); break;
-      case 32: rc = wide ? launch_fwd_h<32, 2>(d, st) : launch_fwd_h<32, 1>(d, st); break;
-      case 40: rc = wide ? launch_fwd_h<40, 2>(d, st) : launch_fwd_h<40, 1>(d, st); break;
-      case 64: rc = wide ? launch_fwd_h<64, 2>(d, st) : launch_fwd_h<64, 1>(d, st); break;
-      case 80: rc = wide ? launch_fwd_h<80, 2>(d, st) : launch_fwd_h<80, 1>(d, st); break;
-      case 96: rc = wide ? launch_fwd_h<96, 2>(d, st) : launch_fwd_h<96, 1>(d, st); break;
-      case 128: rc = launch_fwd_h<128, 1>(d, st); break;
-      case 160: rc = launch_fwd_h<160, 1>(d, st); break;
-      case 192: rc = launch_fwd_h<192, 1>(d, st); break;
-      case 224: rc = launch_fwd_h<224, 1>(d, st); break;
-      default: rc = launch_fwd_h<256, 1>(d, st); break;
-    }
-    if (rc) return rc;
-    GAD_LAUNCH_CHECK("gad_attention_fwd(bf16)");
-    return 0;
-  }
-  switch (a->d) {
-    case 16: rc = wide ? launch_fwd<16, 2>(d, st) : launch_fwd<16, 1>(d, st); break;
-    case 32: rc = wide ? launch_fwd<32, 2>(d, st) : launch_fwd<32, 1>(d, st); break;
-    case 40: rc = wide ? launch_fwd<40, 2>(d, st) : launch_fwd<40, 1>(d, st); break;
-    case 64: rc = wide ? launch_fwd<64, 2>(d, st) : launch_fwd<64, 1>(d, st); break;
-    case 80: rc = wide ? launch_fwd<80, 2>(d, st) : launch_fwd<80, 1>(d, st); break;
-    case 96: rc = launch_fwd<96, 1>(d, st); break;
-    case 128: rc = launch_fwd<128, 1>(d, st); break;
-    case 160: rc = launch_fwd<160, 1>(d, st); break;
-    case 192: rc = launch_fwd<192, 1>(d, st); break;
-    case 224: rc = launch_fwd<224, 1>(d, st); break;
-    default: rc = launch_fwd<256, 1>(d, st); break;
+  int rc = 1;
+  switch (instance_dim(a->d)) {
+#define X(DIM) case DIM: rc = fwd_dim<DIM>(d, st, rg, bf16, wide); break;
+    GAD_ATTN_DIMS(X)
+#undef X
   }
   if (rc) return rc;
   GAD_LAUNCH_CHECK("gad_attention_fwd");
@@ -1063,42 +1201,14 @@ extern "C" int gad_attention_bwd(const gad_attention_args* a, void* stream) {
   GAD_CHECK(a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv, "gad_attention_bwd: null pointer (lse / d_o / delta / dq / dk / dv)");
   const int w = a->heads * a->d;
   GAD_CHECK(a->ld_do >= w && a->ld_dq >= w && a->ld_dk >= w && a->ld_dv >= w, "gad_attention_bwd: a gradient row stride is smaller than heads*d = %d", w);
-  GAD_CHECK(a->ld_do % 4 == 0 && a->ld_dq % 4 == 0 && a->ld_dk % 4 == 0 && a->ld_dv % 4 == 0, "gad_attention_bwd: gradient row strides must be multiples of 4 floats");
-  GAD_CHECK(a->stride_do % 4 == 0 && a->stride_dq % 4 == 0 && a->stride_dk % 4 == 0 && a->stride_dv % 4 == 0, "gad_attention_bwd: gradient batch strides must be multiples of 4 floats");
-  GAD_CHECK(gad_aligned16(a->d_o) && gad_aligned16(a->dq) && gad_aligned16(a->dk) && gad_aligned16(a->dv), "gad_attention_bwd: gradients must be 16-byte aligned");
-  AttnDev d = make_dev(a);
+  const AttnDev d = make_dev(a);
   hipStream_t st = (hipStream_t)stream;
-  int rc = 0;
-  if (a->operand_precision == 1) {
-    switch (a->d) {
-      case 16: rc = launch_bwd_h<16>(d, a->delta, st); break;
-      case 32: rc = launch_bwd_h<32>(d, a->delta, st); break;
-      case 40: rc = launch_bwd_h<40>(d, a->delta, st); break;
-      case 64: rc = launch_bwd_h<64>(d, a->delta, st); break;
-      case 80: rc = launch_bwd_h<80>(d, a->delta, st); break;
-      case 96: rc = launch_bwd_h<96>(d, a->delta, st); break;
-      case 128: rc = launch_bwd_h<128>(d, a->delta, st); break;
-      case 160: rc = launch_bwd_h<160>(d, a->delta, st); break;
-      case 192: rc = launch_bwd_h<192>(d, a->delta, st); break;
-      case 224: rc = launch_bwd_h<224>(d, a->delta, st); break;
-      default: rc = launch_bwd_h<256>(d, a->delta, st); break;
-    }
-    if (rc) return rc;
-    GAD_LAUNCH_CHECK("gad_attention_bwd(bf16)");
-    return 0;
-  }
-  switch (a->d) {
-    case 16: rc = launch_bwd<16>(d, a->delta, st); break;
-    case 32: rc = launch_bwd<32>(d, a->delta, st); break;
-    case 40: rc = launch_bwd<40>(d, a->delta, st); break;
-    case 64: rc = launch_bwd<64>(d, a->delta, st); break;
-    case 80: rc = launch_bwd<80>(d, a->delta, st); break;
-    case 96: rc = launch_bwd<96>(d, a->delta, st); break;
-    case 128: rc = launch_bwd<128>(d, a->delta, st); break;
-    case 160: rc = launch_bwd<160>(d, a->delta, st); break;
-    case 192: rc = launch_bwd<192>(d, a->delta, st); break;
-    case 224: rc = launch_bwd<224>(d, a->delta, st); break;
-    default: rc = launch_bwd<256>(d, a->delta, st); break;
+  const bool rg = !fast_contract(a, true), bf16 = a->operand_precision == 1;
+  int rc = 1;
+  switch (instance_dim(a->d)) {
+#define X(DIM) case DIM: rc = bwd_dim<DIM>(d, a->delta, st, rg, bf16); break;
+    GAD_ATTN_DIMS(X)
+#undef X
   }
   if (rc) return rc;
   GAD_LAUNCH_CHECK("gad_attention_bwd");

@@ -251,6 +251,36 @@ __global__ void final_sum_kernel(const float* __restrict__ part, float* __restri
 
 // ---- row softmax, one wave per row ----
 // in-place launches (p == s, ds == dp) are part of the contract: no restrict on the aliased pairs
+// 3x3 convolution weights of a flat parameter buffer, all at once, into the layout that turns a data gradient into a
+// FORWARD convolution: dst[ci][2-r][2-s][co] = src[co][r][s][ci] (180-degree rotation + channel transpose).  One
+// workgroup per (weight, 32 co x 32 ci tile): the nine taps go through a padded LDS tile so that both the reads (ci
+// contiguous) and the writes (co contiguous) are whole 128-B lines.  table[t] = {offset of the weight in both buffers,
+// Cout, Cin, co0, ci0}.
+__global__ __launch_bounds__(256) void rotate_conv3x3_kernel(const float* __restrict__ src, float* __restrict__ dst,
+                                                             const int64_t* __restrict__ table) {
+  __shared__ float tile[32][33];
+  const int64_t* e = table + 5 * (long)blockIdx.x;
+  const long off = e[0];
+  const int Cout = (int)e[1], Cin = (int)e[2], co0 = (int)e[3], ci0 = (int)e[4];
+  const int tx = threadIdx.x & 31, ty = threadIdx.x >> 5;        // 32 x 8
+  const float* S = src + off;
+  float* D = dst + off;
+  for (int tap = 0; tap < 9; ++tap) {
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int co = co0 + ty + 8 * r, ci = ci0 + tx;
+      tile[ty + 8 * r][tx] = (co < Cout && ci < Cin) ? S[((long)co * 9 + tap) * Cin + ci] : 0.f;
+    }
+    __syncthreads();
+#pragma unroll
+    for (int r = 0; r < 4; ++r) {
+      const int ci = ci0 + ty + 8 * r, co = co0 + tx;
+      if (ci < Cin && co < Cout) D[((long)ci * 9 + (8 - tap)) * Cout + co] = tile[tx][ty + 8 * r];
+    }
+    __syncthreads();
+  }
+}
+
 __global__ void softmax_fwd_kernel(const float* s, float* p, long rows, int n, float scale) {
   long row = (long)blockIdx.x * (blockDim.x >> 6) + (threadIdx.x >> 6);
   if (row >= rows) return;
@@ -409,5 +439,13 @@ extern "C" int gad_softmax_bwd(const float* p, const float* dp, float* ds, int64
   GAD_CHECK(p && dp && ds && rows > 0 && n > 0, "gad_softmax_bwd: bad args");
   hipLaunchKernelGGL(softmax_bwd_kernel, dim3((unsigned)gad_ceil_div(rows, 4)), dim3(NT), 0, ST, p, dp, ds, (long)rows, n, scale);
   GAD_LAUNCH_CHECK("gad_softmax_bwd");
+  return 0;
+}
+
+extern "C" int gad_rotate_conv3x3(const float* src, float* dst, const int64_t* table, int32_t n_tiles, void* stream) {
+  GAD_CHECK(src && dst && table && n_tiles > 0, "gad_rotate_conv3x3: null pointer or no tiles");
+  GAD_CHECK(src != dst, "gad_rotate_conv3x3: in place is not supported");
+  hipLaunchKernelGGL(rotate_conv3x3_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, table);
+  GAD_LAUNCH_CHECK("gad_rotate_conv3x3");
   return 0;
 }

@@ -1501,16 +1501,31 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 // kernel: 32 KB per 1.05 MFLOP) and computes no im2col addresses.  Partial slabs of the pixel splits go to the
 // workspace and through splitk_reduce_kernel, as for the generic split-K.
 // ------------------------------------------------------------------------------------
-template <int W>
-__global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const DevArgs p) {   // 2 waves / SIMD: <= 256 registers
-  constexpr int BM = 128;
+// Output-channel tiles.  BM = 128: wave w owns channels [32 w, 32 w + 32) and all nine taps (9 accumulator tiles).
+// BM = 96 (the pruned widths 96 / 192 that unlearn.py:363-367 fine-tunes, CelebA's 672): a 128-channel tile would leave a
+// wave idle, so the 3 channel groups x 9 taps = 27 (group, tap) units are dealt 7 / 7 / 7 / 6 to the four waves - wave w
+// owns units [7 w, 7 w + 7), which touch at most two channel groups and never repeat a tap.  Which accumulator meets which
+// fragment must be static, so the K loop is instantiated per wave (WAVE = 0..3; -1 = the BM = 128 form, wave at run time).
+template <int BM, int WAVE>
+struct WgradUnits {
+  static constexpr int U0 = BM == 128 ? 0 : 7 * WAVE;
+  static constexpr int N = BM == 128 ? 9 : (27 - U0 < 7 ? 27 - U0 : 7);
+  static constexpr int CG0 = BM == 128 ? 0 : U0 / 9;                          // BM = 128: + wave at run time
+  static constexpr bool TWO = BM != 128 && (U0 + N - 1) / 9 != CG0;            // the units span two channel groups
+  static constexpr int tap(int i) { return BM == 128 ? i : (U0 + i) % 9; }
+  static constexpr int grp(int i) { return BM == 128 ? 0 : (U0 + i) / 9 - CG0; }
+};
+
+template <int W, int BM, int WAVE>
+__device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
+  using U = WgradUnits<BM, WAVE>;
   constexpr int ROWS = BK / W;                    // image rows per K step (1 or 2)
   constexpr int PW = W + 2, PRW = ROWS + 2, NPX = PRW * PW;
   constexpr int PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;      // DMA slots per thread for the patch
   constexpr int PSIZE = PSL * 32 * BK;                            // floats (whole wave-instructions)
   constexpr int A_TILE = BK * BM;
-  using AL = ALoader<GAD_A_MC, BM, 4>;
-  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + PSIZE)];
+  constexpr int ANS = BM / 32;                    // dy-tile DMA pieces (1 KiB each) per wave
+  static_assert(ANS + PSL <= 16, "one DMA slot per pixel pair");
 
   // block -> (pixel split, co tile, ci chunk); chunks of one (split, co tile) are adjacent: they share the dy tiles in L2
   const int nci = p.g.C / BK;
@@ -1525,6 +1540,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
   const int nkt = (kend - kt0 * BK + BK - 1) / BK;
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63, h = lane >> 5, l31 = lane & 31;
+  const int cg0 = BM == 128 ? wave : U::CG0;      // first channel group of this wave's units
 
   // patch slots: slot i covers patch pixel i*32 + tid/8, float4 tid%8
   int prow[PSL], pcol[PSL];
@@ -1542,17 +1558,21 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     return sel_src(p.B, off, ok);
   };
   // Lean staging (see LeanKC above: every VALU instruction of the K step costs MFMA issue time; the general form spent ~200
-  // per step here, most of it on k0 / HW and rem / W per patch slot).  dy: fixed slot pointers (co quads beyond M clamped)
-  // plus one wave-uniform k offset.  x: a K step is ROWS whole rows of ONE image, so (image, first row) advance as scalars
-  // from step to step and a slot's address is a per-slot constant plus one uniform row offset; only the halo test
-  // (row inside the image) is per slot and step.  The fused-upsample geometry keeps the general form.
+  // per step here, most of it on k0 / HW and rem / W per patch slot).  dy: the [32 px][BM co] tile is BM / 32 pieces of
+  // 1 KiB per wave; piece (wave + 4 i) covers float4s 64 (wave + 4 i) .. + 63 of the image, i.e. pixel f4 / (BM / 4),
+  // channel quad f4 % (BM / 4) - fixed per lane (channel quads beyond M clamped) plus one wave-uniform k offset.  x: a K
+  // step is ROWS whole rows of ONE image, so (image, first row) advance as scalars from step to step and a slot's address
+  // is a per-slot constant plus one uniform row offset; only the halo test (row inside the image) is per slot and step.
+  // The fused-upsample geometry keeps the general form.
   const int wv = wave_id();
-  const float* aptr[AL::NS];
-  {
-    int c0 = row0 + MCSlots<BM>::rq4();
-    c0 = c0 < p.M ? c0 : p.M - 4;
+  const float* aptr[ANS];
 #pragma unroll
-    for (int i = 0; i < AL::NS; ++i) aptr[i] = p.A + (long)MCSlots<BM>::krow(i) * p.lda + c0;
+  for (int i = 0; i < ANS; ++i) {
+    const int f4 = (wave + 4 * i) * 64 + lane;
+    const int px = f4 / (BM / 4);
+    int c0 = row0 + (f4 - px * (BM / 4)) * 4;
+    c0 = c0 < p.M ? c0 : p.M - 4;
+    aptr[i] = p.A + (long)px * p.lda + c0;
   }
   int xoff[PSL];               // (prow * W + pcol) * ldx + ci0 + float4 column: the slot's offset from the step's row base
   unsigned colok = 0;          // slot's column inside the image (and the slot exists)
@@ -1562,10 +1582,10 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     colok |= (unsigned)(prow[i] >= 0 && pcol[i] >= 0 && pcol[i] < W) << i;
   }
   auto stage = [&](int piece, int k0, int img, int oh, float* ta, float* tp) {
-    if (piece < AL::NS) {
-      glds16(aptr[piece] + (long)k0 * p.lda, ta + (wv * (MCSlots<BM>::KSTEP / 4) + MCSlots<BM>::KSTEP * piece) * BM);
-    } else if (piece < AL::NS + PSL) {
-      const int i = piece - AL::NS;
+    if (piece < ANS) {
+      glds16(aptr[piece] + (long)k0 * p.lda, ta + (wv + 4 * piece) * 256);
+    } else if (piece < ANS + PSL) {
+      const int i = piece - ANS;
       float* dst = tp + (i * 32 + wv * 8) * BK;
       if (ups) {
         glds16(patch_src(i, k0), dst);
@@ -1578,20 +1598,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     }
   };
 
-  f32x16 acc[9];
+  f32x16 acc[U::N];
 #pragma unroll
-  for (int t = 0; t < 9; ++t)
+  for (int t = 0; t < U::N; ++t)
 #pragma unroll
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   int img = (kt0 * BK) / HW, oh = ((kt0 * BK) - img * HW) / W;      // the first step's image and first row (scalars)
   if (nkt > 0) {
 #pragma unroll
-    for (int q = 0; q < AL::NS + PSL; ++q) stage(q, kt0 * BK, img, oh, lds, lds + A_TILE);
+    for (int q = 0; q < ANS + PSL; ++q) stage(q, kt0 * BK, img, oh, lds, lds + A_TILE);
   }
   barrier_after_dma();
 
-  // fragment bases: A[(2j + h)][wave*32 + l31]; B: pixel q = 2j + h -> patch pixel (q / W) * PW + q % W (+ tap shift)
+  // fragment bases: A[(2j + h)][32 cg + l31]; B: pixel q = 2j + h -> patch pixel (q / W) * PW + q % W (+ tap shift)
   for (int kt = 0; kt < nkt; ++kt) {
     const float* la = lds + (kt & 1) * (A_TILE + PSIZE);
     const float* lp = la + A_TILE;
@@ -1600,39 +1620,56 @@ __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const D
     const int knext = (kt0 + kt + 1) * BK;
     int nimg = img, noh = oh + ROWS;
     if (noh >= p.g.Ho) { noh = 0; ++nimg; }
-    float fa[2], fb[2][9];
+    float fa[2][2], fb[2][U::N];
     auto load_frags = [&](int j, int buf) {
       const int q = 2 * j + h;
-      fa[buf] = la[q * BM + wave * 32 + l31];
+      fa[buf][0] = la[q * BM + cg0 * 32 + l31];
+      if (U::TWO) fa[buf][1] = la[q * BM + cg0 * 32 + 32 + l31];
       const float* pb = lp + ((q / W) * PW + (q % W)) * BK + l31;
 #pragma unroll
-      for (int t = 0; t < 9; ++t) fb[buf][t] = pb[((t / 3) * PW + (t % 3)) * BK];
+      for (int t = 0; t < U::N; ++t) fb[buf][t] = pb[((U::tap(t) / 3) * PW + (U::tap(t) % 3)) * BK];
     };
     load_frags(0, 0);
 #pragma unroll
     for (int j = 0; j < 16; ++j) {
       if (j + 1 < 16) load_frags(j + 1, (j + 1) & 1);
 #pragma unroll
-      for (int t = 0; t < 9; ++t)
-        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1], fb[j & 1][t], acc[t], 0, 0, 0);
-      if (more) stage(j, knext, nimg, noh, na, na + A_TILE);     // one DMA slot per pixel pair (AL::NS + PSL <= 16)
+      for (int t = 0; t < U::N; ++t)
+        acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][U::grp(t)], fb[j & 1][t], acc[t], 0, 0, 0);
+      if (more) stage(j, knext, nimg, noh, na, na + A_TILE);     // one DMA slot per pixel pair (ANS + PSL <= 16)
     }
     img = nimg;
     oh = noh;
     barrier_after_dma();
   }
 
-  // epilogue: D row = co (wave*32 + (e&3) + 8(e>>2) + 4h), D col = ci (l31); N index = tap * C + ci0 + ci
+  // epilogue: D row = co (32 cg + (e&3) + 8(e>>2) + 4h), D col = ci (l31); N index = tap * C + ci0 + ci
   const bool direct = p.splitk == 1;
   float* Cp = direct ? p.C : p.ws + (long)split * p.M * p.N;
   const int ldc = direct ? p.ldc : p.N;
 #pragma unroll
-  for (int t = 0; t < 9; ++t) {
-    const int n = t * p.g.C + ci0 + l31;
+  for (int t = 0; t < U::N; ++t) {
+    const int n = U::tap(t) * p.g.C + ci0 + l31;
 #pragma unroll
     for (int e = 0; e < 16; ++e) {
-      int m = row0 + wave * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
+      int m = row0 + (cg0 + U::grp(t)) * 32 + (e & 3) + 8 * (e >> 2) + 4 * h;
       if (m < p.M) Cp[(long)m * ldc + n] = direct ? acc[t][e] * p.alpha : acc[t][e];
+    }
+  }
+}
+
+template <int W, int BM = 128>
+__global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const DevArgs p) {   // 2 waves / SIMD: <= 256 registers
+  constexpr int ROWS = BK / W, NPX = (ROWS + 2) * (W + 2), PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (BK * BM + PSL * 32 * BK)];
+  if (BM == 128) {
+    wgrad_patch_body<W, BM, -1>(p, lds);
+  } else {                                        // every instance runs the same barriers: one per K step
+    switch (wave_id()) {
+      case 0: wgrad_patch_body<W, BM, 0>(p, lds); break;
+      case 1: wgrad_patch_body<W, BM, 1>(p, lds); break;
+      case 2: wgrad_patch_body<W, BM, 2>(p, lds); break;
+      default: wgrad_patch_body<W, BM, 3>(p, lds); break;
     }
   }
 }
@@ -1996,8 +2033,14 @@ static bool use_fewout_conv(const gad_gemm_args* a) {
          (long)a->M * g.ldx < (1L << 31) && !(a->flags & GAD_GEMM_NO_PATCH);
 }
 
-// 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible)
-static int wgrad_patch_splits(const gad_gemm_args* a) {
+// 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible) and the
+// output-channel tile: 96 where 128-channel tiles would idle a wave on a quarter or more of them (M = 96, 192, 288, 672):
+// modelled time = tiles x (accumulator units per wave: 9 at 128, 7 at 96, the latter with 5 % more fragment reads per MFMA)
+static int wgrad_patch_bm(const gad_gemm_args* a) {
+  const double c128 = (double)gad_ceil_div(a->M, 128) * 9.0, c96 = (double)gad_ceil_div(a->M, 96) * 7.0 * 1.05;
+  return (c96 < c128 && a->M % 4 == 0) ? 96 : 128;
+}
+static int wgrad_patch_splits(const gad_gemm_args* a, int* bm_out = nullptr) {
   const gad_conv_geom& g = a->g;
   if (a->flags & GAD_GEMM_NO_PATCH) return 0;
   if (use_bf16(a) || pick_vec(a) != 4 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV) return 0;
@@ -2006,7 +2049,9 @@ static int wgrad_patch_splits(const gad_gemm_args* a) {
   if (!(g.Wo == 32 || g.Wo == 16 || g.Wo == 8) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
   if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
   if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
-  const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, 128) * (g.C / BK);
+  const int bm = a->tile_hint == 1 ? 128 : wgrad_patch_bm(a);      // tile_hint 1: 128-channel tiles (A/B, tests)
+  if (bm_out) *bm_out = bm;
+  const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, bm) * (g.C / BK);
   long sp = 512 / groups;                 // one round of 2 workgroups per CU
   if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
   if (sp < 1) sp = 1;
@@ -2066,8 +2111,8 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   if (use_fewout_conv(a)) {                      // vector-ALU kernel: 256 pixels x all (<= 4) output channels
     *tile = 256;
     *splitk = 1;
-  } else if (int sp = wgrad_patch_splits(a)) {   // patch weight gradient: 128 output channels x pixel splits
-    *tile = 128;
+  } else if (int bm = 0; int sp = wgrad_patch_splits(a, &bm)) {   // patch weight gradient: 128 / 96 output channels x pixel splits
+    *tile = bm;
     *splitk = sp;
   } else if (!use_bf16(a) && use_patch_conv_f32(a, &pp)) {   // patch forward / dgrad: 128 pixels x bn channels
     *tile = pp.bn;
@@ -2216,9 +2261,10 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     GAD_LAUNCH_CHECK("gad_gemm(conv3x3 few outputs)");
     return 0;
   }
-  if (int sp = wgrad_patch_splits(a)) {
+  int wbm = 128;
+  if (int sp = wgrad_patch_splits(a, &wbm)) {
     const long ksteps = a->K / BK;
-    d.tiles_m = (int)gad_ceil_div(a->M, 128);
+    d.tiles_m = (int)gad_ceil_div(a->M, wbm);
     d.ktiles_per_split = (int)gad_ceil_div(ksteps, sp);
     d.splitk = (int)gad_ceil_div(ksteps, d.ktiles_per_split);
     if (d.splitk > 1) {
@@ -2226,9 +2272,15 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       GAD_CHECK(a->ws && a->ws_bytes >= need, "gad_gemm: wgrad workspace too small (%lld < %lld)", (long long)a->ws_bytes, (long long)need);
     }
     dim3 grid((unsigned)(d.splitk * d.tiles_m * (a->g.C / BK))), block(NTHREADS);
-    if (a->g.Wo == 32) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<32>), grid, block, 0, st, d);
-    else if (a->g.Wo == 16) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<16>), grid, block, 0, st, d);
-    else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<8>), grid, block, 0, st, d);
+#define GAD_WGRAD(W_)                                                                                   \
+    do {                                                                                                \
+      if (wbm == 96) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 96>), grid, block, 0, st, d);    \
+      else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 128>), grid, block, 0, st, d);             \
+    } while (0)
+    if (a->g.Wo == 32) GAD_WGRAD(32);
+    else if (a->g.Wo == 16) GAD_WGRAD(16);
+    else GAD_WGRAD(8);
+#undef GAD_WGRAD
     GAD_LAUNCH_CHECK("gad_gemm(wgrad3x3 patch)");
     if (d.splitk > 1) {
       launch_splitk_reduce(d, 1, st);

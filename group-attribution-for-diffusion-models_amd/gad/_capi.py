@@ -86,6 +86,7 @@ SIGNATURES = {
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_attention_supported": (C.c_int, [_i32]),
+    "gad_attention_uses_bf16": (C.c_int, [C.POINTER(AttentionArgs), _i32]),
     "gad_attention_fwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
     "gad_attention_bwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
     "gad_softmax_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),
@@ -96,6 +97,7 @@ SIGNATURES = {
     "gad_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "gad_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "gad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),
+    "gad_rotate_conv3x3": (C.c_int, [_vp, _vp, _vp, _i32, _vp]),
     "gad_silu_fwd": (C.c_int, [_vp, _vp, _i64, _vp]),
     "gad_silu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "gad_concat_channels": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _i32, _vp]),

@@ -161,13 +161,12 @@ class Attention(nn.Module):
         res = x.view(b, hh * ww, c)
         h = self.group_norm(x).view(b, hh * ww, c)                   # :1297-1298 (NHWC: no transposes needed)
         lora = any(l.lora_layer is not None for l in (self.to_q, self.to_k, self.to_v))
-        if (not torch.is_grad_enabled() and not lora and self.to_q.weight.shape[0] == c
-                and not torch.cuda.is_current_stream_capturing()):
+        if not torch.is_grad_enabled() and not lora and not torch.cuda.is_current_stream_capturing():
             # sampling: one [3C, C] projection instead of three (h is read once), q/k/v consumed in place.  Not inside a
             # hipGraph capture: a replayed graph would keep reading the cached copy after the parameters changed.
             w, bias = self._fused_qkv()
             qkv = ops.linear_fwd_raw(h.view(b * hh * ww, c), w, bias)
-            o = ops.attention_core_qkv_raw(qkv, b, hh * ww, c, self.heads)
+            o = ops.attention_core_qkv_raw(qkv, b, hh * ww, self.to_q.weight.shape[0], self.heads)   # inner dim: != c when pruned
             o = self.to_out[0](o, residual=res, scale=scale)
             return o.view(b, hh, ww, c)
         q, k, v = self.to_q(h, scale=scale), self.to_k(h, scale=scale), self.to_v(h, scale=scale)   # :1301-1309

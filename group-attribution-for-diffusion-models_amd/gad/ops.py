@@ -140,13 +140,17 @@ def set_operand_precision(name):
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
 # structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
-KERNEL_FLAGS = {"gemm": 0, "gn": 0}
+KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False}
 
 
 class kernel_flags:
-    """``with ops.kernel_flags(no_patch=True, tap_major_k=True, scalar_epilogue=True, general_loaders=True, gn_two_pass=True): ...``"""
+    """``with ops.kernel_flags(no_patch=True, tap_major_k=True, scalar_epilogue=True, general_loaders=True, gn_two_pass=True,
+    native_dgrad=True): ...``  (native_dgrad is a host-side switch: data-gradient kernels instead of forward kernels on
+    rotated weights, see `dgrad_as_forward`)"""
 
-    def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False):
+    def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
+                 native_dgrad=False):
+        self.native_dgrad = native_dgrad
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
                      | (_capi.GEMM_GENERAL_LOADERS if general_loaders else 0))
@@ -154,7 +158,7 @@ class kernel_flags:
 
     def __enter__(self):
         self.prev = dict(KERNEL_FLAGS)
-        KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"] = self.gemm, self.gn
+        KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"], KERNEL_FLAGS["native_dgrad"] = self.gemm, self.gn, self.native_dgrad
         return self
 
     def __exit__(self, *exc):
@@ -327,18 +331,62 @@ def bf16_weight(w):
     return cached[1]
 
 
-def frozen_dgrad_as_forward(w, stride, pad, upsample) -> bool:
-    """A FROZEN 3x3 / stride-1 / pad-1 weight (the SD LoRA step: every convolution of the base U-Net) lets the data
-    gradient run as a FORWARD convolution of dy with the 180-degree-rotated, channel-transposed weight: the forward patch
-    kernels (4 x 1 waves, 96 / 128 / 160-channel tiles; in bf16 mode the LDS-DMA bf16 weight stream instead of the generic
-    bf16 kernel) are faster than the data-gradient instances, and the rotated copy is made once."""
-    return (not w.requires_grad and tuple(w.shape[2:]) == (3, 3) and stride == 1 and tuple(pad) == (1, 1, 1, 1)
-            and not upsample and w.shape[0] % 32 == 0 and w.shape[1] >= 64)
+def _in_flat_buffer(w) -> bool:
+    home = getattr(w, "_gad_flat", None)
+    return home is not None and w.data_ptr() == home[0].data_ptr() + 4 * home[1]
+
+
+def dgrad_as_forward(w, stride, pad) -> bool:
+    """The data gradient of a 3x3 / stride-1 / pad-1 convolution is the FORWARD convolution of dy with the 180-degree-
+    rotated, channel-transposed weight, and the forward patch kernels (4 x 1 waves, [n][k] weight tiles read as b128, 96 /
+    128 / 160-channel tiles - no padding at the pruned widths 96 / 192 / 288; in bf16 mode the LDS-DMA bf16 weight stream)
+    are faster than the data-gradient instances (128-column tiles, [k][n] weight tiles read as dwords).  Taken when the
+    rotated copy is cheap: a FROZEN weight (the SD base U-Net under LoRA: made once) or one living in a flat parameter
+    buffer (training.flatten_params: ONE launch per optimizer step rotates every 3x3 weight of the model,
+    `gad_rotate_conv3x3`).  `kernel_flags(native_dgrad=True)` keeps the data-gradient kernels (A/B tools, tests)."""
+    return (tuple(w.shape[2:]) == (3, 3) and stride == 1 and tuple(pad) == (1, 1, 1, 1) and w.shape[0] % 32 == 0
+            and w.shape[1] >= 64 and (not w.requires_grad or _in_flat_buffer(w)) and not KERNEL_FLAGS.get("native_dgrad"))
+
+
+def _rot_table(flat):
+    """(device table, tiles) of `gad_rotate_conv3x3` for the 3x3 weights resident in `flat` - built once per buffer."""
+    cached = getattr(flat, "_gad_rot_table", None)
+    if cached is None:
+        rows = [(off, p_.shape[0], p_.shape[1], a, b)
+                for p_, off, _ in getattr(flat, "_gad_params", ()) if p_.ndim == 4 and tuple(p_.shape[2:]) == (3, 3)
+                for a in range(0, p_.shape[0], 32) for b in range(0, p_.shape[1], 32)]
+        cached = (torch.tensor(rows, dtype=torch.int64, device=flat.device), len(rows)) if rows else (None, 0)
+        flat._gad_rot_table = cached
+    return cached
 
 
 def rotated_weight(w):
     """W'[ci][2-r][2-s][co] = W[co][r][s][ci] as a conv parameter of logical shape [Cin, Cout, 3, 3] (storage
-    [Cin][3][3][Cout]), cached per weight version."""
+    [Cin][3][3][Cout]).  A weight living in a flat parameter buffer is served from ONE rotated shadow of the buffer,
+    refreshed by a single launch when the weights changed (same keys as `bf16_weight`; the returned view carries
+    `_gad_flat`, so bf16 mode casts the whole shadow once, too); any other weight caches its own copy per version."""
+    if _in_flat_buffer(w):
+        flat, off, n = w._gad_flat
+        table, tiles = _rot_table(flat)
+        key = (flat._version, WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
+        cached = getattr(flat, "_gad_rot", None)
+        stale = cached is None or cached[0] != key
+        if not stale and cached[2].get(off, w._version) != w._version:      # written through torch since the last refresh
+            stale = True
+        if stale and tiles:
+            shadow = cached[1] if cached is not None else torch.empty_like(flat)
+            check(_capi.load().gad_rotate_conv3x3(flat.data_ptr(), shadow.data_ptr(), table.data_ptr(), tiles, _stream()),
+                  "gad_rotate_conv3x3")
+            shadow._gad_epoch = getattr(shadow, "_gad_epoch", 0) + 1         # its residents changed (bf16_weight's key)
+            cached = (key, shadow, {o_: p_._version for p_, o_, _ in flat._gad_params}, cached[3] if cached is not None else {})
+            flat._gad_rot = cached
+        view = cached[3].get(off)
+        if view is None:
+            co, ci = w.shape[0], w.shape[1]
+            view = cached[1][off:off + n].view(ci, 3, 3, co).permute(0, 3, 1, 2)
+            view._gad_flat = (cached[1], off, n)
+            cached[3][off] = view
+        return view
     key = weight_key(w)
     cached = getattr(w, "_gad_rot", None)
     if cached is None or cached[0] != key:
@@ -458,8 +506,12 @@ class Conv2dFn(torch.autograd.Function):
         Bn, Ho, Wo, Cout = dy.shape
         dx = None
         if ctx.needs_input_grad[0]:
-            if frozen_dgrad_as_forward(w, stride, pad, upsample):
+            if dgrad_as_forward(w, stride, pad):
                 dx = conv2d_fwd_raw(dy, rotated_weight(w), None)
+                if upsample:                         # the conv ran on the nearest-2x grid: sum the 2 x 2 replicas
+                    dxe, dx = dx, torch.empty(x.shape, device=dy.device, dtype=torch.float32)
+                    check(_capi.load().gad_upsample2x_bwd(dxe.data_ptr(), dx.data_ptr(), x.shape[0], x.shape[1], x.shape[2],
+                                                          x.shape[3], _stream()), "gad_upsample2x_bwd")
             else:
                 dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample)
         dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o)) \
@@ -754,8 +806,10 @@ def _attn_gemm(A, B, Cm, a_mode, b_mode, M, N, K, lda, ldb, ldc, Bn, heads, sA, 
 
 
 def fused_attention_ok(d: int, *lds) -> bool:
-    """Is there a fused (flash-style) instance for this head dim / these row strides?"""
-    return bool(_capi.load().gad_attention_supported(int(d))) and all(int(x) % 4 == 0 for x in lds)
+    """Does the fused (flash-style) attention take this head dim?  Any d <= 256 does; row strides need no alignment
+    (an exact instance - 16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 224, 256 - with float4-aligned rows streams by
+    LDS-DMA, anything else - the head-grouped-pruned CelebA model's d = 23 - runs the dword-staged RG instance)."""
+    return bool(_capi.load().gad_attention_supported(int(d)))
 
 
 def _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, sq, sk, sv):

@@ -177,8 +177,12 @@ int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
  * CelebA-HQ) and the self / cross attentions of the SD U-Net (head dims 40 / 80 / 160, Tk = Tq or 77;
  * text_to_image/train_text_to_image_lora.py:1268-1270).
  * Operands are [B][T][heads*d]-shaped views: row r of batch b, head h starts at base + b*stride + r*ld + h*d, so q, k, v
- * may be column blocks of one fused [B*T][3C] projection output (ld = 3C).  d in {16, 32, 40, 64, 80, 96, 128, 160, 192, 224, 256} (gad_attention_supported); every ld
- * and stride a multiple of 4 floats, every pointer 16-byte aligned.
+ * may be column blocks of one fused [B*T][3C] projection output (ld = 3C).  Any head dim 1 <= d <= 256
+ * (gad_attention_supported).  Launches with d in {16, 24, 32, 40, 48, 64, 80, 96, 128, 160, 192, 224, 256}, every ld and
+ * stride a multiple of 4 floats and every pointer 16-byte aligned stream their tiles by LDS-DMA; any other head dim or
+ * alignment - the head-grouped-pruned CelebA-HQ model keeps its heads and shrinks the head dim 32 -> 23
+ * (unconditional_generation/prune.py:337-342): rows of 322 floats - runs the next larger instance in its dword-staged
+ * form (always exact fp32: gad_attention_uses_bf16 tells).
  * fwd writes o and, if lse != NULL, lse[b][h][q] = log2(sum_k exp2(scale*log2(e)*(q.k)))  (the statistics the backward
  * pass recomputes the probabilities from).  bwd needs q, k, v, o, lse, d_o and a caller-owned scratch `delta` of
  * B*heads*Tq floats; it writes dq, dk, dv (no atomics: every element is written once, bit-reproducibly).
@@ -197,7 +201,8 @@ typedef struct gad_attention_args {
   int32_t operand_precision;/* 0: exact fp32 products (v_mfma_f32_16x16x4_f32); 1: operands rounded to bf16 (RNE), fp32
                              * accumulation and softmax statistics (v_mfma_f32_16x16x32_bf16) - the autocast analogue */
 } gad_attention_args;
-int gad_attention_supported(int32_t d);      /* 1 if head dim d has a fused instance */
+int gad_attention_supported(int32_t d);      /* 1 if 1 <= d <= 256 */
+int gad_attention_uses_bf16(const gad_attention_args* a, int32_t backward);   /* 1 if this launch multiplies bf16 operands */
 int gad_attention_fwd(const gad_attention_args* a, void* stream);
 int gad_attention_bwd(const gad_attention_args* a, void* stream);
 
@@ -235,6 +240,12 @@ int gad_timestep_embedding(const int64_t* t, float* out, int32_t B, int32_t dim,
 /* y = x*sigmoid(x) ; dx = dy * s(1 + x(1-s)) */
 int gad_silu_fwd(const float* x, float* y, int64_t n, void* stream);
 int gad_silu_bwd(const float* x, const float* dy, float* dx, int64_t n, void* stream);
+/* Rotated copies of the 3x3 conv weights that live in one flat parameter buffer, in ONE launch:
+ *   dst[off + ((ci*3 + 2-r)*3 + 2-s)*Cout + co] = src[off + ((co*3 + r)*3 + s)*Cin + ci]
+ * i.e. W'[ci][2-r][2-s][co] = W[co][r][s][ci]: with W' the data gradient of a 3x3 / stride-1 / pad-1 convolution IS the
+ * forward convolution of dy (same kernels, same channel tiles).  table (device, int64[n_tiles][5]) = {off, Cout, Cin,
+ * co0, ci0}, one row per 32 x 32 (co, ci) tile of every listed weight; src != dst.  Refreshed once per optimizer step. */
+int gad_rotate_conv3x3(const float* src, float* dst, const int64_t* table, int32_t n_tiles, void* stream);
 /* out[p][0:C1] = a[p][0:C1], out[p][C1:C1+C2] = b[p][0:C2]  (skip-connection concat, NHWC) */
 int gad_concat_channels(const float* a, const float* b, float* out, int64_t pixels, int32_t C1, int32_t C2,
                         void* stream);

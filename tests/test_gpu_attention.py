@@ -118,11 +118,73 @@ def test_fused_attention_is_bit_reproducible_and_leaves_no_score_tensor():
 
 def test_attention_argument_contract():
     from gad import _capi, ops
-    q = rnd(1, 8, 24, seed=1).to(dev)
-    assert not ops.fused_attention_ok(24, 24) and ops.fused_attention_ok(40, 320) and not ops.fused_attention_ok(40, 322)
-    a = ops._attention_args(q, q, q, q, None, 1, 1, 8, 8, 24, 24, 24, 24, 192, 192, 192)
-    with pytest.raises(_capi.GadError, match="no instance"):
+    q = rnd(1, 8, 300, seed=1).to(dev)
+    assert ops.fused_attention_ok(24, 24) and ops.fused_attention_ok(40, 322) and ops.fused_attention_ok(23, 322)
+    assert ops.fused_attention_ok(256, 256) and not ops.fused_attention_ok(257, 257) and not ops.fused_attention_ok(0, 8)
+    a = ops._attention_args(q, q, q, q, None, 1, 1, 8, 8, 300, 300, 300, 300, 2400, 2400, 2400)
+    with pytest.raises(_capi.GadError, match="outside 1..256"):
         _capi.check(_capi.load().gad_attention_fwd(_capi.C.byref(a), ops._stream()), "gad_attention_fwd")
+    a = ops._attention_args(q, q, q, q, None, 1, 2, 8, 8, 40, 40, 80, 80, 320, 640, 640)      # ldq < heads * d
+    with pytest.raises(_capi.GadError, match="row stride"):
+        _capi.check(_capi.load().gad_attention_fwd(_capi.C.byref(a), ops._stream()), "gad_attention_fwd")
+
+
+# Any head dim, any alignment: the head-grouped-pruned CelebA-HQ model keeps its 14 / 21 / 28 heads and shrinks the head
+# dim 32 -> 23 (reference unconditional_generation/prune.py:337-342; rows of 322 / 483 / 644 floats), pruned SD-style
+# widths give 20 or 46; 7 x 9 = 63-float rows, a head dim below one MFMA step, a wide odd head and an exact instance
+# behind an unaligned row stride (q | k | v blocks of a 3 x 322-wide projection) take the same dword-staged instances.
+RAGGED = [  # B, Tq, Tk, heads, d
+    (2, 1024, 1024, 14, 23), (2, 256, 256, 21, 23), (3, 64, 64, 28, 23), (2, 100, 77, 8, 20), (1, 130, 95, 5, 46),
+    (2, 40, 40, 7, 9), (1, 33, 50, 3, 3), (1, 70, 70, 2, 100), (1, 48, 40, 1, 200), (1, 64, 64, 1, 250),
+]
+
+
+@pytest.mark.parametrize("B,Tq,Tk,heads,d", RAGGED)
+def test_fused_attention_any_head_dim_vs_fp64(B, Tq, Tk, heads, d):
+    from gad import ops
+    C = heads * d
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.7), rnd(B, Tk, C, seed=2, scale=0.7), rnd(B, Tk, C, seed=3)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    o = sdpa64(qd, kd, vd, heads)
+    do = rnd(B, Tq, C, seed=4)
+    o.backward(do.double())
+    gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    base = torch.cuda.memory_allocated(dev)
+    torch.cuda.reset_peak_memory_stats(dev)
+    # the product's router must pick the fused kernels (the one exception it makes: TRAINING at one wide head, d > 160,
+    # over <= 256 x 256 scores, see ops.attention_core)
+    out = ops.attention_core(gq, gk, gv, heads) if d <= 160 else ops.attention_core_fused(gq, gk, gv, heads)
+    assert torch.cuda.max_memory_allocated(dev) - base < 4 * B * heads * Tq * Tk or B * heads * Tq * Tk < (1 << 16), \
+        "a score tensor was allocated: the launch went through the three-launch route"
+    out.backward(do.to(dev))
+    for got, want, tol in ((out, o, 3e-5), (gq.grad, qd.grad, 6e-5), (gk.grad, kd.grad, 6e-5), (gv.grad, vd.grad, 6e-5)):
+        err = (got.detach().cpu().double() - want.detach()).abs().max().item()
+        assert err < tol, err
+    # bit-reproducible, and bf16 mode falls back to the same exact-fp32 instances for these launches
+    uq, uk, uv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+    with ops.operand_precision("bf16"):
+        again = ops.attention_core_fused(uq, uk, uv, heads)
+        again.backward(do.to(dev))
+    assert torch.equal(again, out) and torch.equal(uq.grad, gq.grad) and torch.equal(uk.grad, gk.grad) and torch.equal(uv.grad, gv.grad)
+
+
+def test_fused_attention_exact_instance_behind_unaligned_rows():
+    """q | k | v as column blocks of one [B T, 3 x 322]-wide projection (the sampling path of a pruned model): head dim 23
+    at row stride 966, block offsets 322 and 644 floats - and a d = 32 instance whose rows are 4-float aligned but whose
+    base pointer is not."""
+    from gad import ops
+    B, T, heads, d = 2, 64, 14, 23
+    C = heads * d
+    qkv = rnd(B * T, 3 * C, seed=5, scale=0.7).to(dev)
+    got = ops.attention_core_qkv_raw(qkv, B, T, C, heads)
+    q, k, v = (qkv[:, i * C:(i + 1) * C].reshape(B, T, C).cpu().double() for i in range(3))
+    assert (got.cpu().double() - sdpa64(q, k, v, heads)).abs().max().item() < 3e-5
+    heads, d = 3, 32
+    C = heads * d
+    buf = rnd(3 * B * T * C + 1, seed=6, scale=0.7).to(dev)
+    q, k, v = (buf[1 + i * B * T * C: 1 + (i + 1) * B * T * C].view(B, T, C) for i in range(3))      # 4-byte aligned only
+    out, _ = ops.attention_fwd_raw(q, k, v, B, heads, T, T, d, C, C, C)
+    assert (out.cpu().double() - sdpa64(q.cpu().double(), k.cpu().double(), v.cpu().double(), heads)).abs().max().item() < 3e-5
 
 
 @pytest.mark.parametrize("B,Tq,Tk,heads,d", [(2, 256, 256, 1, 256), (2, 64, 64, 7, 32), (2, 256, 256, 8, 40), (2, 64, 77, 4, 40),

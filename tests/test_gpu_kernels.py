@@ -838,7 +838,7 @@ def test_frozen_weight_data_gradient_runs_as_forward_conv(ops, prec, B, Cin, Cou
     w = torch.nn.Parameter(rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last), requires_grad=False)
     dy = rnd(B, H, H, Cout, seed=3).to(dev)
     with gad.operand_precision(prec):
-        assert ops.frozen_dgrad_as_forward(w, 1, (1, 1, 1, 1), False)
+        assert ops.dgrad_as_forward(w, 1, (1, 1, 1, 1))
         y = ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), False)
         y.backward(dy)
         dx_direct = ops.conv2d_dgrad_raw(dy, w, x.shape)
@@ -854,6 +854,55 @@ def test_frozen_weight_data_gradient_runs_as_forward_conv(ops, prec, B, Cin, Cou
     with gad.operand_precision(prec):
         ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), False).backward(dy)
     close(x.grad, 2.0 * want, rtol=tol, atol=tol)
+
+
+@pytest.mark.parametrize("prec", ["f32", "bf16"])
+def test_trainable_weights_in_a_flat_buffer_take_the_rotated_shadow(ops, prec):
+    """Parameters living in a flat buffer (training.flatten_params): ONE `gad_rotate_conv3x3` launch rotates every 3x3
+    weight, the data gradients run as forward convolutions on the shadow - also behind the fused nearest-2x upsample -
+    and must equal the data-gradient kernels (fp64 autograd as the referee).  The shadow must follow an optimizer-style
+    rewrite of the buffer (epoch bump) and a write through torch (version bump of one parameter)."""
+    import gad
+    from gad.training import flatten_params
+    shapes = [(96, 64, False, 16), (192, 96, True, 8), (64, 288, False, 8), (32, 3, False, 8)]   # Cout, Cin, upsample, H; the last is not eligible
+    ws = [torch.nn.Parameter(rnd(co, ci, 3, 3, seed=10 + i, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last))
+          for i, (co, ci, _, _) in enumerate(shapes)]
+    extra = torch.nn.Parameter(rnd(77, seed=20).to(dev))                       # a non-conv resident between them
+    flat, _ = flatten_params([ws[0], extra] + ws[1:])
+    assert [ops.dgrad_as_forward(w, 1, (1, 1, 1, 1)) for w in ws] == [True, True, True, False]
+
+    def run(w, ci, up, H, native):
+        x = rnd(2, H, H, ci, seed=3).to(dev).requires_grad_(True)
+        with gad.operand_precision(prec), ops.kernel_flags(native_dgrad=native):
+            y = ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), up)
+            dy = rnd(*y.shape, seed=4).to(dev)
+            y.backward(dy)
+        return x, dy, x.grad
+
+    def check_all():
+        for w, (co, ci, up, H) in zip(ws[:3], shapes[:3]):
+            w.grad = None
+            x, dy, dx = run(w, ci, up, H, native=False)
+            _, _, dx_native = run(w, ci, up, H, native=True)
+            xr = x.detach().permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+            xe = F.interpolate(xr, scale_factor=2.0, mode="nearest") if up else xr
+            F.conv2d(xe, w.detach().double().cpu(), padding=1).backward(dy.permute(0, 3, 1, 2).double().cpu())
+            tol = 3e-5 if prec == "f32" else 2e-2
+            close(dx, xr.grad.permute(0, 2, 3, 1), rtol=tol, atol=tol)
+            close(dx, dx_native, rtol=tol, atol=tol)
+
+    check_all()
+    shadow = flat._gad_rot[1]
+    got = shadow[ws[1]._gad_flat[1]:][:ws[1].numel()].view(96, 3, 3, 192)      # [ci][2-r][2-s][co]
+    assert torch.equal(got, ops.weight_krsc(ws[1]).detach().flip(1, 2).permute(3, 1, 2, 0))
+    with torch.no_grad():
+        flat.detach().mul_(1.5)                                                 # what the raw optimizer kernel does ...
+    flat._gad_epoch = getattr(flat, "_gad_epoch", 0) + 1                        # ... and how it announces it
+    check_all()
+    with torch.no_grad():
+        ws[2].copy_(ws[2] * 0.25)                                               # through torch: only ws[2]._version moves
+    check_all()
+    assert flat._gad_rot[1] is shadow                                           # refreshed in place, one buffer
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
