@@ -1519,8 +1519,10 @@ struct WgradUnits {
 template <int W, int BM, int WAVE>
 __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
   using U = WgradUnits<BM, WAVE>;
-  constexpr int ROWS = BK / W;                    // image rows per K step (1 or 2)
-  constexpr int PW = W + 2, PRW = ROWS + 2, NPX = PRW * PW;
+  // a K step is 32 consecutive pixels: WS = min(W, 32) columns of ROWS = 32 / WS image rows (W = 64: half a row - the
+  // step's first column `seg` alternates 0 / 32 and the halo columns seg - 1, seg + 32 come from the same row)
+  constexpr int WS = W < BK ? W : BK, ROWS = BK / WS;
+  constexpr int PW = WS + 2, PRW = ROWS + 2, NPX = PRW * PW;
   constexpr int PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;      // DMA slots per thread for the patch
   constexpr int PSIZE = PSL * 32 * BK;                            // floats (whole wave-instructions)
   constexpr int A_TILE = BK * BM;
@@ -1552,7 +1554,7 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
   }
   auto patch_src = [&](int i, int k0) -> const float* {
     int img = k0 / HW, rem = k0 - img * HW;
-    int ih = rem / W - 1 + prow[i], iw = pcol[i];
+    int ih = rem / W - 1 + prow[i], iw = (W > WS ? rem % W : 0) + pcol[i];
     bool ok = k0 < kend && ih >= 0 && ih < p.g.Ho && iw >= 0 && iw < W;
     long off = ((long)(img * p.g.H + (ih >> ups)) * p.g.W + (iw >> ups)) * p.g.ldx + ci0 + (tid & 7) * 4;
     return sel_src(p.B, off, ok);
@@ -1581,7 +1583,7 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
     xoff[i] = prow[i] >= 0 ? (prow[i] * W + pcol[i]) * p.g.ldx + ci0 + (tid & 7) * 4 : 0;
     colok |= (unsigned)(prow[i] >= 0 && pcol[i] >= 0 && pcol[i] < W) << i;
   }
-  auto stage = [&](int piece, int k0, int img, int oh, float* ta, float* tp) {
+  auto stage = [&](int piece, int k0, int img, int oh, int seg, float* ta, float* tp) {
     if (piece < ANS) {
       glds16(aptr[piece] + (long)k0 * p.lda, ta + (wv + 4 * piece) * 256);
     } else if (piece < ANS + PSL) {
@@ -1591,8 +1593,9 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
         glds16(patch_src(i, k0), dst);
       } else {
         const int ih = oh - 1 + prow[i];
-        const bool ok = ((colok >> i) & 1u) && ih >= 0 && ih < p.g.Ho;
-        const long rowbase = ((long)img * p.g.H + (oh - 1)) * W * p.g.ldx;     // wave-uniform
+        bool ok = ((colok >> i) & 1u) && ih >= 0 && ih < p.g.Ho;
+        if (W > WS) ok = prow[i] >= 0 && ih >= 0 && ih < p.g.Ho && seg + pcol[i] >= 0 && seg + pcol[i] < W;
+        const long rowbase = (((long)img * p.g.H + (oh - 1)) * W + seg) * p.g.ldx;     // wave-uniform
         glds16(sel_src(p.B, rowbase + xoff[i], ok), dst);
       }
     }
@@ -1605,9 +1608,10 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
     for (int e = 0; e < 16; ++e) acc[t][e] = 0.f;
 
   int img = (kt0 * BK) / HW, oh = ((kt0 * BK) - img * HW) / W;      // the first step's image and first row (scalars)
+  int seg = W > WS ? ((kt0 * BK) - img * HW) % W : 0;              // ... and first column
   if (nkt > 0) {
 #pragma unroll
-    for (int q = 0; q < ANS + PSL; ++q) stage(q, kt0 * BK, img, oh, lds, lds + A_TILE);
+    for (int q = 0; q < ANS + PSL; ++q) stage(q, kt0 * BK, img, oh, seg, lds, lds + A_TILE);
   }
   barrier_after_dma();
 
@@ -1618,14 +1622,19 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
     float* na = lds + ((kt + 1) & 1) * (A_TILE + PSIZE);
     const bool more = kt + 1 < nkt;                                  // nothing is staged after the last step
     const int knext = (kt0 + kt + 1) * BK;
-    int nimg = img, noh = oh + ROWS;
+    int nimg = img, noh = oh + ROWS, nseg = 0;
+    if (W > WS) {
+      nseg = seg + WS;
+      noh = oh;
+      if (nseg >= W) { nseg = 0; noh = oh + 1; }
+    }
     if (noh >= p.g.Ho) { noh = 0; ++nimg; }
     float fa[2][2], fb[2][U::N];
     auto load_frags = [&](int j, int buf) {
       const int q = 2 * j + h;
       fa[buf][0] = la[q * BM + cg0 * 32 + l31];
       if (U::TWO) fa[buf][1] = la[q * BM + cg0 * 32 + 32 + l31];
-      const float* pb = lp + ((q / W) * PW + (q % W)) * BK + l31;
+      const float* pb = lp + ((q / WS) * PW + (q % WS)) * BK + l31;
 #pragma unroll
       for (int t = 0; t < U::N; ++t) fb[buf][t] = pb[((U::tap(t) / 3) * PW + (U::tap(t) % 3)) * BK];
     };
@@ -1636,10 +1645,11 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
 #pragma unroll
       for (int t = 0; t < U::N; ++t)
         acc[t] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[j & 1][U::grp(t)], fb[j & 1][t], acc[t], 0, 0, 0);
-      if (more) stage(j, knext, nimg, noh, na, na + A_TILE);     // one DMA slot per pixel pair (ANS + PSL <= 16)
+      if (more) stage(j, knext, nimg, noh, nseg, na, na + A_TILE);     // one DMA slot per pixel pair (ANS + PSL <= 16)
     }
     img = nimg;
     oh = noh;
+    seg = nseg;
     barrier_after_dma();
   }
 
@@ -1660,7 +1670,7 @@ __device__ __forceinline__ void wgrad_patch_body(const DevArgs& p, float* lds) {
 
 template <int W, int BM = 128>
 __global__ __launch_bounds__(NTHREADS, 2) void wgrad3x3_patch_f32_kernel(const DevArgs p) {   // 2 waves / SIMD: <= 256 registers
-  constexpr int ROWS = BK / W, NPX = (ROWS + 2) * (W + 2), PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;
+  constexpr int WS = W < BK ? W : BK, ROWS = BK / WS, NPX = (ROWS + 2) * (WS + 2), PSL = (NPX * 8 + NTHREADS - 1) / NTHREADS;
   __shared__ __attribute__((aligned(16))) float lds[2 * (BK * BM + PSL * 32 * BK)];
   if (BM == 128) {
     wgrad_patch_body<W, BM, -1>(p, lds);
@@ -2046,7 +2056,7 @@ static int wgrad_patch_splits(const gad_gemm_args* a, int* bm_out = nullptr) {
   if (use_bf16(a) || pick_vec(a) != 4 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV) return 0;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1) return 0;
   if (g.Ho != (g.upsample ? 2 * g.H : g.H) || g.Wo != (g.upsample ? 2 * g.W : g.W)) return 0;
-  if (!(g.Wo == 32 || g.Wo == 16 || g.Wo == 8) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
+  if (!(g.Wo == 64 || g.Wo == 32 || g.Wo == 16 || g.Wo == 8) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
   if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
   if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
   const int bm = a->tile_hint == 1 ? 128 : wgrad_patch_bm(a);      // tile_hint 1: 128-channel tiles (A/B, tests)
@@ -2277,7 +2287,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       if (wbm == 96) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 96>), grid, block, 0, st, d);    \
       else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 128>), grid, block, 0, st, d);             \
     } while (0)
-    if (a->g.Wo == 32) GAD_WGRAD(32);
+    if (a->g.Wo == 64) GAD_WGRAD(64);
+    else if (a->g.Wo == 32) GAD_WGRAD(32);
     else if (a->g.Wo == 16) GAD_WGRAD(16);
     else GAD_WGRAD(8);
 #undef GAD_WGRAD

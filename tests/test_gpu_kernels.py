@@ -130,6 +130,60 @@ def test_conv_bwd(ops, case):
     close(db, b.grad, atol=1e-5 * math.sqrt(B * y.shape[-1] * y.shape[-2]))
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,ups", [(8, 64, 96, 32, False), (4, 96, 192, 16, False), (4, 192, 288, 8, False),
+                                              (2, 64, 672, 16, False), (4, 96, 192, 16, True), (16, 288, 96, 32, False),
+                                              (2, 64, 96, 64, False), (3, 32, 192, 32, True)])
+def test_wgrad_patch_kernel_96_channel_tiles(ops, B, Cin, Cout, H, ups):
+    """Weight gradient of a 3x3 convolution whose output-channel count is a multiple of 96 but not of 128 (the pruned
+    widths 96 / 192 that unlearn.py:363-367 fine-tunes, 288, CelebA's 672): the patch kernel deals the 3 channel groups x
+    9 taps of a 96-channel tile 7 / 7 / 7 / 6 to its four waves instead of idling a wave in a 128-channel tile.  Against
+    fp64 autograd and against the 128-channel instance (tile_hint = 1) on the same inputs."""
+    x = rnd(B, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05)
+    He = 2 * H if ups else H
+    dy = rnd(B, Cout, He, He, seed=6)
+    xd = x.double().requires_grad_(True)
+    wd = w.double().requires_grad_(True)
+    conv_ref(xd, wd, None, 1, (1, 1, 1, 1), ups).backward(dy.double())
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        dw = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), ups)
+        dw128 = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), ups, tile_hint=1)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    keys = list(prof.summary())
+    assert [k[0] for k in keys] == [f"conv_wgrad_patch_w{He}"] * len(keys) and sorted(k[1] for k in keys) == [96, 128], keys
+    tol = 3e-5 * math.sqrt(B * He * He / 16)
+    close(dw, wd.grad, atol=tol)
+    close(dw, dw128, atol=tol)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,ups", [(2, 64, 224, 64, False), (2, 160, 160, 64, False), (1, 224, 128, 32, True), (3, 32, 64, 64, False)])
+def test_wgrad_patch_kernel_64_wide_maps(ops, B, Cin, Cout, H, ups):
+    """The 64x64 level of the CelebA-HQ LDM U-Net (ddpm_config.py:425-450: 224 channels, 160 pruned): a K step of the patch
+    weight-gradient kernel is half an image row there (columns 0-31 / 32-63 alternate, halo columns from the same row).
+    Against fp64 autograd and the im2col-gather kernel (no_patch)."""
+    x = rnd(B, Cin, H, H, seed=1)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05)
+    He = 2 * H if ups else H
+    dy = rnd(B, Cout, He, He, seed=6)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    conv_ref(xd, wd, None, 1, (1, 1, 1, 1), ups).backward(dy.double())
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        dw = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), ups)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    assert [k[0] for k in prof.summary()] == ["conv_wgrad_patch_w64"], list(prof.summary())
+    with ops.kernel_flags(no_patch=True):
+        dw_gather = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), ups)
+    tol = 3e-5 * math.sqrt(B * He * He / 16)
+    close(dw, wd.grad, atol=tol)
+    close(dw, dw_gather, atol=tol)
+
+
 def test_conv_autograd_function(ops):
     B, Cin, Cout, H = 2, 64, 96, 8
     x, w, b, t, r = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3), rnd(B, Cout, seed=4), rnd(B, Cout, H, H, seed=5)
