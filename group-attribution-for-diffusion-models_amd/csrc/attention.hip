@@ -65,6 +65,7 @@ struct AttnDev {
   int ldq, ldk, ldv, ldo, lddo, lddq, lddk, lddv;       // row strides (floats)
   long sq, sk, sv, so, sdo, sdq, sdk, sdv;              // batch strides (floats)
   float scale;                                           // 1/sqrt(d)
+  float* ws;                                             // single-pass backward: dQ partial slabs [key block][B][Tq][heads*d]
 };
 
 // Fill a [KV][S] row-major tile with rows row0 .. row0+KV-1 of `base` (row stride ld, D valid columns, T valid rows);
@@ -645,6 +646,245 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_f32_kernel(const AttnDev p) {
   }
 }
 
+// ------------------------------------------------------------------------------------------------------------------
+// Single-pass backward (head dims up to 96): ONE kernel computes S and dP once and feeds all three gradients - the five
+// products of the minimal scheme (10 B h Tq Tk d FLOPs) instead of the seven the dQ + dK/dV pair executes.
+//   workgroup = one block of KB = 64 NK keys of one (b, h); wave w owns key tiles j < NK at keys 16 (NK w + j); K and V
+//   row fragments of those keys are loop-invariant registers, dK^T / dV^T accumulate in registers for the whole sweep
+//   (as in the dK/dV kernel); Q / dO tiles of 32 queries stream through the double-buffered LDS tiles.
+//   dQ contracts over KEYS - the lane index of the dS accumulators - so dS crosses LDS once: every wave writes its
+//   [32 q][16 NK keys] block into a [32][KB] image; one barrier later (the loop's own: the image is double-buffered and
+//   tile it-1's dQ is computed at the top of iteration it) the workgroup computes dQ^T[kdim][q] = K^T dS^T over all KB
+//   keys with the output tiles dealt round-robin to the waves.  K sits in LDS TRANSPOSED ([kdim][key], written once per
+//   workgroup), so both operands of that product are ds_read_b128 - four MFMA steps per read (a row-major K image costs a
+//   dword read per MFMA: the LDS issue rate, not the matrix pipe, then paces the phase).
+//   Key blocks of one (b, h) each hold a partial dQ: it goes to slab [block] of the caller's workspace and
+//   `attn_dq_reduce_kernel` sums the slabs in block order - no atomics, every element written once in a fixed order, so a
+//   training step stays bit-reproducible.  A single key block (cross attention, Tk = 77) writes dQ directly.
+// ------------------------------------------------------------------------------------------------------------------
+template <int D, int NK>
+struct Bwd1 {
+  using C = Cfg<D>;
+  static constexpr int KB = 64 * NK;
+  static constexpr int SQ = KB + 20;                 // dS image row stride: (4 g + e) * SQ covers both bank halves; 16-B aligned
+  static constexpr int KIMG = (C::DP * SQ + 3) / 4 * 4;                  // floats: the block's K, TRANSPOSED: [kdim][key]
+  static constexpr int DSIMG = 32 * SQ;
+  static constexpr int LDS_FLOATS = KIMG + 4 * C::TILE + 2 * DSIMG;
+  static constexpr int NOUT = 2 * C::NDV;            // dQ output tiles (16 kdim x 16 q) per 32-query tile
+};
+
+template <int D, int NK, bool RG>
+__global__ __launch_bounds__(NT) void attn_bwd1_f32_kernel(const AttnDev p) {
+  using C = Cfg<D>;
+  using W = Bwd1<D, NK>;
+  constexpr int KB = W::KB, SQ = W::SQ;
+  extern __shared__ __attribute__((aligned(16))) float lds[];
+  float* const kimg = lds;                           // [DP][SQ]  K of this block, transposed: kimg[kdim][key] (zeros past Tk / d)
+  float* const stream = lds + W::KIMG;               // [2][Q tile | dO tile]
+  float* const dsimg = stream + 4 * C::TILE;         // [2][32 q][SQ]
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * p.d;
+  const float* DO = p.d_o + b * p.sdo + h * p.d;
+  const float* Kp = p.k + b * p.sk + h * p.d;
+  const float* Vp = p.v + b * p.sv + h * p.d;
+  const int key0 = blk * KB + wave * (16 * NK);
+
+  float kf[NK][C::KS], vf[NK][C::KS];
+  bool kok[NK];
+  f32x4 dk[NK][C::NDV], dv[NK][C::NDV];
+#pragma unroll
+  for (int j = 0; j < NK; ++j) {
+    const int key = key0 + 16 * j + c;
+    kok[j] = key < p.Tk;
+    row_frag_global<D, RG>(Kp, p.ldk, key, kok[j], p.scale * LOG2E, kf[j], p.d);
+    row_frag_global<D, RG>(Vp, p.ldv, key, kok[j], 1.f, vf[j], p.d);
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) { dk[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[j][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
+  const float* lse = p.lse + (long)bh * p.Tq;
+  const float* dlt = p.delta + (long)bh * p.Tq;
+  const bool vec_stats = p.Tq % 4 == 0 && (reinterpret_cast<uintptr_t>(p.lse) & 15) == 0 && (reinterpret_cast<uintptr_t>(p.delta) & 15) == 0;
+
+  // the K image (transposed): zero everything once (pad rows kdim >= d, keys past Tk), then scatter the block's K
+  for (int i = threadIdx.x * 4; i < W::LDS_FLOATS; i += NT * 4) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
+  __syncthreads();
+  if (RG) {
+    for (int e = threadIdx.x; e < KB * D; e += NT) {
+      const int row = e / D, col = e - row * D;
+      if (blk * KB + row < p.Tk && col < p.d) kimg[col * SQ + row] = Kp[(long)(blk * KB + row) * p.ldk + col];
+    }
+  } else {
+    for (int e = threadIdx.x; e < KB * (D / 4); e += NT) {
+      const int row = e / (D / 4), col = (e - row * (D / 4)) * 4;
+      if (blk * KB + row < p.Tk) {
+        const f32x4 v4 = *reinterpret_cast<const f32x4*>(Kp + (long)(blk * KB + row) * p.ldk + col);
+#pragma unroll
+        for (int x = 0; x < 4; ++x) kimg[(col + x) * SQ + row] = v4[x];
+      }
+    }
+  }
+  const int ntiles = (p.Tq + KV - 1) / KV;
+  Stream<D, RG> qs, gs;
+  qs.init(p.ldq);
+  gs.init(p.lddo);
+  {                                  // first Q / dO tiles (the RG form zeroed the whole LDS above)
+    qs.issue(stream, Q, p.ldq, 0, p.Tq, p.d);
+    gs.issue(stream + C::TILE, DO, p.lddo, 0, p.Tq, p.d);
+    qs.commit(stream);
+    gs.commit(stream + C::TILE);
+    barrier_after_dma();
+  }
+
+  // dQ of query tile `tq` from the dS image it left behind: output tile o = (i = o % NDV, t = o / NDV) -> wave o % 4
+  const bool direct = p.nblk == 1;
+  auto dq_phase = [&](int tq) {
+    const float* dsb = dsimg + (tq & 1) * W::DSIMG;
+#pragma unroll
+    for (int oo = 0; oo < (W::NOUT + 3) / 4; ++oo) {
+      const int o = wave + 4 * oo;
+      if (o >= W::NOUT) break;                       // wave-uniform
+      const int i = o % C::NDV, t = o / C::NDV;
+      f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};      // two chains: the f32 MFMA's dependent latency
+      const float* brow = dsb + (16 * t + c) * SQ + 4 * g;          // dS[q = 16 t + c][keys 16 m + 4 g ..+3]
+      const float* arow = kimg + (16 * i + c) * SQ + 4 * g;         // K^T[kdim = 16 i + c][the same keys]
+#pragma unroll 2
+      for (int m = 0; m < KB / 16; m += 2) {
+        const f32x4 b0 = *reinterpret_cast<const f32x4*>(brow + 16 * m), b1 = *reinterpret_cast<const f32x4*>(brow + 16 * m + 16);
+        const f32x4 a0 = *reinterpret_cast<const f32x4*>(arow + 16 * m), a1 = *reinterpret_cast<const f32x4*>(arow + 16 * m + 16);
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          acc0 = mfma16(a0[e], b0[e], acc0);
+          acc1 = mfma16(a1[e], b1[e], acc1);
+        }
+      }
+      const f32x4 acc = acc0 + acc1;
+      const int q = tq * KV + 16 * t + c;
+      if (q < p.Tq) {
+        if (direct) {
+          store_cols<D, RG>(p.dq + b * p.sdq + h * p.d + (long)q * p.lddq, 16 * i + 4 * g, acc * p.scale, p.d);
+        } else {       // slab [blk][b][q][heads*d], dense rows of heads*d floats
+          const int wd = p.heads * p.d;
+          float* row = p.ws + (((long)blk * p.B + b) * p.Tq + q) * wd + h * p.d;
+          store_cols<D, RG>(row, 16 * i + 4 * g, acc, p.d);
+        }
+      }
+    }
+  };
+
+  for (int it = 0; it < ntiles; ++it) {
+    const float* qt_ = stream + (it & 1) * (2 * C::TILE);
+    const float* dot_ = qt_ + C::TILE;
+    float* const nb = stream + ((it + 1) & 1) * (2 * C::TILE);
+    float* const dsw = dsimg + (it & 1) * W::DSIMG;
+    const bool more = it + 1 < ntiles;
+    if (more) {
+      qs.issue(nb, Q, p.ldq, (it + 1) * KV, p.Tq, p.d);
+      gs.issue(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq, p.d);
+    }
+    if (it > 0) dq_phase(it - 1);
+#pragma unroll
+    for (int t = 0; t < 2; ++t) {
+      f32x4 pr[NK], ds[NK];
+      {
+        float qf[C::KS], gf[C::KS];
+        row_frag_lds<D>(qt_, 16 * t, qf);
+        row_frag_lds<D>(dot_, 16 * t, gf);
+        f32x4 L4, d4;
+        const int q0 = it * KV + 16 * t + 4 * g;
+        if ((it + 1) * KV <= p.Tq && vec_stats) {
+          L4 = *reinterpret_cast<const f32x4*>(lse + q0);
+          d4 = *reinterpret_cast<const f32x4*>(dlt + q0);
+        } else {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const bool qok = q0 + e < p.Tq;
+            L4[e] = qok ? lse[q0 + e] : __builtin_inff();          // exp2(s - inf) = 0: rows past Tq contribute nothing
+            d4[e] = qok ? dlt[q0 + e] : 0.f;
+          }
+        }
+#pragma unroll
+        for (int j = 0; j < NK; ++j) {
+          f32x4 sacc = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+          for (int st = 0; st < C::KS; ++st) {
+            sacc = mfma16(qf[st], kf[j][st], sacc);              // S[q][key]
+            dp = mfma16(gf[st], vf[j][st], dp);                  // dP[q][key] = dO V^T
+          }
+#pragma unroll
+          for (int e = 0; e < 4; ++e) {
+            const float pe = kok[j] ? ex2(sacc[e] - L4[e]) : 0.f;     // keys past Tk: no probability, no dS
+            pr[j][e] = pe;
+            ds[j][e] = pe * (dp[e] - d4[e]);
+          }
+          // dS block -> image [q][key] for the dQ product of the next iteration
+          float* drow = dsw + (16 * t + 4 * g) * SQ + 16 * (NK * wave + j) + c;
+#pragma unroll
+          for (int e = 0; e < 4; ++e) drow[e * SQ] = ds[j][e];
+        }
+      }
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* grow = dot_ + (16 * t + 4 * g + e) * C::S + c;
+        const float* qrow = qt_ + (16 * t + 4 * g + e) * C::S + c;
+#pragma unroll
+        for (int i = 0; i < C::NDV; ++i) {
+          const float ag = grow[16 * i], aq = qrow[16 * i];
+#pragma unroll
+          for (int j = 0; j < NK; ++j) {
+            dv[j][i] = mfma16(ag, pr[j][e], dv[j][i]);           // dV^T[dv][key] += dO^T[dv][q] P[q][key]
+            dk[j][i] = mfma16(aq, ds[j][e], dk[j][i]);           // dK^T[k][key]  += Q^T[k][q]  dS[q][key]
+          }
+        }
+      }
+    }
+    if (RG && more) {
+      qs.commit(nb);
+      gs.commit(nb + C::TILE);
+    }
+    barrier_after_dma();
+  }
+  dq_phase(ntiles - 1);
+#pragma unroll
+  for (int j = 0; j < NK; ++j)
+    if (kok[j]) {
+      const int key = key0 + 16 * j + c;
+      float* DK = p.dk + b * p.sdk + h * p.d + (long)key * p.lddk;
+      float* DV = p.dv + b * p.sdv + h * p.d + (long)key * p.lddv;
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        store_cols<D, RG>(DK, 16 * i + 4 * g, dk[j][i] * p.scale, p.d);
+        store_cols<D, RG>(DV, 16 * i + 4 * g, dv[j][i], p.d);
+      }
+    }
+}
+
+// dq[b][q][:] = scale * sum over key blocks (in block order) of slab[block][b][q][:]
+__global__ void attn_dq_reduce_kernel(const AttnDev p, int nslab, int vec) {
+  const int wd = p.heads * p.d;
+  const long rows = (long)p.B * p.Tq, slab = rows * wd;
+  if (vec) {
+    const int w4 = wd / 4;
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < rows * w4; idx += (long)gridDim.x * blockDim.x) {
+      const long r = idx / w4;
+      const int c4 = (int)(idx - r * w4) * 4;
+      f32x4 acc = *reinterpret_cast<const f32x4*>(p.ws + r * wd + c4);
+      for (int s = 1; s < nslab; ++s) acc += *reinterpret_cast<const f32x4*>(p.ws + s * slab + r * wd + c4);
+      const long bq = r / p.Tq;
+      *reinterpret_cast<f32x4*>(p.dq + bq * p.sdq + (r - bq * p.Tq) * p.lddq + c4) = acc * p.scale;
+    }
+  } else {
+    for (long idx = (long)blockIdx.x * blockDim.x + threadIdx.x; idx < rows * wd; idx += (long)gridDim.x * blockDim.x) {
+      const long r = idx / wd;
+      const int cc = (int)(idx - r * wd);
+      float acc = p.ws[r * wd + cc];
+      for (int s = 1; s < nslab; ++s) acc += p.ws[s * slab + r * wd + cc];
+      const long bq = r / p.Tq;
+      p.dq[bq * p.sdq + (r - bq * p.Tq) * p.lddq + cc] = acc * p.scale;
+    }
+  }
+}
+
 // ==================================================================================================================
 // bf16-operand instances (gad_attention_args.operand_precision = 1; the analogue of the reference's fp16 autocast for
 // configs 4 / 5): the same three kernels on v_mfma_f32_16x16x32_bf16 - operands rounded to bf16 (RNE), products exact,
@@ -1092,6 +1332,7 @@ static AttnDev make_dev(const gad_attention_args* a) {
   d.sq = a->stride_q; d.sk = a->stride_k; d.sv = a->stride_v; d.so = a->stride_o;
   d.sdo = a->stride_do; d.sdq = a->stride_dq; d.sdk = a->stride_dk; d.sdv = a->stride_dv;
   d.scale = a->scale;
+  d.ws = (float*)a->ws;
   return d;
 }
 
@@ -1137,6 +1378,63 @@ static int launch_bwd(AttnDev d, float* delta, hipStream_t st) {
   return 0;
 }
 
+// ---- single-pass backward: plan and launch ---------------------------------------------------------------------------
+// keys per workgroup = 64 NK; NK <= 4 up to d = 40, <= 2 up to 80, 1 at 96 (dK / dV accumulators + the K / V fragments of
+// NK key tiles per wave must fit the register file); among those the NK with the fewest padded keys, ties to the larger
+// (fewer dQ slabs: a single block writes dQ directly)
+static int bwd1_nk(int dinst, int Tk, long bh, int Tq) {
+  if (dinst > 96) return 0;
+  const int nkmax = dinst <= 40 ? 4 : dinst <= 80 ? 2 : 1;
+  int best = 0;
+  long best_pad = 0;
+  for (int nk = 1; nk <= nkmax; nk *= 2) {
+    const long nblk = gad_ceil_div(Tk, 64 * nk), pad = nblk * 64 * nk;
+    if (bh * nblk < 512 && nk > 1) continue;               // keep two workgroups per CU in flight
+    if (!best || pad <= best_pad) { best_pad = pad; best = nk; }
+  }
+  // few keys, many queries (cross attention over 77 text tokens at 64 x 64 latents): a key block per workgroup leaves
+  // most of the chip idle, the dQ kernel of the pair is parallel over the queries - keep the pair there
+  if (best == 1 && bh * gad_ceil_div(Tk, 64) < 512 && bh * gad_ceil_div(Tq, 128) > 4 * bh * gad_ceil_div(Tk, 64)) return 0;
+  return best;
+}
+static int64_t bwd1_ws_bytes(const gad_attention_args* a) {
+  const int nk = bwd1_nk(instance_dim(a->d), a->Tk, (long)a->B * a->heads, a->Tq);
+  if (!nk) return 0;
+  const long nblk = gad_ceil_div(a->Tk, 64 * nk);
+  return nblk > 1 ? nblk * (int64_t)a->B * a->Tq * a->heads * a->d * (int64_t)sizeof(float) : 0;
+}
+
+template <int D, int NK, bool RG>
+static int launch_bwd1(AttnDev d, float* delta, hipStream_t st) {
+  using W = Bwd1<D, NK>;
+  static unsigned lds_set = 0;
+  const int bytes = W::LDS_FLOATS * (int)sizeof(float);
+  if (set_lds(attn_bwd1_f32_kernel<D, NK, RG>, bytes, "gad_attention_bwd", &lds_set)) return 1;
+  const long total = (long)d.B * d.Tq * d.heads;
+  hipLaunchKernelGGL((attn_delta_kernel<D, RG>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
+  const dim3 grid = grid_of(d, d.Tk, W::KB);
+  GAD_CHECK(d.nblk == 1 || d.ws, "gad_attention_bwd: %d key blocks but no dQ slab workspace", d.nblk);   // never a null store
+  hipLaunchKernelGGL((attn_bwd1_f32_kernel<D, NK, RG>), grid, dim3(NT), bytes, st, d);
+  if (d.nblk > 1) {
+    const int wd = d.heads * d.d;
+    const int vec = wd % 4 == 0 && d.lddq % 4 == 0 && d.sdq % 4 == 0 && gad_aligned16(d.dq) && gad_aligned16(d.ws);
+    const long n = (long)d.B * d.Tq * (vec ? wd / 4 : wd);
+    const long blocks = gad_ceil_div(n, 256);
+    hipLaunchKernelGGL(attn_dq_reduce_kernel, dim3((unsigned)(blocks < 4096 ? blocks : 4096)), dim3(256), 0, st, d, d.nblk, vec);
+  }
+  return 0;
+}
+template <int D, bool RG>
+static int bwd1_dim(const AttnDev& d, float* delta, hipStream_t st, int nk) {
+  if constexpr (D <= 96) {
+    if (nk == 1) return launch_bwd1<D, 1, RG>(d, delta, st);
+    if constexpr (D <= 80) { if (nk == 2) return launch_bwd1<D, 2, RG>(d, delta, st); }
+    if constexpr (D <= 40) { if (nk == 4) return launch_bwd1<D, 4, RG>(d, delta, st); }
+  }
+  gad_set_error("gad_attention_bwd: no single-pass instance for d = %d, NK = %d", D, nk);
+  return 1;
+}
+
 template <int D>
 static int launch_bwd_h(AttnDev d, float* delta, hipStream_t st) {
   using C = CfgH<D>;
@@ -1165,13 +1463,20 @@ static int fwd_dim(const AttnDev& d, hipStream_t st, bool rg, bool bf16, bool wi
   return launch_fwd<D, 1, false>(d, st);
 }
 template <int D>
-static int bwd_dim(const AttnDev& d, float* delta, hipStream_t st, bool rg, bool bf16) {
+static int bwd_dim(const AttnDev& d, float* delta, hipStream_t st, bool rg, bool bf16, int nk1) {
+  if (nk1) return rg ? bwd1_dim<D, true>(d, delta, st, nk1) : bwd1_dim<D, false>(d, delta, st, nk1);
   if (rg) return launch_bwd<D, true>(d, delta, st);
   if (bf16) return launch_bwd_h<D>(d, delta, st);
   return launch_bwd<D, false>(d, delta, st);
 }
 
 }  // namespace
+
+extern "C" int64_t gad_attention_bwd_workspace_bytes(const gad_attention_args* a) {
+  if (!a || !gad_attention_supported(a->d) || a->B <= 0 || a->heads <= 0 || a->Tq <= 0 || a->Tk <= 0) return 0;
+  if (a->operand_precision == 1 && fast_contract(a, true)) return 0;        // bf16 launches run the two-kernel pair
+  return bwd1_ws_bytes(a);
+}
 
 // 1 if this launch runs bf16-operand kernels (operand_precision = 1 AND the float4 contract holds; RG launches are fp32)
 extern "C" int gad_attention_uses_bf16(const gad_attention_args* a, int32_t backward) {
@@ -1204,9 +1509,16 @@ extern "C" int gad_attention_bwd(const gad_attention_args* a, void* stream) {
   const AttnDev d = make_dev(a);
   hipStream_t st = (hipStream_t)stream;
   const bool rg = !fast_contract(a, true), bf16 = a->operand_precision == 1;
+  // single-pass kernel: exact-fp32 launches up to d = 96 whose dQ slabs fit the caller's workspace (flags bit 0 keeps the
+  // dQ + dK/dV pair: A/B tools, tests); everything else - wider heads, bf16 operands - runs the pair
+  int nk1 = (bf16 && !rg) || (a->flags & GAD_ATTN_TWO_KERNEL_BWD) ? 0 : bwd1_nk(instance_dim(a->d), a->Tk, (long)a->B * a->heads, a->Tq);
+  if (nk1) {
+    const int64_t need = bwd1_ws_bytes(a);
+    if (need > 0 && !(a->ws && a->ws_bytes >= need && gad_aligned16(a->ws))) nk1 = 0;
+  }
   int rc = 1;
   switch (instance_dim(a->d)) {
-#define X(DIM) case DIM: rc = bwd_dim<DIM>(d, a->delta, st, rg, bf16); break;
+#define X(DIM) case DIM: rc = bwd_dim<DIM>(d, a->delta, st, rg, bf16, nk1); break;
     GAD_ATTN_DIMS(X)
 #undef X
   }

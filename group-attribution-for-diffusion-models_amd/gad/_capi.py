@@ -56,7 +56,11 @@ class AttentionArgs(C.Structure):
                 ("ld_do", C.c_int32), ("ld_dq", C.c_int32), ("ld_dk", C.c_int32), ("ld_dv", C.c_int32),
                 ("stride_q", C.c_int64), ("stride_k", C.c_int64), ("stride_v", C.c_int64), ("stride_o", C.c_int64),
                 ("stride_do", C.c_int64), ("stride_dq", C.c_int64), ("stride_dk", C.c_int64), ("stride_dv", C.c_int64),
-                ("scale", C.c_float), ("operand_precision", C.c_int32)]
+                ("scale", C.c_float), ("operand_precision", C.c_int32),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("flags", C.c_int32)]
+
+
+ATTN_TWO_KERNEL_BWD = 1
 
 
 class AdamArgs(C.Structure):
@@ -87,6 +91,7 @@ SIGNATURES = {
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_attention_supported": (C.c_int, [_i32]),
     "gad_attention_uses_bf16": (C.c_int, [C.POINTER(AttentionArgs), _i32]),
+    "gad_attention_bwd_workspace_bytes": (_i64, [C.POINTER(AttentionArgs)]),
     "gad_attention_fwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
     "gad_attention_bwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
     "gad_softmax_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _f32, _vp]),

@@ -140,7 +140,7 @@ def set_operand_precision(name):
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
 # structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
-KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False}
+KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False}
 
 
 class kernel_flags:
@@ -149,8 +149,8 @@ class kernel_flags:
     rotated weights, see `dgrad_as_forward`)"""
 
     def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
-                 native_dgrad=False):
-        self.native_dgrad = native_dgrad
+                 native_dgrad=False, two_kernel_attn_bwd=False):
+        self.native_dgrad, self.two_kernel_attn_bwd = native_dgrad, two_kernel_attn_bwd
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
                      | (_capi.GEMM_GENERAL_LOADERS if general_loaders else 0))
@@ -159,6 +159,7 @@ class kernel_flags:
     def __enter__(self):
         self.prev = dict(KERNEL_FLAGS)
         KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"], KERNEL_FLAGS["native_dgrad"] = self.gemm, self.gn, self.native_dgrad
+        KERNEL_FLAGS["two_kernel_attn_bwd"] = self.two_kernel_attn_bwd
         return self
 
     def __exit__(self, *exc):
@@ -871,6 +872,11 @@ class AttentionCoreFn(torch.autograd.Function):
         a.stride_do = a.stride_dq = Tq * Cq
         a.stride_dk = a.stride_dv = Tk * Cq
         a.operand_precision = ctx.prec                   # the precision the forward's LSE was computed in
+        a.flags = _capi.ATTN_TWO_KERNEL_BWD if KERNEL_FLAGS.get("two_kernel_attn_bwd") else 0
+        need = _capi.load().gad_attention_bwd_workspace_bytes(C.byref(a))
+        if need:                                         # dQ partial slabs of the single-pass kernel (one per key block)
+            slabs = torch.empty(need // 4, device=q.device, dtype=torch.float32)
+            a.ws, a.ws_bytes = slabs.data_ptr(), need
         if PROFILER is not None:
             PROFILER.attention(_capi.load().gad_attention_bwd, a, "bwd")
         else:

@@ -185,7 +185,10 @@ int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
  * form (always exact fp32: gad_attention_uses_bf16 tells).
  * fwd writes o and, if lse != NULL, lse[b][h][q] = log2(sum_k exp2(scale*log2(e)*(q.k)))  (the statistics the backward
  * pass recomputes the probabilities from).  bwd needs q, k, v, o, lse, d_o and a caller-owned scratch `delta` of
- * B*heads*Tq floats; it writes dq, dk, dv (no atomics: every element is written once, bit-reproducibly).
+ * B*heads*Tq floats; it writes dq, dk, dv (no atomics: every element is written once, bit-reproducibly).  Exact-fp32
+ * launches up to d = 96 run ONE kernel per key block (S and dP computed once: the five products of the minimal scheme); key
+ * blocks of one (b, h) leave dQ partials in `ws` and a fixed-order reduce sums them.  Wider heads and bf16-operand
+ * launches run a dQ kernel + a dK/dV kernel that each recompute S and dP.
  * ---------------------------------------------------------------------------- */
 typedef struct gad_attention_args {
   const float* q; const float* k; const float* v;
@@ -200,7 +203,13 @@ typedef struct gad_attention_args {
   float scale;              /* 1/sqrt(d)                                                      */
   int32_t operand_precision;/* 0: exact fp32 products (v_mfma_f32_16x16x4_f32); 1: operands rounded to bf16 (RNE), fp32
                              * accumulation and softmax statistics (v_mfma_f32_16x16x32_bf16) - the autocast analogue */
+  void* ws;                 /* bwd: caller-owned workspace of gad_attention_bwd_workspace_bytes(args) bytes (16-byte aligned)
+                             * for the single-pass kernel's dQ partial slabs; NULL / too small: the dQ + dK/dV kernel pair runs */
+  int64_t ws_bytes;
+  int32_t flags;            /* GAD_ATTN_* */
 } gad_attention_args;
+#define GAD_ATTN_TWO_KERNEL_BWD 1   /* bwd: keep the recomputing dQ + dK/dV kernel pair (A/B tools, tests) */
+int64_t gad_attention_bwd_workspace_bytes(const gad_attention_args* a);
 int gad_attention_supported(int32_t d);      /* 1 if 1 <= d <= 256 */
 int gad_attention_uses_bf16(const gad_attention_args* a, int32_t backward);   /* 1 if this launch multiplies bf16 operands */
 int gad_attention_fwd(const gad_attention_args* a, void* stream);

@@ -116,6 +116,31 @@ def test_fused_attention_is_bit_reproducible_and_leaves_no_score_tensor():
     assert peak_fwd <= 2 * (4 * B * T * C + 4 * B * heads * T) + (1 << 20)
 
 
+@pytest.mark.parametrize("B,Tq,Tk,heads,d", [(1, 2048, 2048, 2, 40), (2, 300, 700, 3, 23), (2, 64, 77, 4, 40), (1, 1000, 1030, 2, 32),
+                                           (1, 520, 260, 2, 80), (1, 200, 130, 1, 96), (2, 256, 256, 14, 32), (1, 96, 4100, 1, 24)])
+def test_single_pass_backward_vs_the_two_kernel_pair_and_fp64(B, Tq, Tk, heads, d):
+    """Head dims up to 96 run ONE backward kernel per key block (S and dP once; dQ partial slabs + fixed-order reduce when
+    a (b, h) has several key blocks: Tk = 2048 at d = 40 is 8 slabs, Tk = 77 writes dQ directly).  Same gradients as the
+    recomputing dQ + dK/dV pair (`kernel_flags(two_kernel_attn_bwd=True)`) and as fp64 autograd; bit-reproducible."""
+    from gad import ops
+    C = heads * d
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.7), rnd(B, Tk, C, seed=2, scale=0.7), rnd(B, Tk, C, seed=3)
+    do = rnd(B, Tq, C, seed=4)
+    qd, kd, vd = (t.double().requires_grad_(True) for t in (q, k, v))
+    sdpa64(qd, kd, vd, heads).backward(do.double())
+    grads = []
+    for pair in (False, True, False):
+        gq, gk, gv = (t.to(dev).requires_grad_(True) for t in (q, k, v))
+        with ops.kernel_flags(two_kernel_attn_bwd=pair):
+            ops.attention_core_fused(gq, gk, gv, heads).backward(do.to(dev))
+        grads.append((gq.grad, gk.grad, gv.grad))
+    for one, two, again, want in zip(grads[0], grads[1], grads[2], (qd.grad, kd.grad, vd.grad)):
+        assert torch.equal(one, again)
+        scale = want.abs().max().item()
+        assert (one.cpu().double() - want).abs().max().item() < 6e-5 * max(1.0, scale)
+        assert (one - two).abs().max().item() < 6e-5 * max(1.0, scale)
+
+
 def test_attention_argument_contract():
     from gad import _capi, ops
     q = rnd(1, 8, 300, seed=1).to(dev)

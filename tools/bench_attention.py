@@ -16,7 +16,8 @@ SHAPES = [  # name, B, Tq, Tk, heads, d
     ("sd512 self 32x32", 16, 1024, 1024, 8, 80), ("sd512 self 16x16", 16, 256, 256, 8, 160),
     ("sd256 self 32x32", 64, 1024, 1024, 8, 40), ("sd256 cross 32x32", 64, 1024, 77, 8, 40),
     ("sd256 self 16x16", 64, 256, 256, 8, 80), ("sd256 self 8x8", 64, 64, 64, 8, 160),
-    ("celeba 32x32", 32, 1024, 1024, 14, 32), ("cifar train 16x16", 128, 256, 256, 1, 256),
+    ("celeba 32x32", 32, 1024, 1024, 14, 32), ("celeba 16x16", 32, 256, 256, 21, 32), ("celeba-pruned 32x32", 32, 1024, 1024, 14, 23),
+    ("celeba-pruned 16x16", 32, 256, 256, 21, 23), ("cifar train 16x16", 128, 256, 256, 1, 256),
     ("cifar sample 16x16", 1024, 256, 256, 1, 256), ("cifar-pruned sample", 1024, 256, 256, 1, 192),
 ]
 
@@ -36,9 +37,13 @@ for name, B, Tq, Tk, h, d in SHAPES:
     do = torch.randn(B, Tq, C, device=dev, generator=g)
     unit = B * h * Tq * Tk * d
     res = {}
-    for route, fn in (("fused", ops.attention_core), ("3-launch", ops.attention_core_unfused)):
+    def pair(*a):                      # fused forward, recomputing dQ + dK/dV backward pair (the round-2 backward)
+        return ops.attention_core_fused(*a)
+    for route, fn in (("fused", ops.attention_core_fused if d <= 160 else ops.attention_core), ("2-kernel-bwd", pair), ("3-launch", ops.attention_core_unfused)):
         if route == "3-launch" and 4 * B * h * Tq * Tk * 3 > 40e9:
             continue
+        if route == "2-kernel-bwd" and d > 96:
+            continue                   # the pair IS the backward there
         tf, tb = [], []
         for r in range(ROUNDS + 1):
             qq, kk, vv = (t.clone().requires_grad_(True) for t in (q, k, v))
@@ -47,7 +52,8 @@ for name, B, Tq, Tk, h, d in SHAPES:
                 global out_
                 out_ = fn(qq, kk, vv, h)
             t1 = ev_time(fwd)
-            t2 = ev_time(lambda: out_.backward(do))
+            with ops.kernel_flags(two_kernel_attn_bwd=(route == "2-kernel-bwd")):
+                t2 = ev_time(lambda: out_.backward(do))
             if r:
                 tf.append(t1); tb.append(t2)
         res[route] = (sorted(tf)[len(tf) // 2], sorted(tb)[len(tb) // 2])
