@@ -361,7 +361,9 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     d = summ[dom_key]
     nm = dom_key[0]
     if nm.startswith("attn_"):
-        kname = f"attn_{'fwd' if 'fwd' in nm else 'bwd_dq + attn_bwd_dkv'}_f32_kernel<{nm.rsplit('_d', 1)[1]}> ({nm}, Tq={dom_key[1]}, Tk={dom_key[2]})"
+        dd = int(nm.rsplit('_d', 1)[1])
+        kern_ = "attn_fwd" if "fwd" in nm else ("attn_bwd1" if dd <= 96 else "attn_bwd_dq + attn_bwd_dkv")     # single-pass backward up to d = 96
+        kname = f"{kern_}_f32_kernel<{dd}> ({nm}, Tq={dom_key[1]}, Tk={dom_key[2]}" + (", incl. attn_delta + attn_dq_reduce" if "bwd" in nm else "") + ")"
     elif "_patch" in nm:      # the name rocprofv3 shows for it
         wo = int(nm.rsplit("_w", 1)[1])
         ni = {8: 2, 4: 8}.get(wo, 1)

@@ -361,7 +361,7 @@ __global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restric
                                                           float* __restrict__ dx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, float* __restrict__ part,
-                                                          SlabGeo s, int silu) {
+                                                          SlabGeo s, int silu, const float* __restrict__ dx_add) {
   __shared__ f32x4 red_a[NTH], red_b[NTH];
   __shared__ float s_m1[64], s_m2[64];
   int b, sl;
@@ -431,6 +431,7 @@ __global__ __launch_bounds__(NTH) void gn_bwd_slab_kernel(const float* __restric
       f32x4 o;
 #pragma unroll
       for (int e = 0; e < 4; ++e) o[e] = rs[e] * (ge[i][e] * ga[e] - m1[e] - xh[i][e] * m2[e]);
+      if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + base + (long)p * s.C);     // the bypass branch's gradient
       *reinterpret_cast<f32x4*>(dx + base + (long)p * s.C) = o;
     }
   }
@@ -492,7 +493,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
                                                           float* __restrict__ dx, const float* __restrict__ gamma,
                                                           const float* __restrict__ beta, const float* __restrict__ mean,
                                                           const float* __restrict__ rstd, const float* __restrict__ part,
-                                                          Geo g, int silu) {
+                                                          Geo g, int silu, const float* __restrict__ dx_add) {
   __shared__ float s_a[MAXC], s_b[MAXC];     // per channel sums (gamma-weighted)
   __shared__ float s_s1[256], s_s2[256];     // per group
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
@@ -545,6 +546,7 @@ __global__ __launch_bounds__(NT) void gn_bwd_apply_kernel(const float* __restric
         float ge = act_grad(d[e], xh[e] * ga[e] + be[e], silu);
         o[e] = rs[e] * (ge * ga[e] - m1[e] - xh[e] * m2[e]);
       }
+      if (dx_add) o += *reinterpret_cast<const f32x4*>(dx_add + base + (long)p * g.C);
       *reinterpret_cast<f32x4*>(dx + base + (long)p * g.C) = o;
     }
   }
@@ -625,6 +627,7 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
 extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream) {
   if (check(a, "gad_groupnorm_silu_bwd")) return 1;
   GAD_CHECK(a->dy && gad_aligned16(a->dy) && ((a->dgamma == nullptr) == (a->dbeta == nullptr)), "gad_groupnorm_silu_bwd: null/unaligned grad pointer");
+  GAD_CHECK(!a->dx_add || gad_aligned16(a->dx_add), "gad_groupnorm_silu_bwd: dx_add must be 16-byte aligned");
   Geo g = make_geo(a);
   hipStream_t st = (hipStream_t)stream;
   if (!(a->flags & GAD_GN_TWO_PASS)) {
@@ -636,7 +639,7 @@ extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream)
       float* part = (float*)a->ws;
       dim3 sgrid(a->B * sg.nslab);
 #define GAD_GNB(NV_, NTH_) hipLaunchKernelGGL((gn_bwd_slab_kernel<NV_, NTH_>), sgrid, dim3(NTH_), 0, st, a->x, a->dy, a->y, a->gamma, \
-                                              a->beta, a->mean, a->rstd, part, sg, a->silu)
+                                              a->beta, a->mean, a->rstd, part, sg, a->silu, a->dx_add)
       if (nth == NT) {              // (the 8-slot instance is not built: hipcc allocates it 256 registers + scratch)
         if (nv <= 4) GAD_GNB(4, NT);
         else GAD_GNB(16, NT);
@@ -656,7 +659,7 @@ extern "C" int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream)
   dim3 grid(a->B * g.nch), block(NT);
   hipLaunchKernelGGL(gn_bwd_stats_kernel, grid, block, 0, st, a->x, a->dy, a->gamma, a->beta, a->mean, a->rstd, (float*)a->ws, g, a->silu);
   GAD_LAUNCH_CHECK("gn_bwd_stats");
-  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a->x, a->dy, a->y, a->gamma, a->beta, a->mean, a->rstd, (const float*)a->ws, g, a->silu);
+  hipLaunchKernelGGL(gn_bwd_apply_kernel, grid, block, 0, st, a->x, a->dy, a->y, a->gamma, a->beta, a->mean, a->rstd, (const float*)a->ws, g, a->silu, a->dx_add);
   GAD_LAUNCH_CHECK("gn_bwd_apply");
   // dbeta[c] = sum parts[.][c][0], dgamma[c] = sum parts[.][c][1]: a column sum of the [B*nch][2C] partials -
   // skipped when the caller wants no affine gradients (dgamma == dbeta == NULL: frozen norms of LoRA training)

@@ -50,7 +50,7 @@ __global__ __launch_bounds__(NT) void ln_fwd_kernel(const float* __restrict__ x,
 __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ x, const float* __restrict__ dy,
                                                     float* __restrict__ dx, const float* __restrict__ gamma,
                                                     const float* __restrict__ mean, const float* __restrict__ rstd,
-                                                    float* __restrict__ part, long rows, int C) {
+                                                    float* __restrict__ part, long rows, int C, const float* __restrict__ dx_add) {
   __shared__ float red[2 * 2048];
   const int lane = threadIdx.x & 63, wave = threadIdx.x >> 6, C4 = C >> 2;
   f32x4 ag[MAXV], ab[MAXV];
@@ -83,7 +83,11 @@ __global__ __launch_bounds__(NT) void ln_bwd_kernel(const float* __restrict__ x,
 #pragma unroll
     for (int i = 0; i < MAXV; ++i) {
       int c = lane + 64 * i;
-      if (c < C4) xo[c] = (g[i] - m1 - xh[i] * m2) * rs;
+      if (c < C4) {
+        f32x4 o = (g[i] - m1 - xh[i] * m2) * rs;
+        if (dx_add) o += reinterpret_cast<const f32x4*>(dx_add + row * C)[c];      // the residual branch's gradient
+        xo[c] = o;
+      }
     }
   }
   // combine the 4 waves' per-channel partials -> part[block][2][C]   (rows: 0 = dgamma, 1 = dbeta)
@@ -171,16 +175,17 @@ extern "C" int gad_layernorm_fwd(const float* x, float* y, const float* gamma, c
   return 0;
 }
 
-extern "C" int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* mean,
-                                 const float* rstd, float* dgamma_dbeta, int64_t rows, int32_t C, void* ws, int64_t ws_bytes,
-                                 void* stream) {
+extern "C" int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* dx_add, const float* gamma,
+                                 const float* mean, const float* rstd, float* dgamma_dbeta, int64_t rows, int32_t C, void* ws,
+                                 int64_t ws_bytes, void* stream) {
   GAD_CHECK(x && dy && dx && gamma && mean && rstd && rows > 0, "gad_layernorm_bwd: bad args");
   GAD_CHECK(C % 4 == 0 && C <= 2048 && gad_aligned16(x) && gad_aligned16(dy) && gad_aligned16(dx) && gad_aligned16(gamma),
             "gad_layernorm_bwd: needs C%%4==0, C<=2048, 16-B alignment (C=%d)", C);
   GAD_CHECK(ws && ws_bytes >= gad_layernorm_workspace_bytes(rows, C), "gad_layernorm_bwd: workspace too small");
+  GAD_CHECK(!dx_add || gad_aligned16(dx_add), "gad_layernorm_bwd: dx_add must be 16-byte aligned");
   int nb = ln_blocks(rows);
   float* part = (float*)ws;
-  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, x, dy, dx, gamma, mean, rstd, part, (long)rows, C);
+  hipLaunchKernelGGL(ln_bwd_kernel, dim3(nb), dim3(NT), 0, (hipStream_t)stream, x, dy, dx, gamma, mean, rstd, part, (long)rows, C, dx_add);
   GAD_LAUNCH_CHECK("gad_layernorm_bwd");
   if (dgamma_dbeta) {      // NULL: frozen affine parameters (LoRA training) - no reduction of the partials
     gad_reduce::launch(part, dgamma_dbeta, nullptr, 1, nb, 2 * C, part + (long)nb * 2 * C, (hipStream_t)stream);   // [2C] = dgamma | dbeta

@@ -45,7 +45,7 @@ class GroupNormArgs(C.Structure):
                 ("dgamma", C.c_void_p), ("dbeta", C.c_void_p),
                 ("B", C.c_int32), ("HW", C.c_int32), ("C", C.c_int32), ("G", C.c_int32),
                 ("eps", C.c_float), ("silu", C.c_int32), ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
-                ("x2", C.c_void_p), ("C1", C.c_int32), ("flags", C.c_int32)]
+                ("x2", C.c_void_p), ("C1", C.c_int32), ("flags", C.c_int32), ("dx_add", C.c_void_p)]
 
 
 class AttentionArgs(C.Structure):
@@ -98,7 +98,7 @@ SIGNATURES = {
     "gad_softmax_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _f32, _vp]),
     "gad_layernorm_workspace_bytes": (_i64, [_i64, _i32]),
     "gad_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
-    "gad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
+    "gad_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp, _i64, _vp]),
     "gad_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "gad_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
     "gad_timestep_embedding": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _f32, _f32, _vp]),

@@ -102,6 +102,11 @@ class GroupNorm(nn.Module):
             return ops.group_norm_cat_raw(x, x2, self.weight, self.bias, self.num_groups, self.eps, silu)
         return ops.group_norm(x, self.weight, self.bias, self.num_groups, self.eps, silu)
 
+    def with_bypass(self, x, silu=False):
+        """(norm(x), alias of x for the block's residual branch): the backward sums both gradients in the norm's own
+        kernel instead of an elementwise launch (ops.GroupNormBypassFn)."""
+        return ops.group_norm_bypass(x, self.weight, self.bias, self.num_groups, self.eps, silu)
+
 
 # ----------------------------------------------------------------------------------
 # blocks
@@ -118,7 +123,10 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb_act, x2=None):
         """x2: the block input is cat([x, x2], channels) (up blocks); norm1 and conv_shortcut read both in place."""
-        h = self.norm1(x, silu=True, x2=x2)
+        if x2 is None:
+            h, x = self.norm1.with_bypass(x, silu=True)              # x: this node's alias, for the shortcut below
+        else:
+            h = self.norm1(x, silu=True, x2=x2)
         h = self.conv1(h, rowadd=self.time_emb_proj(temb_act))       # conv + bias + temb add, one kernel
         h = self.norm2(h, silu=True)
         sc = self.conv_shortcut(x, x2=x2) if self.conv_shortcut is not None else x
@@ -158,8 +166,9 @@ class Attention(nn.Module):
 
     def forward(self, x, scale: float = 1.0):
         b, hh, ww, c = x.shape
+        h, x = self.group_norm.with_bypass(x)                        # :1297-1298 (NHWC: no transposes needed); x: alias for the residual
         res = x.view(b, hh * ww, c)
-        h = self.group_norm(x).view(b, hh * ww, c)                   # :1297-1298 (NHWC: no transposes needed)
+        h = h.view(b, hh * ww, c)
         lora = any(l.lora_layer is not None for l in (self.to_q, self.to_k, self.to_v))
         if not torch.is_grad_enabled() and not lora and not torch.cuda.is_current_stream_capturing():
             # sampling: one [3C, C] projection instead of three (h is read once), q/k/v consumed in place.  Not inside a

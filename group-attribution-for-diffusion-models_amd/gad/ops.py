@@ -651,13 +651,15 @@ class GroupNormSiluFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dbypass=None):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         G, eps, silu = ctx.cfg
         dy = dy.contiguous()
         dx = torch.empty_like(x)
         a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
         a.dy = dy.data_ptr()
+        if dbypass is not None:                          # gradient of the bypass output: summed in the kernel's store
+            a.dx_add = _req(dbypass.contiguous(), "groupnorm bypass gradient").data_ptr()
         if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):      # frozen norm (LoRA training): dx only
             check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
             return dx, None, None, None, None, None
@@ -676,6 +678,31 @@ class GroupNormSiluFn(torch.autograd.Function):
                 sb.add_(dbeta)
             dbeta = None
         return dx, dgamma, dbeta, None, None, None
+
+
+class GroupNormBypassFn(GroupNormSiluFn):
+    """(y, x_bypass) = (GroupNorm(+SiLU)(x), x): the input of ResnetBlock2D / the attention block feeds the norm AND the
+    residual branch.  Handing the second consumer this node's own alias of x makes x single-consumer for autograd, and the
+    backward receives both gradients at once: dx = gn_bwd(dy) + d(bypass) is one kernel (`gad_groupnorm_args.dx_add`)
+    instead of the norm's backward plus an elementwise add launch."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, G, eps, silu):
+        y = GroupNormSiluFn.forward(ctx, x, gamma, beta, G, eps, silu)
+        return y, x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dbypass):
+        if dy is None:                                   # only the bypass was used downstream
+            return dbypass, None, None, None, None, None
+        return GroupNormSiluFn.backward(ctx, dy, dbypass)
+
+
+def group_norm_bypass(x, gamma, beta, G, eps, silu):
+    """-> (GroupNorm(+SiLU)(x), alias of x for the residual branch); see GroupNormBypassFn."""
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return group_norm(x, gamma, beta, G, eps, silu), x
+    return GroupNormBypassFn.apply(x, gamma, beta, G, eps, silu)
 
 
 def group_norm(x, gamma, beta, G, eps, silu):
@@ -1069,7 +1096,7 @@ class LayerNormFn(torch.autograd.Function):
         return y
 
     @staticmethod
-    def backward(ctx, dy):
+    def backward(ctx, dy, dbypass=None):
         x, gamma, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
         C_ = x.shape[-1]
@@ -1078,16 +1105,38 @@ class LayerNormFn(torch.autograd.Function):
         want = ctx.needs_input_grad[1] or ctx.needs_input_grad[2]            # frozen LayerNorm (LoRA training): dx only
         dgb = torch.empty(2 * C_, device=x.device, dtype=torch.float32) if want else None
         ws = workspace(x.device)
-        check(_capi.load().gad_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), gamma.data_ptr(), mean.data_ptr(),
-                                             rstd.data_ptr(), _ptr(dgb), rows, C_, ws.data_ptr(), ws.numel(),
+        add = _req(dbypass.contiguous(), "layernorm bypass gradient") if dbypass is not None else None
+        check(_capi.load().gad_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), _ptr(add), gamma.data_ptr(),
+                                             mean.data_ptr(), rstd.data_ptr(), _ptr(dgb), rows, C_, ws.data_ptr(), ws.numel(),
                                              _stream()), "gad_layernorm_bwd")
         if not want:
             return dx, None, None, None
         return dx, _deliver(gamma, dgb[:C_]), _deliver(ctx.beta_ref, dgb[C_:]), None
 
 
+class LayerNormBypassFn(LayerNormFn):
+    """(LayerNorm(x), alias of x): the residual branch of a transformer sub-block takes the alias, so the norm's backward
+    receives both gradients and adds them in its own store (see GroupNormBypassFn)."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, eps):
+        return LayerNormFn.forward(ctx, x, gamma, beta, eps), x.view_as(x)
+
+    @staticmethod
+    def backward(ctx, dy, dbypass):
+        if dy is None:
+            return dbypass, None, None, None
+        return LayerNormFn.backward(ctx, dy, dbypass)
+
+
 def layer_norm(x, gamma, beta, eps=1e-5):
     return LayerNormFn.apply(x, gamma, beta, eps)
+
+
+def layer_norm_bypass(x, gamma, beta, eps=1e-5):
+    if not (torch.is_grad_enabled() and x.requires_grad):
+        return layer_norm(x, gamma, beta, eps), x
+    return LayerNormBypassFn.apply(x, gamma, beta, eps)
 
 
 class GegluFn(torch.autograd.Function):

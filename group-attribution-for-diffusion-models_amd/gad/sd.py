@@ -25,6 +25,9 @@ class LayerNorm(nn.Module):
     def forward(self, x):
         return ops.layer_norm(x, self.weight, self.bias, self.eps)
 
+    def with_bypass(self, x):
+        return ops.layer_norm_bypass(x, self.weight, self.bias, self.eps)
+
 
 class CrossAttention(nn.Module):
     def __init__(self, query_dim, context_dim, heads, dim_head):
@@ -71,9 +74,14 @@ class BasicTransformerBlock(nn.Module):
         self.ff = FeedForward(dim)
 
     def forward(self, x, context, scale=1.0):
-        x = self.attn1(self.norm1(x), residual=x, scale=scale)
-        x = self.attn2(self.norm2(x), context, residual=x, scale=scale)
-        return self.ff(self.norm3(x), residual=x)
+        # each sub-block's input feeds its norm AND its residual: the norm hands out the alias the residual uses, so the
+        # two gradients meet inside the norm's backward kernel (ops.LayerNormBypassFn)
+        h, x = self.norm1.with_bypass(x)
+        x = self.attn1(h, residual=x, scale=scale)
+        h, x = self.norm2.with_bypass(x)
+        x = self.attn2(h, context, residual=x, scale=scale)
+        h, x = self.norm3.with_bypass(x)
+        return self.ff(h, residual=x)
 
 
 class Transformer2DModel(nn.Module):
@@ -86,7 +94,8 @@ class Transformer2DModel(nn.Module):
 
     def forward(self, x, context, scale=1.0):
         b, h, w, c = x.shape
-        y = self.proj_in(self.norm(x)).view(b, h * w, c)
+        y, x = self.norm.with_bypass(x)
+        y = self.proj_in(y).view(b, h * w, c)
         for blk in self.transformer_blocks:
             y = blk(y, context, scale)
         return self.proj_out(y.view(b, h, w, c), residual=x)

@@ -161,6 +161,10 @@ typedef struct gad_groupnorm_args {
   const float* x2;
   int32_t C1;
   int32_t flags;            /* GAD_GN_TWO_PASS = 1: force the two-pass plan (A/B tests); 0 in production          */
+  /* backward only: dx = (gradient through the norm) + dx_add ([B][HW][C], may alias nothing else): the gradient of a
+   * second consumer of x - the residual branch of ResnetBlock2D / the attention block, whose input feeds both the norm
+   * and the skip - summed in the store instead of by a separate elementwise launch.  NULL: none. */
+  const float* dx_add;
 } gad_groupnorm_args;
 enum gad_groupnorm_flags { GAD_GN_TWO_PASS = 1 };
 
@@ -234,7 +238,9 @@ int gad_softmax_bwd(const float* p, const float* dp, float* ds, int64_t rows, in
 int64_t gad_layernorm_workspace_bytes(int64_t rows, int32_t C);
 int gad_layernorm_fwd(const float* x, float* y, const float* gamma, const float* beta, float* mean, float* rstd,
                       int64_t rows, int32_t C, float eps, void* stream);
-int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* gamma, const float* mean,
+/* dx_add (may be NULL): [rows][C] added to dx in the store - the gradient of the residual branch that shares x with the
+ * norm (BasicTransformerBlock: x = attn(norm(x)) + x), instead of a separate elementwise launch */
+int gad_layernorm_bwd(const float* x, const float* dy, float* dx, const float* dx_add, const float* gamma, const float* mean,
                       const float* rstd, float* dgamma_dbeta, int64_t rows, int32_t C, void* ws, int64_t ws_bytes,
                       void* stream);
 int gad_geglu_fwd(const float* h, float* out, int64_t M, int32_t F, void* stream);

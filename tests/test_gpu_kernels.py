@@ -363,6 +363,54 @@ def test_norm_backward_with_frozen_affine_parameters_and_wide_column_sums(ops):
 
 
 # ------------------------------------------------------------------------ elementwise ----
+@pytest.mark.parametrize("two_pass", [False, True])
+@pytest.mark.parametrize("B,C,H,G,silu", [(4, 128, 16, 32, True), (2, 96, 32, 32, True), (3, 256, 8, 32, False), (2, 320, 16, 32, False)])
+def test_groupnorm_bypass_sums_the_residual_gradient_in_its_backward_kernel(ops, B, C, H, G, silu, two_pass):
+    """ResnetBlock2D / attention block input: x feeds the norm and the residual.  `group_norm_bypass` hands the residual
+    branch the norm node's own alias of x, so autograd sees one consumer and the backward adds both gradients in the
+    kernel's store (gad_groupnorm_args.dx_add).  Bit-identical to the plain node followed by autograd's add launch."""
+    x0 = rnd(B, H, H, C, seed=1).to(dev)
+    gamma = (1 + 0.1 * rnd(C, seed=2)).to(dev).requires_grad_(True)
+    beta = (0.1 * rnd(C, seed=3)).to(dev).requires_grad_(True)
+    wy, wr = rnd(B, H, H, C, seed=4).to(dev), rnd(B, H, H, C, seed=5).to(dev)
+    res = []
+    for bypass in (False, True):
+        x = x0.clone().requires_grad_(True)
+        gamma.grad = beta.grad = None
+        with ops.kernel_flags(gn_two_pass=two_pass):
+            if bypass:
+                y, xr = ops.group_norm_bypass(x, gamma, beta, G, 1e-5, silu)
+            else:
+                y, xr = ops.group_norm(x, gamma, beta, G, 1e-5, silu), x
+            ((y * wy).sum() + (xr * wr * 2.0).sum()).backward()
+        res.append((y.detach(), x.grad.clone(), gamma.grad.clone(), beta.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+    # only the bypass output used downstream / no grad mode
+    x = x0.clone().requires_grad_(True)
+    y, xr = ops.group_norm_bypass(x, gamma, beta, G, 1e-5, silu)
+    (xr * wr).sum().backward()
+    assert torch.equal(x.grad, wr)
+    with torch.no_grad(), ops.kernel_flags(gn_two_pass=two_pass):
+        y2, xr2 = ops.group_norm_bypass(x0, gamma, beta, G, 1e-5, silu)
+    assert xr2 is x0 and torch.equal(y2, res[0][0])
+
+
+def test_layernorm_bypass_sums_the_residual_gradient_in_its_backward_kernel(ops):
+    x0 = rnd(2, 77, 320, seed=1).to(dev)
+    gamma, beta = (1 + 0.1 * rnd(320, seed=2)).to(dev).requires_grad_(True), (0.1 * rnd(320, seed=3)).to(dev).requires_grad_(True)
+    wy, wr = rnd(2, 77, 320, seed=4).to(dev), rnd(2, 77, 320, seed=5).to(dev)
+    res = []
+    for bypass in (False, True):
+        x = x0.clone().requires_grad_(True)
+        gamma.grad = beta.grad = None
+        y, xr = ops.layer_norm_bypass(x, gamma, beta) if bypass else (ops.layer_norm(x, gamma, beta), x)
+        ((y * wy).sum() + (xr * wr).sum()).backward()
+        res.append((y.detach(), x.grad.clone(), gamma.grad.clone(), beta.grad.clone()))
+    for a, b in zip(*res):
+        assert torch.equal(a, b)
+
+
 def test_timestep_embedding(ops):
     from oracle.diffusers_ref import get_timestep_embedding
     t = torch.tensor([0, 1, 10, 500, 990, 999])
