@@ -464,7 +464,11 @@ def measure(a, name, steps, warmup, env, headline):
             engine.run_coalition(10_000 + rank)
         barrier()
         t0 = time.time()
-        recs = [engine.run_coalition(rank + world * i, verbose=(rank == 0)) for i in range(steps)]
+        recs = []
+        for i in range(steps):                                           # (stdout carries the JSON line only)
+            recs.append(engine.run_coalition(rank + world * i, verbose=False))
+            r = recs[-1]
+            log(f"coalition {r.removal_seed}: |S|={r.n_remaining} train {r.total_steps_time:.1f}s sample+score {r.total_sampling_time:.1f}s fid {r.fid_value:.4f}")
         barrier()
         dt = time.time() - t0
         units = steps * world                                           # coalitions

@@ -146,12 +146,27 @@ class Attention(nn.Module):
     def __init__(self, channels, heads, dim_head, eps, groups):
         super().__init__()
         inner = heads * dim_head
-        self.heads = heads
+        self.heads, self.dim_head = heads, dim_head
+        # head dims that are not a multiple of 4 (head-grouped-pruned CelebA: 23) run with zero-padded heads: ops.PadHeadsFn
+        self.dpad = dim_head if dim_head % 4 == 0 else (dim_head + 7) // 8 * 8
         self.group_norm = GroupNorm(groups, channels, eps)
         self.to_q = Linear(channels, inner)
         self.to_k = Linear(channels, inner)
         self.to_v = Linear(channels, inner)
         self.to_out = nn.ModuleList([Linear(inner, channels), nn.Dropout(0.0)])
+
+    def _padded(self):
+        """(Wq, bq, Wk, bk, Wv, bv, Wo) with the heads zero-padded to self.dpad; differentiable (training) - in no-grad
+        mode cached per weight version (sampling: thousands of forwards on fixed EMA weights)."""
+        h, d, dp = self.heads, self.dim_head, self.dpad
+        ps = (self.to_q.weight, self.to_q.bias, self.to_k.weight, self.to_k.bias, self.to_v.weight, self.to_v.bias)
+        if torch.is_grad_enabled():
+            return tuple(ops.pad_heads(p, h, d, dp, 0) for p in ps) + (ops.pad_heads(self.to_out[0].weight, h, d, dp, 1),)
+        key = tuple(ops.weight_key(p) for p in ps + (self.to_out[0].weight,))
+        if getattr(self, "_pad_key", None) != key:
+            self._pad_w = tuple(ops.pad_heads(p, h, d, dp, 0) for p in ps) + (ops.pad_heads(self.to_out[0].weight, h, d, dp, 1),)
+            self._pad_key = key
+        return self._pad_w
 
     def _fused_qkv(self):
         """[3C, C] weight and [3C] bias of the three projections, concatenated once and reused while the parameters are
@@ -159,6 +174,9 @@ class Attention(nn.Module):
         ps = (self.to_q.weight, self.to_k.weight, self.to_v.weight, self.to_q.bias, self.to_k.bias, self.to_v.bias)
         key = tuple(ops.weight_key(p) for p in ps)           # incl. the epochs the raw optimizer kernels bump
         if getattr(self, "_qkv_key", None) != key:
+            if self.dpad != self.dim_head:
+                wq, bq, wk, bk, wv, bv, _ = self._padded()
+                ps = (wq, wk, wv, bq, bk, bv)
             self._qkv_w = torch.cat([p.detach() for p in ps[:3]], 0).contiguous()
             self._qkv_b = torch.cat([p.detach() for p in ps[3:]], 0).contiguous()
             self._qkv_key = key
@@ -169,15 +187,25 @@ class Attention(nn.Module):
         h, x = self.group_norm.with_bypass(x)                        # :1297-1298 (NHWC: no transposes needed); x: alias for the residual
         res = x.view(b, hh * ww, c)
         h = h.view(b, hh * ww, c)
-        lora = any(l.lora_layer is not None for l in (self.to_q, self.to_k, self.to_v))
+        lora = any(l.lora_layer is not None for l in (self.to_q, self.to_k, self.to_v, self.to_out[0]))
+        padded = self.dpad != self.dim_head and not lora
+        sm_scale = self.dim_head ** -0.5 if padded else None         # the softmax scale of the TRUE head dim (:1321-1323)
         if not torch.is_grad_enabled() and not lora and not torch.cuda.is_current_stream_capturing():
             # sampling: one [3C, C] projection instead of three (h is read once), q/k/v consumed in place.  Not inside a
             # hipGraph capture: a replayed graph would keep reading the cached copy after the parameters changed.
             w, bias = self._fused_qkv()
             qkv = ops.linear_fwd_raw(h.view(b * hh * ww, c), w, bias)
-            o = ops.attention_core_qkv_raw(qkv, b, hh * ww, self.to_q.weight.shape[0], self.heads)   # inner dim: != c when pruned
-            o = self.to_out[0](o, residual=res, scale=scale)
+            o = ops.attention_core_qkv_raw(qkv, b, hh * ww, w.shape[0] // 3, self.heads, scale=sm_scale)   # inner dim: != c when pruned
+            if padded:
+                o = ops.linear(o, self._padded()[6], self.to_out[0].bias, res)
+            else:
+                o = self.to_out[0](o, residual=res, scale=scale)
             return o.view(b, hh, ww, c)
+        if padded:
+            wq, bq, wk, bk, wv, bv, wo = self._padded()
+            q, k, v = ops.linear(h, wq, bq), ops.linear(h, wk, bk), ops.linear(h, wv, bv)
+            o = ops.attention_core(q, k, v, self.heads, scale=sm_scale)
+            return ops.linear(o, wo, self.to_out[0].bias, res).view(b, hh, ww, c)
         q, k, v = self.to_q(h, scale=scale), self.to_k(h, scale=scale), self.to_v(h, scale=scale)   # :1301-1309
         o = ops.attention_core(q, k, v, self.heads)                   # :1314-1325
         o = self.to_out[0](o, residual=res, scale=scale)              # :1329 + residual :1336-1337

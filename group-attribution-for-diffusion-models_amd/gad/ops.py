@@ -246,10 +246,11 @@ class GemmProfiler:
         s.record()
         check(fn(C.byref(a), _stream()), f"gad_attention_{what}")
         e.record()
-        unit = float(a.B) * a.heads * a.Tq * a.Tk * a.d
-        qb, kb = 4.0 * a.B * a.Tq * a.heads * a.d, 4.0 * a.B * a.Tk * a.heads * a.d
+        d_alg = getattr(a, "alg_d", a.d)               # zero-padded heads (ops.PadHeadsFn): count the TRUE head dim's FLOPs
+        unit = float(a.B) * a.heads * a.Tq * a.Tk * d_alg
+        qb, kb = 4.0 * a.B * a.Tq * a.heads * d_alg, 4.0 * a.B * a.Tk * a.heads * d_alg
         flops, nbytes = (4.0 * unit, 2 * qb + 2 * kb) if what == "fwd" else (10.0 * unit, 4 * qb + 4 * kb)
-        self.records.append(((f"attn_{what}_d{a.d}", a.Tq, a.Tk, 4), flops, nbytes, s, e))
+        self.records.append(((f"attn_{what}_d{d_alg}", a.Tq, a.Tk, 4), flops, nbytes, s, e))
 
     def summary(self):
         """{key: dict(launches, ms, flops)} - call after a device synchronize."""
@@ -840,23 +841,25 @@ def fused_attention_ok(d: int, *lds) -> bool:
     return bool(_capi.load().gad_attention_supported(int(d)))
 
 
-def _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, sq, sk, sv):
+def _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, sq, sk, sv, scale=None):
     a = _capi.AttentionArgs()
     a.q, a.k, a.v, a.o, a.lse = q.data_ptr(), k.data_ptr(), v.data_ptr(), o.data_ptr(), _ptr(lse)
     a.B, a.heads, a.Tq, a.Tk, a.d = Bn, heads, Tq, Tk, d
     a.ldq, a.ldk, a.ldv, a.ldo = ldq, ldk, ldv, heads * d
     a.stride_q, a.stride_k, a.stride_v, a.stride_o = sq, sk, sv, Tq * heads * d
-    a.scale = 1.0 / math.sqrt(d)
+    a.scale = 1.0 / math.sqrt(d) if scale is None else scale       # (zero-padded heads keep the true head dim's scale)
+    if scale is not None:
+        a.alg_d = int(round(1.0 / (scale * scale)))
     a.operand_precision = 0
     return a
 
 
-def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=True):
+def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=True, scale=None):
     """Fused attention forward on [Bn, T, *] views (q, k, v may be column blocks of one projection output: their
     data_ptr is the column offset, ld* the row stride).  -> (o [Bn, Tq, heads*d], lse [Bn, heads, Tq] or None)"""
     o = torch.empty((Bn, Tq, heads * d), device=q.device, dtype=torch.float32)
     lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
-    a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv)
+    a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv, scale)
     a.operand_precision = OPERAND_PRECISION[0]         # bf16 mode: bf16-operand instance of the fused kernel
     if PROFILER is not None:
         PROFILER.attention(_capi.load().gad_attention_fwd, a, "fwd")
@@ -872,15 +875,15 @@ class AttentionCoreFn(torch.autograd.Function):
     recomputing dQ + dK/dV kernel pair backward (csrc/attention.hip)."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads):
+    def forward(ctx, q, k, v, heads, scale=None):
         for t_, n_ in ((q, "q"), (k, "k"), (v, "v")):
             _req(t_, n_)
         Bn, Tq, Cq = q.shape
         Tk = k.shape[1]
         d = Cq // heads
-        o, lse = attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, need_lse=True)
+        o, lse = attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, need_lse=True, scale=scale)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads, ctx.prec = heads, OPERAND_PRECISION[0]
+        ctx.heads, ctx.prec, ctx.scale = heads, OPERAND_PRECISION[0], scale
         return o
 
     @staticmethod
@@ -893,7 +896,7 @@ class AttentionCoreFn(torch.autograd.Function):
         d = Cq // heads
         dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
         delta = torch.empty_like(lse)
-        a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, Tq * Cq, Tk * Cq, Tk * Cq)
+        a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, Tq * Cq, Tk * Cq, Tk * Cq, ctx.scale)
         a.d_o, a.delta, a.dq, a.dk, a.dv = do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
         a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq
         a.stride_do = a.stride_dq = Tq * Cq
@@ -908,7 +911,7 @@ class AttentionCoreFn(torch.autograd.Function):
             PROFILER.attention(_capi.load().gad_attention_bwd, a, "bwd")
         else:
             check(_capi.load().gad_attention_bwd(C.byref(a), _stream()), "gad_attention_bwd")
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
 class UnfusedAttentionCoreFn(torch.autograd.Function):
@@ -916,13 +919,14 @@ class UnfusedAttentionCoreFn(torch.autograd.Function):
     for head dims without a fused instance, and the independent implementation the fused kernels are tested against."""
 
     @staticmethod
-    def forward(ctx, q, k, v, heads):
+    def forward(ctx, q, k, v, heads, scale=None):
         for t_, n_ in ((q, "q"), (k, "k"), (v, "v")):
             _req(t_, n_)
         Bn, Tq, Cq = q.shape
         Tk = k.shape[1]
         d = Cq // heads
-        scale = 1.0 / math.sqrt(d)
+        scale = 1.0 / math.sqrt(d) if scale is None else scale
+        ctx.scale = scale
         S = torch.empty((Bn, heads, Tq, Tk), device=q.device, dtype=torch.float32)
         _attn_gemm(q, k, S, A_KC, B_KC, Tq, Tk, d, Cq, Cq, Tk, Bn, heads,
                    (Tq * Cq, d), (Tk * Cq, d), (heads * Tq * Tk, Tq * Tk))
@@ -943,7 +947,7 @@ class UnfusedAttentionCoreFn(torch.autograd.Function):
         Bn, Tq, Cq = q.shape
         Tk = k.shape[1]
         d = Cq // heads
-        scale = 1.0 / math.sqrt(d)
+        scale = ctx.scale
         sP = (heads * Tq * Tk, Tq * Tk)
         sQ, sK = (Tq * Cq, d), (Tk * Cq, d)
         # dV[b,h] = P^T dO   (A = P as [k=Tq][m=Tk], B = dO as [k=Tq][n=d])
@@ -960,18 +964,56 @@ class UnfusedAttentionCoreFn(torch.autograd.Function):
         _attn_gemm(dP, k, dq, A_KC, B_MC, Tq, d, Tk, Tk, Cq, Cq, Bn, heads, sP, sK, sQ)
         dk = torch.empty_like(k)
         _attn_gemm(dP, q, dk, A_MC, B_MC, Tk, d, Tq, Tk, Cq, Cq, Bn, heads, sP, sQ, sK)
-        return dq, dk, dv, None
+        return dq, dk, dv, None, None
 
 
-def attention_core(q, k, v, heads):
+class PadHeadsFn(torch.autograd.Function):
+    """Zero-pad the per-head blocks of an attention projection parameter from head dim d to dpad (a multiple of 8):
+    axis 0 - the rows of to_q / to_k / to_v weights [heads*d, C] and biases [heads*d]; axis 1 - the columns of the to_out
+    weight [C, heads*d].  The head-grouped-pruned CelebA model has d = 23 (reference unconditional_generation/prune.py:
+    337-342): 322-float rows are not float4-aligned, which puts the four projections on the scalar-gather GEMM path and
+    the attention on its dword-staged instances.  With zero-padded heads (d = 24) every launch is back on LDS-DMA and the
+    result is the same function: the extra q / k channels are 0 * 0, the extra v / output channels meet zero columns of
+    to_out.  The gradient of the padded tensor is sliced back into the parameter (its flat-buffer sink when a
+    FusedTrainer step is running)."""
+
+    @staticmethod
+    def forward(ctx, w, heads, d, dpad, axis):
+        ctx.param, ctx.cfg = w, (heads, d, dpad, axis)
+        src = w.detach()
+        if axis == 0:
+            rest = src.shape[1:]
+            out = src.new_zeros((heads, dpad) + tuple(rest))
+            out[:, :d] = src.reshape((heads, d) + tuple(rest))
+            return out.view((heads * dpad,) + tuple(rest))
+        out = src.new_zeros((src.shape[0], heads, dpad))
+        out[:, :, :d] = src.reshape(src.shape[0], heads, d)
+        return out.view(src.shape[0], heads * dpad)
+
+    @staticmethod
+    def backward(ctx, g):
+        heads, d, dpad, axis = ctx.cfg
+        w = ctx.param
+        if axis == 0:
+            gs = g.view((heads, dpad) + tuple(w.shape[1:]))[:, :d].reshape(w.shape)
+        else:
+            gs = g.view(w.shape[0], heads, dpad)[:, :, :d].reshape(w.shape)
+        return _deliver(w, gs), None, None, None, None
+
+
+def pad_heads(w, heads, d, dpad, axis):
+    return PadHeadsFn.apply(w, heads, d, dpad, axis)
+
+
+def attention_core(q, k, v, heads, scale=None):
     d = q.shape[-1] // heads
     # Training at one wide head over a short sequence (CIFAR: d = 256 / 192, T <= 256) keeps the three-launch route: S is a
     # few MB there, and the recomputing backward (7 products, 1 wave per SIMD at d >= 192) measured 0.48 ms against
     # 0.32 ms (tools/bench_attention.py).  Everything else - every sampling forward, CelebA's and SD's heads - is fused.
     wide_short = torch.is_grad_enabled() and d > 160 and q.shape[1] * k.shape[1] <= 256 * 256
     if fused_attention_ok(d, q.shape[-1]) and not wide_short:
-        return AttentionCoreFn.apply(q, k, v, heads)
-    return UnfusedAttentionCoreFn.apply(q, k, v, heads)
+        return AttentionCoreFn.apply(q, k, v, heads, scale)
+    return UnfusedAttentionCoreFn.apply(q, k, v, heads, scale)
 
 
 def attention_core_fused(q, k, v, heads):
@@ -982,15 +1024,15 @@ def attention_core_unfused(q, k, v, heads):
     return UnfusedAttentionCoreFn.apply(q, k, v, heads)
 
 
-def attention_core_qkv_raw(qkv, Bn, T, Cq, heads):
+def attention_core_qkv_raw(qkv, Bn, T, Cq, heads, scale=None):
     """Inference form on the output of ONE fused projection: qkv is [Bn*T, 3*Cq] (q | k | v along the columns); the
     fused attention kernel reads q, k, v in place through their row stride 3*Cq.  No autograd."""
     d = Cq // heads
     ld = 3 * Cq
     q, k, v = qkv[:, 0:Cq], qkv[:, Cq:2 * Cq], qkv[:, 2 * Cq:3 * Cq]        # views: data_ptr = column offset
     if fused_attention_ok(d, ld):
-        return attention_fwd_raw(q, k, v, Bn, heads, T, T, d, ld, ld, ld, need_lse=False)[0]
-    scale = 1.0 / math.sqrt(d)
+        return attention_fwd_raw(q, k, v, Bn, heads, T, T, d, ld, ld, ld, need_lse=False, scale=scale)[0]
+    scale = 1.0 / math.sqrt(d) if scale is None else scale
     S = torch.empty((Bn, heads, T, T), device=qkv.device, dtype=torch.float32)
     _attn_gemm(q, k, S, A_KC, B_KC, T, T, d, ld, ld, T, Bn, heads, (T * ld, d), (T * ld, d), (heads * T * T, T * T))
     check(_capi.load().gad_softmax_fwd(S.data_ptr(), S.data_ptr(), Bn * heads * T, T, scale, _stream()), "gad_softmax_fwd")

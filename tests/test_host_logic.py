@@ -263,3 +263,28 @@ def test_lora_file_keys_follow_unet_save_attn_procs(tmp_path):
     save_file({**sd, "down_blocks.9.attn.processor.to_q_lora.down.weight": torch.zeros(2, 2)}, str(tmp_path / "bad2.safetensors"))
     with pytest.raises(KeyError, match="match no attention projection"):
         gad.UNet2DConditionModel(**cfg).load_attn_procs(str(tmp_path), weight_name="bad2.safetensors")
+
+
+def test_pad_heads_is_a_zero_padding_of_the_per_head_blocks_and_slices_the_gradient_back():
+    """ops.PadHeadsFn (host tensor ops only): the projections of a head-grouped-pruned attention (heads of 23,
+    unconditional_generation/prune.py:337-342) are zero-padded per head to 24 so that every launch is float4-aligned."""
+    import torch
+    from gad import ops
+    heads, d, dp, C = 3, 5, 8, 4
+    w = torch.nn.Parameter(torch.arange(heads * d * C, dtype=torch.float32).view(heads * d, C))
+    b = torch.nn.Parameter(torch.arange(heads * d, dtype=torch.float32))
+    wo = torch.nn.Parameter(torch.arange(C * heads * d, dtype=torch.float32).view(C, heads * d))
+    wp, bp, wop = ops.pad_heads(w, heads, d, dp, 0), ops.pad_heads(b, heads, d, dp, 0), ops.pad_heads(wo, heads, d, dp, 1)
+    assert wp.shape == (heads * dp, C) and bp.shape == (heads * dp,) and wop.shape == (C, heads * dp)
+    for h in range(heads):
+        assert torch.equal(wp[h * dp:h * dp + d], w[h * d:(h + 1) * d]) and not wp[h * dp + d:(h + 1) * dp].any()
+        assert torch.equal(bp[h * dp:h * dp + d], b[h * d:(h + 1) * d]) and not bp[h * dp + d:(h + 1) * dp].any()
+        assert torch.equal(wop[:, h * dp:h * dp + d], wo[:, h * d:(h + 1) * d]) and not wop[:, h * dp + d:(h + 1) * dp].any()
+    gw, gb, go = torch.randn_like(wp), torch.randn_like(bp), torch.randn_like(wop)
+    ((wp * gw).sum() + (bp * gb).sum() + (wop * go).sum()).backward()
+    assert torch.equal(w.grad, gw.view(heads, dp, C)[:, :d].reshape(heads * d, C))
+    assert torch.equal(b.grad, gb.view(heads, dp)[:, :d].reshape(-1))
+    assert torch.equal(wo.grad, go.view(C, heads, dp)[:, :, :d].reshape(C, heads * d))
+    # x W^T on the padded weight = the unpadded product scattered into the padded layout
+    x = torch.randn(7, C)
+    assert torch.equal((x @ wp.t()).view(7, heads, dp)[:, :, :d].reshape(7, heads * d), x @ w.t())
