@@ -412,6 +412,12 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False,
     _, Ho, Wo, _ = dy.shape
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     dxe = torch.empty((Bn, He, We, Cin), device=dy.device, dtype=torch.float32)
+    if (KH == 1 and KW == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not upsample and Cin % 4 == 0 and Cout % 4 == 0
+            and not KERNEL_FLAGS["gemm"] & _capi.GEMM_GENERAL_LOADERS):
+        # a 1x1 / stride-1 convolution (ResNet shortcuts, proj_in / proj_out of the SD transformer blocks) is a dense
+        # GEMM over the pixel rows: dx = dy W on the lean dense loaders instead of the transposed im2col gather
+        gemm_raw(dy, wk, dxe, A_KC, B_MC, Bn * H * W, Cin, Cout, Cout, Cin, Cin, tile_hint=tile_hint, splitk_hint=splitk_hint)
+        return dxe
     g = ConvGeom(Ho, Wo, Cout, Cout, He, We, KH, KW, stride, pad[0], pad[2], 0)
     gemm_raw(dy, wk, dxe, A_CONVT, B_WDGRAD, Bn * He * We, Cin, KH * KW * Cout, 0, 0, Cin, geom=g,
              tile_hint=tile_hint, splitk_hint=splitk_hint)
@@ -431,6 +437,10 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
     Cout, _, KH, KW = w_like.shape
     _, Ho, Wo, _ = dy.shape
     dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32) if out is None else weight_krsc(out)
+    if (KH == 1 and KW == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not upsample and Cin % 4 == 0 and Cout % 4 == 0
+            and not KERNEL_FLAGS["gemm"] & _capi.GEMM_GENERAL_LOADERS):
+        gemm_raw(dy, x, dwk, A_MC, B_MC, Cout, Cin, Bn * H * W, Cout, Cin, Cin, tile_hint=tile_hint, splitk_hint=splitk_hint)   # dW = dy^T x
+        return dwk.permute(0, 3, 1, 2)
     g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
              tile_hint=tile_hint, splitk_hint=splitk_hint)
