@@ -372,7 +372,8 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
         elif "bf16" in nm:
             kname = f"conv3x3_patch_bf16_kernel<{wo}, {ni}> ({nm})"
         else:
-            kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {dom_key[1]}> ({nm}, {dom_key[1]}-channel tiles)"
+            tiles_ = "128- then 96-channel tiles, two launches" if dom_key[1] == 224 else f"{dom_key[1]}-channel tiles"
+            kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {'128 | 96' if dom_key[1] == 224 else dom_key[1]}> ({nm}, {tiles_})"
     else:
         kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
     traffic, traffic_src = None, None

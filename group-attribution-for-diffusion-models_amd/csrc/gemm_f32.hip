@@ -2033,6 +2033,34 @@ static bool use_patch_conv_f32(const gad_gemm_args* a, PatchPlan* pp) {
   return pp->blocks >= 192;
 }
 
+// Channel counts that no single tile width divides (CelebA-HQ LDM: 224 = 128 + 96, 448 = 2 x 128 + 2 x 96;
+// ddpm_config.py:425-450) run as TWO launches over disjoint column ranges - the first n1 columns on 128-wide tiles, the
+// rest on 96-wide tiles - when that models faster than the best padded single launch (128-wide tiles waste an eighth of
+// the MFMA work there).  Forward form only (which the data gradients share, ops.dgrad_as_forward), no split-K.
+static bool patch_split_n(const gad_gemm_args* a, int* n1_out) {
+  if (use_bf16(a) || !patch_conv_geom(a) || a->N % 32 != 0 || a->N < 224 || a->tile_hint != 0) return false;
+  PatchPlan single;
+  if (!use_patch_conv_f32(a, &single) || single.splitk != 1) return false;
+  auto cost = [](const PatchPlan& q) { return (double)gad_ceil_div(q.blocks, 512) * q.chunks_per_split * q.bn; };
+  if (gad_ceil_div(a->N, single.bn) * single.bn == a->N) return false;        // already exact
+  for (int n2 = 96; n2 < a->N; n2 += 96) {
+    const int n1 = a->N - n2;
+    if (n1 % 128 != 0) continue;
+    gad_gemm_args lo = *a, hi = *a;
+    lo.N = n1;
+    hi.N = n2;
+    PatchPlan pl, ph;
+    patch_plan_for(&lo, 128, &pl);
+    patch_plan_for(&hi, 96, &ph);
+    if (pl.splitk != 1 || ph.splitk != 1 || pl.blocks < 192 || ph.blocks < 192) continue;
+    if (cost(pl) + cost(ph) < 0.97 * cost(single)) {
+      *n1_out = n1;
+      return true;
+    }
+  }
+  return false;
+}
+
 // 3x3 / stride 1 / pad 1 forward conv with <= 4 output channels on whole 256-pixel row tiles: the vector-ALU kernel
 static bool use_fewout_conv(const gad_gemm_args* a) {
   const gad_conv_geom& g = a->g;
@@ -2066,6 +2094,30 @@ static int wgrad_patch_splits(const gad_gemm_args* a, int* bm_out = nullptr) {
   if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
   if (sp < 1) sp = 1;
   return (int)sp;
+}
+
+// The same for the weight gradient's output channels (M): 224 = 128 + 96, 320 = 128 + 2 x 96, 448, 480 run as two launches
+// over disjoint row ranges (128-channel tiles, then 96-channel tiles) when the accumulator-unit model prefers it.
+static bool wgrad_split_m(const gad_gemm_args* a, int* m1_out) {
+  if (a->tile_hint != 0 || a->M % 32 != 0 || a->M < 224 || !wgrad_patch_splits(a)) return false;
+  const double single = fmin((double)gad_ceil_div(a->M, 128) * 9.0, (double)gad_ceil_div(a->M, 96) * 7.0 * 1.05);
+  for (int m2 = 96; m2 < a->M; m2 += 96) {
+    const int m1 = a->M - m2;
+    if (m1 % 128 != 0) continue;
+    if ((m1 / 128) * 9.0 + (m2 / 96) * 7.0 * 1.05 < 0.97 * single) {
+      *m1_out = m1;
+      return true;
+    }
+  }
+  return false;
+}
+static void wgrad_split_args(const gad_gemm_args* a, int m1, gad_gemm_args* lo, gad_gemm_args* hi) {
+  *lo = *a;
+  *hi = *a;
+  lo->M = m1;
+  hi->M = a->M - m1;
+  hi->A = a->A + m1;                       // A_MC: dy [pixels][Cout], the output channel is the contiguous index
+  hi->C = a->C + (long)m1 * a->ldc;
 }
 
 // 1x1 / stride 1 / pad 0 convolutions (ResNet shortcuts, attention projections of the LDM / SD blocks written as convs) are
@@ -2122,10 +2174,12 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
     *tile = 256;
     *splitk = 1;
   } else if (int bm = 0; int sp = wgrad_patch_splits(a, &bm)) {   // patch weight gradient: 128 / 96 output channels x pixel splits
-    *tile = bm;
+    int m1 = 0;
+    *tile = wgrad_split_m(a, &m1) ? 224 : bm;                 // 224: two launches, 128-channel tiles then 96-channel tiles
     *splitk = sp;
   } else if (!use_bf16(a) && use_patch_conv_f32(a, &pp)) {   // patch forward / dgrad: 128 pixels x bn channels
-    *tile = pp.bn;
+    int n1 = 0;
+    *tile = patch_split_n(a, &n1) ? 224 : pp.bn;              // 224: two launches, 128-wide tiles then 96-wide tiles
     *splitk = pp.splitk;
   } else {
     Plan pl = make_plan(a);
@@ -2138,6 +2192,12 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   GAD_CANON(a);
   if (use_fewout_conv(a)) return 0;
+  if (int m1 = 0; wgrad_split_m(a, &m1)) {
+    gad_gemm_args lo, hi;
+    wgrad_split_args(a, m1, &lo, &hi);
+    const int64_t wl = gad_gemm_workspace_bytes(&lo), wh = gad_gemm_workspace_bytes(&hi);
+    return wl > wh ? wl : wh;
+  }
   if (int sp = wgrad_patch_splits(a)) return sp > 1 ? (int64_t)sp * a->M * a->N * (int64_t)sizeof(float) : 0;
   {
     PatchPlan pp;
@@ -2153,6 +2213,24 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   GAD_CHECK(a && a->A && a->B && a->C, "gad_gemm: null pointer");
   GAD_CANON(a);
   GAD_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gad_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
+  if (int n1 = 0; patch_split_n(a, &n1)) {          // 224 / 448 output channels: 128-wide tiles, then 96-wide tiles
+    gad_gemm_args lo = *a, hi = *a;
+    lo.N = n1;
+    hi.N = a->N - n1;
+    hi.B = a->B + (long)n1 * a->ldb;
+    hi.C = a->C + n1;
+    if (a->bias) hi.bias = a->bias + n1;
+    if (a->rowadd) hi.rowadd = a->rowadd + n1;
+    if (a->residual) hi.residual = a->residual + n1;
+    const int rc = gad_gemm(&lo, stream);
+    return rc ? rc : gad_gemm(&hi, stream);
+  }
+  if (int m1 = 0; wgrad_split_m(a, &m1)) {
+    gad_gemm_args lo, hi;
+    wgrad_split_args(a, m1, &lo, &hi);
+    const int rc = gad_gemm(&lo, stream);
+    return rc ? rc : gad_gemm(&hi, stream);
+  }
   const int am = a->a_mode, bmode = a->b_mode;
   const bool convA = am == GAD_A_CONV || am == GAD_A_CONVT;
   const bool geomB = bmode == GAD_B_CONV || bmode == GAD_B_WDGRAD;

@@ -167,9 +167,9 @@ def test_celeba_unet_full_size_properties():
         assert (y_gen - y).abs().max().item() < 2e-4 * max(1.0, y.abs().max().item())     # kernel family
         orig = ops.attention_core_qkv_raw
 
-        def unfused_qkv(qkv, Bn, T, Cq, heads):
+        def unfused_qkv(qkv, Bn, T, Cq, heads, scale=None):
             q, k, v = (qkv[:, i * Cq:(i + 1) * Cq].reshape(Bn, T, Cq).contiguous() for i in range(3))
-            return ops.attention_core_unfused(q, k, v, heads)
+            return ops.UnfusedAttentionCoreFn.apply(q, k, v, heads, scale)
         ops.attention_core_qkv_raw = unfused_qkv
         try:
             y_unf = net(x, t).sample

@@ -153,7 +153,8 @@ def test_wgrad_patch_kernel_96_channel_tiles(ops, B, Cin, Cout, H, ups):
     finally:
         ops.PROFILER = None
     keys = list(prof.summary())
-    assert [k[0] for k in keys] == [f"conv_wgrad_patch_w{He}"] * len(keys) and sorted(k[1] for k in keys) == [96, 128], keys
+    # 96: 96-channel tiles; 224: a 128-channel-tile launch + a 96-channel-tile launch over disjoint channel rows (672 = 384 + 288)
+    assert [k[0] for k in keys] == [f"conv_wgrad_patch_w{He}"] * len(keys) and sorted(k[1] for k in keys) in ([96, 128], [128, 224]), keys
     tol = 3e-5 * math.sqrt(B * He * He / 16)
     close(dw, wd.grad, atol=tol)
     close(dw, dw128, atol=tol)
@@ -182,6 +183,35 @@ def test_wgrad_patch_kernel_64_wide_maps(ops, B, Cin, Cout, H, ups):
     tol = 3e-5 * math.sqrt(B * He * He / 16)
     close(dw, wd.grad, atol=tol)
     close(dw, dw_gather, atol=tol)
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H", [(32, 32, 224, 64), (64, 32, 448, 32), (8, 64, 224, 32)])
+def test_conv_patch_split_channel_ranges_224_448(ops, B, Cin, Cout, H):
+    """CelebA-HQ LDM widths (ddpm_config.py:425-450): 224 = 128 + 96 and 448 = 2 x 128 + 2 x 96 output channels run as two
+    launches over disjoint column ranges (128-wide tiles, then 96-wide tiles) instead of padding an eighth of the MFMA
+    work - forward with the fused bias + time-embedding + residual epilogue, and the weight gradient's channel rows.
+    Same products in the same order as the single launch: bit-identical to tile_hint = 1 (128-wide tiles everywhere)."""
+    x, w, b = rnd(B, Cin, H, H, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05), rnd(Cout, seed=3)
+    temb, res = rnd(B, Cout, seed=4), rnd(B, Cout, H, H, seed=5)
+    want = conv_ref(x, w, b, 1, (1, 1, 1, 1), False) + temb.double()[:, :, None, None] + res.double()
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        y = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), 1, (1, 1, 1, 1), False, rowadd=temb.to(dev), residual=nhwc(res))
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    # the planner splits where two exact launches model faster than one padded one (round quantisation counts): the
+    # CelebA-sized launches do (tile code 224 = 128-wide then 96-wide tiles), the small one runs a single width
+    keys = list(prof.summary())
+    assert [k[0] for k in keys] == [f"conv_fwd_patch_w{H}"] and keys[0][1] == (224 if B >= 32 else 96), keys
+    y128 = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), 1, (1, 1, 1, 1), False, rowadd=temb.to(dev), residual=nhwc(res), tile_hint=1)
+    close(y.permute(0, 3, 1, 2), want, atol=3e-5)
+    assert torch.equal(y, y128)
+    dy = rnd(B, Cout, H, H, seed=6)
+    xd, wd = x.double().requires_grad_(True), w.double().requires_grad_(True)
+    conv_ref(xd, wd, None, 1, (1, 1, 1, 1), False).backward(dy.double())
+    dw = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), False)
+    close(dw, wd.grad, atol=3e-5 * math.sqrt(B * H * H / 16))
 
 
 def test_conv_autograd_function(ops):
