@@ -160,7 +160,9 @@ class Attention(nn.Module):
         mode cached per weight version (sampling: thousands of forwards on fixed EMA weights)."""
         h, d, dp = self.heads, self.dim_head, self.dpad
         ps = (self.to_q.weight, self.to_q.bias, self.to_k.weight, self.to_k.bias, self.to_v.weight, self.to_v.bias)
-        if torch.is_grad_enabled():
+        if torch.is_grad_enabled() or torch.cuda.is_current_stream_capturing():
+            # (inside a hipGraph capture the padding launches belong to the graph: a replay re-pads the CURRENT weights, and
+            #  nothing allocated from the capture's pool is cached on the module)
             return tuple(ops.pad_heads(p, h, d, dp, 0) for p in ps) + (ops.pad_heads(self.to_out[0].weight, h, d, dp, 1),)
         key = tuple(ops.weight_key(p) for p in ps + (self.to_out[0].weight,))
         if getattr(self, "_pad_key", None) != key:
