@@ -40,7 +40,20 @@ static Geo make_geo(const gad_groupnorm_args* a) {
 __device__ __forceinline__ float silu_f(float z) { return z / (1.f + expf(-z)); }
 
 // ---------------------------------------------------------------- forward ----
-__global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, Geo g) {
+// Two sources (x2 != NULL): channels [0, C1) of the normalised tensor come from x ([B][HW][C1]) and [C1, C) from x2
+// ([B][HW][C - C1]) - UpBlock2D's torch.cat([h, skip], 1) read in place; C1 % 4 == 0, so a channel quad has one source.
+__device__ __forceinline__ const float* gn_src(const float* x, const float* x2, int C1, int C, int HW, int b, int c0, int* stride) {
+  if (x2 == nullptr || c0 < C1) {
+    const int w = x2 ? C1 : C;
+    *stride = w;
+    return x + ((long)b * HW) * w + c0;
+  }
+  *stride = C - C1;
+  return x2 + ((long)b * HW) * (C - C1) + (c0 - C1);
+}
+
+__global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ x, float* __restrict__ part, Geo g,
+                                                      const float* __restrict__ x2, int C1) {
   __shared__ float red[2 * MAXC];  // [rows_par][C] sums then sumsqs; rows_par*C <= max(1024, C)
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
   int p0 = ch * g.ppc, p1 = min(g.HW, p0 + g.ppc);
@@ -49,19 +62,20 @@ __global__ __launch_bounds__(NT) void gn_stats_kernel(const float* __restrict__ 
   if (prow < g.rows_par) {
     for (int cq = cfirst; cq < g.C4; cq += g.tpr) {
       f32x4 s = {0, 0, 0, 0}, ss = {0, 0, 0, 0};
-      const float* xb = x + ((long)b * g.HW) * g.C + cq * 4;
+      int ldx;
+      const float* xb = gn_src(x, x2, C1, g.C, g.HW, b, cq * 4, &ldx);
       int p = p0 + prow;
       const int R = g.rows_par;
       for (; p + 3 * R < p1; p += 4 * R) {      // 4 independent 16-B loads in flight per thread
-        f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
-        f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + R) * g.C);
-        f32x4 v2 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 2 * R) * g.C);
-        f32x4 v3 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 3 * R) * g.C);
+        f32x4 v0 = *reinterpret_cast<const f32x4*>(xb + (long)p * ldx);
+        f32x4 v1 = *reinterpret_cast<const f32x4*>(xb + (long)(p + R) * ldx);
+        f32x4 v2 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 2 * R) * ldx);
+        f32x4 v3 = *reinterpret_cast<const f32x4*>(xb + (long)(p + 3 * R) * ldx);
         s += (v0 + v1) + (v2 + v3);
         ss += (v0 * v0 + v1 * v1) + (v2 * v2 + v3 * v3);
       }
       for (; p < p1; p += R) {
-        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * g.C);
+        f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * ldx);
         s += v;
         ss += v * v;
       }
@@ -109,7 +123,8 @@ __device__ __forceinline__ void gn_combine(const float* part, Geo g, int b, floa
 __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ x, float* __restrict__ y,
                                                       const float* __restrict__ gamma, const float* __restrict__ beta,
                                                       const float* __restrict__ part, float* __restrict__ mean_out,
-                                                      float* __restrict__ rstd_out, Geo g, float eps, int silu) {
+                                                      float* __restrict__ rstd_out, Geo g, float eps, int silu,
+                                                      const float* __restrict__ x2, int C1) {
   __shared__ float s_mean[256], s_rstd[256];
   int b = blockIdx.x / g.nch, ch = blockIdx.x - b * g.nch;
   gn_combine(part, g, b, eps, s_mean, s_rstd);
@@ -135,12 +150,14 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
     }
     f32x4 scale = rs * ga, shift = be - mu * scale;
     long base = ((long)b * g.HW) * g.C + c0;
+    int ldx;
+    const float* xb = gn_src(x, x2, C1, g.C, g.HW, b, c0, &ldx);
     int p = p0 + prow;
     const int R = g.rows_par;
     for (; p + 3 * R < p1; p += 4 * R) {        // 4 independent 16-B loads in flight per thread
       f32x4 v[4];
 #pragma unroll
-      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(x + base + (long)(p + u * R) * g.C);
+      for (int u = 0; u < 4; ++u) v[u] = *reinterpret_cast<const f32x4*>(xb + (long)(p + u * R) * ldx);
 #pragma unroll
       for (int u = 0; u < 4; ++u) {
         f32x4 z = v[u] * scale + shift;
@@ -152,7 +169,7 @@ __global__ __launch_bounds__(NT) void gn_apply_kernel(const float* __restrict__ 
       }
     }
     for (; p < p1; p += R) {
-      f32x4 v = *reinterpret_cast<const f32x4*>(x + base + (long)p * g.C);
+      f32x4 v = *reinterpret_cast<const f32x4*>(xb + (long)p * ldx);
       f32x4 z = v * scale + shift;
       if (silu) {
 #pragma unroll
@@ -584,10 +601,8 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
   hipStream_t st = (hipStream_t)stream;
   SlabGeo sg;
   int nv = (a->flags & GAD_GN_TWO_PASS) ? 0 : make_slab(a, &sg);
-  if (a->x2) {
-    GAD_CHECK(nv, "gad_groupnorm_silu_fwd: the two-source input needs the one-pass plan (check gad_groupnorm_one_pass)");
-    GAD_CHECK(a->C1 > 0 && a->C1 < a->C && a->C1 % 4 == 0 && gad_aligned16(a->x2), "gad_groupnorm_silu_fwd: bad C1 / x2");
-  }
+  if (a->x2)
+    GAD_CHECK(a->C1 > 0 && a->C1 < a->C && a->C1 % 4 == 0 && (a->C - a->C1) % 4 == 0 && gad_aligned16(a->x2), "gad_groupnorm_silu_fwd: bad C1 / x2");
   if (nv) {
     const int c1 = a->x2 ? a->C1 : a->C;
     dim3 sgrid(a->B * sg.nslab), sblock(NT);
@@ -617,9 +632,10 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
   }
   Geo g = make_geo(a);
   dim3 grid(a->B * g.nch), block(NT);
-  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, a->x, (float*)a->ws, g);
+  hipLaunchKernelGGL(gn_stats_kernel, grid, block, 0, st, a->x, (float*)a->ws, g, a->x2, a->C1);
   GAD_LAUNCH_CHECK("gn_stats");
-  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, a->x, a->y, a->gamma, a->beta, (const float*)a->ws, a->mean, a->rstd, g, a->eps, a->silu);
+  hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, a->x, a->y, a->gamma, a->beta, (const float*)a->ws, a->mean, a->rstd, g, a->eps, a->silu,
+                     a->x2, a->C1);
   GAD_LAUNCH_CHECK("gn_apply");
   return 0;
 }

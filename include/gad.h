@@ -157,7 +157,7 @@ typedef struct gad_groupnorm_args {
   int64_t ws_bytes;
   /* forward only: channel-concatenated input without the concat (UpBlock2D's torch.cat([h, skip], 1),
    * SURVEY A.1): channels [0, C1) come from x ([B][HW][C1]) and [C1, C) from x2 ([B][HW][C-C1]).
-   * x2 == NULL: single source.  Needs the one-pass plan (gad_groupnorm_one_pass); C1 % 4 == 0. */
+   * x2 == NULL: single source.  C1 % 4 == 0 and (C - C1) % 4 == 0; both the one-pass and the two-pass plan read two sources. */
   const float* x2;
   int32_t C1;
   int32_t flags;            /* GAD_GN_TWO_PASS = 1: force the two-pass plan (A/B tests); 0 in production          */

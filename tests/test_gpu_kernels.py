@@ -805,11 +805,22 @@ def test_groupnorm_two_source_equals_concat(ops, B, C1, C2, H):
     assert torch.equal(got, want)
 
 
-def test_groupnorm_two_source_needs_the_one_pass_plan(ops):
-    x, x2 = nhwc(rnd(1, 256, 32, 32, seed=1)), nhwc(rnd(1, 128, 32, 32, seed=2))     # 384 channels at 32x32: two-pass only
-    assert not ops.group_norm_two_source_ok(x, x2, 32)
-    with pytest.raises(Exception):
-        ops.group_norm_cat_raw(x, x2, torch.ones(384, device=dev), torch.zeros(384, device=dev), 32, 1e-6, True)
+@pytest.mark.parametrize("B,C1,C2,H,G", [(1, 256, 128, 32, 32), (2, 192, 96, 32, 32), (2, 96, 96, 32, 32), (3, 64, 32, 16, 8)])
+def test_groupnorm_two_source_on_the_two_pass_plan(ops, B, C1, C2, H, G):
+    """Shapes without a one-pass slab plan (384 channels at 32x32; the pruned widths' 288 = 192 + 96 and 192 = 96 + 96 with 9 /
+    6 channels per group) - and the forced two-pass plan - read cat([x, x2]) in place too: bit-identical to the
+    materialised concatenation on the same plan."""
+    x, x2 = nhwc(rnd(B, C1, H, H, seed=1) + 0.5), nhwc(rnd(B, C2, H, H, seed=2) * 2)
+    ga, be = (rnd(C1 + C2, seed=3) * 0.3 + 1).to(dev), rnd(C1 + C2, seed=4).to(dev)
+    assert ops.group_norm_two_source_ok(x, x2, G)
+    for two_pass in (False, True):
+        with torch.no_grad(), ops.kernel_flags(gn_two_pass=two_pass):
+            got = ops.group_norm_cat_raw(x, x2, ga, be, G, 1e-6, True)
+            want = ops.group_norm(torch.cat([x, x2], -1).contiguous(), ga, be, G, 1e-6, True)
+        assert torch.equal(got, want)
+    xr = torch.cat([x, x2], -1).permute(0, 3, 1, 2).double().cpu()
+    ref = F.silu(F.group_norm(xr, G, ga.double().cpu(), be.double().cpu(), 1e-6)).permute(0, 2, 3, 1)
+    close(got, ref, rtol=2e-5, atol=2e-5)
 
 
 def test_unet_sampling_forward_without_concat_equals_grad_mode_forward(ops):
