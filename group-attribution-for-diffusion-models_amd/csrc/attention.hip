@@ -19,9 +19,14 @@
 // so probabilities never touch LDS, and the softmax statistics of a query (running max, sum, LSE, delta) are per-lane
 // scalars wherever the query sits on the lane index.  Row maxima need two cross-lane exchanges (lanes l, l^16, l^32).
 //
-// Backward is two kernels (dQ by query block, dK/dV by key block), each recomputing S and dP: 7 products instead of
-// the minimal 5, but every output element is produced by exactly one workgroup in a fixed order - no float atomics, so
-// a training step stays bit-reproducible (tests/test_gpu_fullsize.py relies on that).
+// Backward, head dims up to 96: ONE kernel per key block computes S and dP once and feeds dV, dK and dQ (the five products
+// of the minimal scheme); dQ partials of the key blocks of one (b, h) go to workspace slabs that a fixed-order reduce sums.
+// Wider heads (and bf16 operands) run two kernels - dQ by query block, dK/dV by key block - that each recompute S and dP
+// (7 products).  Either way every output element is produced in a fixed order - no float atomics, so a training step
+// stays bit-reproducible (tests/test_gpu_fullsize.py relies on that).
+//
+// Any head dim <= 256 and any alignment: launches that cannot stream 16-byte pieces (the pruned CelebA model's d = 23 in
+// 322-float rows) run the `RG` instances of the same kernels - dword staging through registers, masks at d.
 #include "gad_common.h"
 
 namespace {

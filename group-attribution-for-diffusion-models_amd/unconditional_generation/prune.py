@@ -15,6 +15,8 @@ installable offline, so the dependency analysis is restated here for the UNet2DM
     normalizer="mean");
   * spaces that pass through a GroupNorm lose the same number of channels from every norm group, so the
     widths stay multiples of the group count (128 -> 96, 256 -> 192 at ratio 0.3).
+`--pruner taylor | diff-pruning` (reference :320-332, :358-378): first-order Taylor importance |sum w g| / sum |w g| from
+gradients accumulated over the training timesteps on one batch, through the same channel spaces and selection rule.
 Deviation kept on purpose: spaces without a GroupNorm (time embedding, attention q/k and v) are cut to the width
 the model constructor derives from `block_out_channels` (4 x width0, stage width) rather than to
 int(w * (1 - ratio)), so the pruned network is described by a plain `unet_config` and its state_dict - the
@@ -40,7 +42,9 @@ def parse_args(argv=None):
     p.add_argument("--outdir", type=str, default=constants.OUTDIR)
     p.add_argument("--opt_seed", type=int, default=42)
     p.add_argument("--pruning_ratio", type=float, default=0.3)
-    p.add_argument("--pruner", type=str, default="magnitude", choices=["magnitude", "random", "reinit"])
+    p.add_argument("--pruner", type=str, default="magnitude", choices=["magnitude", "random", "reinit", "taylor", "diff-pruning"])
+    p.add_argument("--batch_size", type=int, default=None, help="batch of the Taylor gradient accumulation (default: the config's)")
+    p.add_argument("--device", type=str, default="cuda:0")
     p.add_argument("--thr", type=float, default=0.05)
     p.add_argument("--trained_steps", type=int, default=None)
     return p.parse_args(argv)
@@ -189,18 +193,32 @@ def build_spaces(cfg, ratio=0.0):
     return spaces
 
 
-def channel_scores(space, sd):
+def channel_scores(space, sd, grads=None, multivariable=True):
+    """Importance of the space's channels, mean over its scored tensors, normalised by its mean.
+    grads is None: squared L2 magnitude (MagnitudeImportance p = 2).  Else first-order Taylor (reference prune.py:320-332):
+    |sum_j w_j g_j| over a channel's slice (`--pruner taylor`, TaylorImportance(multivariable=True)) or sum_j |w_j g_j|
+    (`--pruner diff-pruning`, multivariable=False)."""
     acc = []
     for name, dim, off in space.scored:
         w = sd[name].double()
         w = w.transpose(0, dim).reshape(w.shape[dim], -1)[off:off + space.width]
-        acc.append(w.pow(2).sum(dim=1))
+        if grads is None:
+            acc.append(w.pow(2).sum(dim=1))
+        else:
+            g = grads[name].double()
+            g = g.transpose(0, dim).reshape(g.shape[dim], -1)[off:off + space.width]
+            acc.append((w * g).sum(dim=1).abs() if multivariable else (w * g).abs().sum(dim=1))
     s = torch.stack(acc).mean(dim=0)
-    return (s / s.mean()).numpy()
+    return (s / s.mean().clamp_min(1e-300)).numpy()
 
 
-def select_channels(space, sd, target, mode="magnitude", rng=None):
-    score = channel_scores(space, sd) if mode == "magnitude" else rng.rand(space.width)
+def select_channels(space, sd, target, mode="magnitude", rng=None, grads=None):
+    if mode == "magnitude":
+        score = channel_scores(space, sd)
+    elif mode in ("taylor", "diff-pruning"):
+        score = channel_scores(space, sd, grads, multivariable=(mode == "taylor"))
+    else:
+        score = rng.rand(space.width)
     if space.heads:                                  # importance summed over the heads per in-head position
         d = space.width // space.heads
         keep_d = target // space.heads
@@ -218,7 +236,33 @@ def select_channels(space, sd, target, mode="magnitude", rng=None):
     return np.sort(np.argsort(-score, kind="stable")[:target])
 
 
-def prune_state_dict(cfg, sd, ratio, mode="magnitude", seed=42):
+def taylor_gradients(model, scheduler, clean_images, noise, mode, thr, log=print):
+    """Accumulated parameter gradients of the denoising loss over the timesteps t = 0, 1, 2, ... with the SAME batch and
+    noise at every step (reference prune.py:358-378).  `diff-pruning` stops once the loss has fallen below thr x the
+    largest loss seen so far (Taylor expansion over the pruned timesteps only, L_t / L_max > thr)."""
+    import torch.nn.functional as F
+    model.zero_grad()
+    model.eval()
+    loss_max, used = 0.0, 0
+    for step_k in range(scheduler.config.num_train_timesteps):
+        t = torch.full((clean_images.shape[0],), step_k, device=clean_images.device, dtype=torch.long)
+        out = model(scheduler.add_noise(clean_images, noise, t), t).sample
+        loss = F.mse_loss(out, noise)
+        loss.backward()                                       # gradients accumulate across the timesteps
+        used += 1
+        if mode == "diff-pruning":
+            lv = float(loss.detach())
+            loss_max = max(loss_max, lv)
+            if lv < loss_max * thr:
+                break
+    log(f"Accumulated gradients over {used} timesteps for pruning")
+    grads = {n: (p.grad.detach().cpu().contiguous() if p.grad is not None else torch.zeros_like(p).cpu())
+             for n, p in model.named_parameters()}
+    model.zero_grad()
+    return grads
+
+
+def prune_state_dict(cfg, sd, ratio, mode="magnitude", seed=42, grads=None):
     """-> (new unet_config, new state_dict).  Widths of the new config: pruned_width(w, ratio, groups) per stage."""
     G = cfg.get("norm_num_groups", 32)
     boc = list(cfg["block_out_channels"])
@@ -227,7 +271,7 @@ def prune_state_dict(cfg, sd, ratio, mode="magnitude", seed=42):
     spaces = build_spaces(cfg, ratio)
     plan = {}                                   # param -> {dim: [(offset, width, keep idx)]}
     for sp in spaces:
-        sp.keep = select_channels(sp, sd, sp.target, mode, rng)
+        sp.keep = select_channels(sp, sd, sp.target, mode, rng, grads)
         for name, dim, off in sp.members:
             plan.setdefault(name, {}).setdefault(dim, []).append((off, sp.width, sp.keep))
     out = {}
@@ -257,8 +301,27 @@ def main(args, backend=None):
     cfg = dict(ck.get("unet_config") or dataset_config(args.dataset)["unet_config"])
     sd = {k: v.detach().cpu().contiguous() for k, v in ck["unet"].items()}
     base = sum(v.numel() for v in sd.values())
-    mode = "magnitude" if args.pruner == "magnitude" else "random"
-    new_cfg, new_sd = prune_state_dict(cfg, sd, args.pruning_ratio, mode, args.opt_seed)
+    mode = args.pruner if args.pruner in ("magnitude", "taylor", "diff-pruning") else "random"
+    grads = None
+    if mode in ("taylor", "diff-pruning"):
+        # one batch of the training set and one noise draw, as the reference's `clean_images` / `noise` (prune.py:240-251)
+        from src.datasets import create_dataset
+        from src.diffusion_utils import dataset_config as _dc
+        full_cfg = _dc(args.dataset)
+        bs = args.batch_size or full_cfg["batch_size"]
+        ds = create_dataset(dataset_name=args.dataset, train=True)
+        order = torch.randperm(len(ds), generator=torch.Generator().manual_seed(args.opt_seed))[:bs].tolist()
+        dev = torch.device(args.device)
+        clean = torch.stack([torch.as_tensor(ds[i][0]) for i in order]).float().to(dev)
+        noise = torch.randn(clean.shape, generator=torch.Generator().manual_seed(args.opt_seed + 1)).to(dev)
+        dense = getattr(backend, cfg["_class_name"])(**cfg)
+        dense.load_state_dict(sd)
+        dense.to(dev)
+        keys = ("beta_start", "beta_end", "beta_schedule", "num_train_timesteps", "trained_betas")
+        sched = backend.DDPMScheduler(**{k: v for k, v in full_cfg["scheduler_config"].items() if k in keys})
+        grads = taylor_gradients(dense, sched, clean, noise, mode, args.thr)
+        del dense
+    new_cfg, new_sd = prune_state_dict(cfg, sd, args.pruning_ratio, mode, args.opt_seed, grads)
     model = getattr(backend, new_cfg["_class_name"])(**new_cfg)
     if args.pruner == "reinit":
         new_sd = {k: v.detach().cpu().contiguous() for k, v in model.state_dict().items()}

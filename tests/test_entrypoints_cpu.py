@@ -211,6 +211,64 @@ def test_structural_magnitude_pruning(tmp_path):
     assert out.endswith("toy2/pruned/models/pruner=magnitude_pruning_ratio=0.3_threshold=0.05")
 
 
+def test_taylor_and_diff_pruning_importance(tmp_path):
+    """`--pruner taylor | diff-pruning` (reference prune.py:320-332, 358-378): gradients accumulated over the training
+    timesteps on ONE batch with ONE noise draw; importance |sum w g| (taylor) or sum |w g| (diff-pruning) per channel,
+    mean over the space's tensors; diff-pruning stops once L_t < thr * L_max.  Checked on a small U-Net against a direct
+    recomputation from autograd, then end to end through the entry point on the oracle backend."""
+    from src.ddpm_config import DDPMConfig
+    from unconditional_generation import prune as P
+    cfg = dict(DDPMConfig.cifar100_config["unet_config"], block_out_channels=[32, 32, 64, 64], norm_num_groups=8)
+    torch.manual_seed(0)
+    net = OB.UNet2DModel(**cfg)
+    sd = {k: v.detach().clone() for k, v in net.state_dict().items()}
+    sched = OB.DDPMScheduler(num_train_timesteps=6)
+    g = torch.Generator().manual_seed(1)
+    clean, noise = torch.rand(4, 3, 32, 32, generator=g) * 2 - 1, torch.randn(4, 3, 32, 32, generator=g)
+    msgs = []
+    grads = P.taylor_gradients(net, sched, clean, noise, "taylor", 0.05, log=msgs.append)
+    assert "6 timesteps" in msgs[0] and all(p.grad is None or not p.grad.any() for p in net.parameters())
+    # direct recomputation: sum over t of d mse(model(add_noise(x, n, t), t), n) / d theta
+    ref = OB.UNet2DModel(**cfg)
+    ref.load_state_dict(sd)
+    for t in range(6):
+        tt = torch.full((4,), t, dtype=torch.long)
+        torch.nn.functional.mse_loss(ref(sched.add_noise(clean, noise, tt), tt).sample, noise).backward()
+    for n, p in ref.named_parameters():
+        assert torch.allclose(grads[n], p.grad, rtol=1e-5, atol=1e-7), n
+    spaces = {s.name: s for s in P.build_spaces(cfg, 0.25)}
+    inner = spaces["down_blocks.0.resnets.0.inner"]
+    for mode, multi in (("taylor", True), ("diff-pruning", False)):
+        score = P.channel_scores(inner, sd, grads, multivariable=multi)
+        want = []
+        for name, dim, off in inner.scored:
+            wg = (sd[name].double() * grads[name].double()).transpose(0, dim).reshape(sd[name].shape[dim], -1)[off:off + inner.width]
+            want.append(wg.sum(1).abs() if multi else wg.abs().sum(1))
+        want = torch.stack(want).mean(0)
+        assert np.allclose(score, (want / want.mean()).numpy(), rtol=1e-10)
+        keep = P.select_channels(inner, sd, inner.target, mode, None, grads)
+        cpg = inner.width // 8
+        for grp in range(8):                                            # within each norm group: the highest-importance channels
+            idx = np.arange(grp * cpg, (grp + 1) * cpg)
+            kept = [c for c in keep if c in idx]
+            assert len(kept) == inner.target // 8 and min(score[kept]) >= max([score[c] for c in idx if c not in kept] + [-1])
+    # diff-pruning stops once L_t < thr * L_max: force it with a threshold above 1
+    msgs.clear()
+    P.taylor_gradients(net, sched, clean, noise, "diff-pruning", 1.1, log=msgs.append)
+    assert "1 timesteps" in msgs[0]                                    # L_0 < 1.1 * L_max already at the first step (:372-376)
+    # entry point on the oracle backend
+    mdir = tmp_path / "toy2" / "retrain" / "models" / "full"
+    os.makedirs(mdir)
+    torch.save({"unet": sd, "unet_config": cfg}, mdir / "ckpt_steps_00000010.pt")
+    out = P.main(P.parse_args(["--load", str(mdir), "--dataset", "toy2", "--outdir", str(tmp_path), "--pruner", "taylor",
+                               "--pruning_ratio", "0.25", "--batch_size", "2", "--device", "cpu"]), backend=OB)
+    ck = torch.load(os.path.join(out, "ckpt_steps_00000000.pt"), weights_only=False)
+    assert ck["unet_config"]["block_out_channels"] == [24, 24, 48, 48]
+    assert out.endswith("toy2/pruned/models/pruner=taylor_pruning_ratio=0.25_threshold=0.05")
+    small = OB.UNet2DModel(**ck["unet_config"])
+    small.load_state_dict(ck["unet"])
+
+
 def test_head_grouped_pruning_of_the_celeba_topology():
     """prune.py:337-342 (channel_groups[to_q/k/v] = heads): every head of q / k / v keeps the SAME in-head channels, the
     stream widths follow the GroupNorm rule, the sliced state_dict loads strictly into the `attention_layout` model and
