@@ -1502,14 +1502,16 @@ __global__ __launch_bounds__(NTHREADS) void conv3x3_patch_f32_kernel(const DevAr
 // workspace and through splitk_reduce_kernel, as for the generic split-K.
 // ------------------------------------------------------------------------------------
 // Output-channel tiles.  BM = 128: wave w owns channels [32 w, 32 w + 32) and all nine taps (9 accumulator tiles).
-// BM = 96 (the pruned widths 96 / 192 that unlearn.py:363-367 fine-tunes, CelebA's 672): a 128-channel tile would leave a
-// wave idle, so the 3 channel groups x 9 taps = 27 (group, tap) units are dealt 7 / 7 / 7 / 6 to the four waves - wave w
-// owns units [7 w, 7 w + 7), which touch at most two channel groups and never repeat a tap.  Which accumulator meets which
-// fragment must be static, so the K loop is instantiated per wave (WAVE = 0..3; -1 = the BM = 128 form, wave at run time).
+// BM = 96 (the pruned widths 96 / 192 that unlearn.py:363-367 fine-tunes, CelebA's 672), 64, 32 (the tail of 160 = 128 + 32):
+// a 128-channel tile would leave waves idle, so the BM / 32 channel groups x 9 taps (group, tap) units are dealt evenly to
+// the four waves - 27 units as 7 / 7 / 7 / 6, 18 as 5 / 5 / 4 / 4, 9 as 3 / 2 / 2 / 2 -, consecutive units per wave, which
+// touch at most two channel groups and never repeat a tap.  Which accumulator meets which fragment must be static, so the
+// K loop is instantiated per wave (WAVE = 0..3; -1 = the BM = 128 form, wave at run time).
 template <int BM, int WAVE>
 struct WgradUnits {
-  static constexpr int U0 = BM == 128 ? 0 : 7 * WAVE;
-  static constexpr int N = BM == 128 ? 9 : (27 - U0 < 7 ? 27 - U0 : 7);
+  static constexpr int NU = BM / 32 * 9;                                       // (channel group, tap) units of the tile
+  static constexpr int U0 = BM == 128 ? 0 : WAVE * (NU / 4) + (WAVE < NU % 4 ? WAVE : NU % 4);
+  static constexpr int N = BM == 128 ? 9 : NU / 4 + (WAVE < NU % 4 ? 1 : 0);  // 96: 7 7 7 6;  64: 5 5 4 4;  32: 3 2 2 2
   static constexpr int CG0 = BM == 128 ? 0 : U0 / 9;                          // BM = 128: + wave at run time
   static constexpr bool TWO = BM != 128 && (U0 + N - 1) / 9 != CG0;            // the units span two channel groups
   static constexpr int tap(int i) { return BM == 128 ? i : (U0 + i) % 9; }
@@ -2072,12 +2074,35 @@ static bool use_fewout_conv(const gad_gemm_args* a) {
 }
 
 // 3x3 / stride 1 / pad 1 weight gradient with the LDS-patch kernel: pixel-split count (0 = not eligible) and the
-// output-channel tile: 96 where 128-channel tiles would idle a wave on a quarter or more of them (M = 96, 192, 288, 672):
-// modelled time = tiles x (accumulator units per wave: 9 at 128, 7 at 96, the latter with 5 % more fragment reads per MFMA)
-static int wgrad_patch_bm(const gad_gemm_args* a) {
-  const double c128 = (double)gad_ceil_div(a->M, 128) * 9.0, c96 = (double)gad_ceil_div(a->M, 96) * 7.0 * 1.05;
-  return (c96 < c128 && a->M % 4 == 0) ? 96 : 128;
+// output-channel tile: 96 / 64 / 32 where 128-channel tiles would idle waves (M = 96, 192, 288; 64; 32), by modelled time.
+// Modelled time of ONE weight-gradient patch launch over M output channels on bm-channel tiles, calibrated on
+// tools/ab_wgrad_tiles.py (profiles/r03_ab_wgrad_tiles.txt: within ~3 % of the measured ratios): rounds of 512 resident
+// workgroups x (K steps per workgroup + 3 steps' worth of prologue / epilogue) x the tile's cost per step - accumulator units
+// of the busiest wave, the dealt forms (96 / 64 / 32) reading more fragments per MFMA.
+static double wgrad_unit(int bm) { return bm == 128 ? 9.0 : bm == 96 ? 7.7 : bm == 64 ? 5.3 : 4.5; }
+static long wgrad_sp(long M, int bm, int C, long ksteps) {
+  const long groups = gad_ceil_div(M, bm) * (C / BK);
+  long sp = 512 / groups;                 // one round of 2 workgroups per CU
+  if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
+  return sp < 1 ? 1 : sp;
 }
+static double wgrad_launch_cost(const gad_gemm_args* a, long M, int bm) {
+  const long ksteps = a->K / BK, groups = gad_ceil_div(M, bm) * (a->g.C / BK), sp = wgrad_sp(M, bm, a->g.C, ksteps);
+  const long per = gad_ceil_div(ksteps, sp), spe = gad_ceil_div(ksteps, per);
+  return (double)gad_ceil_div(groups * spe, 512) * (double)(per + 3) * wgrad_unit(bm);
+}
+static int wgrad_best_bm(const gad_gemm_args* a, long M, double* cost_out = nullptr) {
+  int best = 128;
+  double bc = 1e300;
+  const int cand[4] = {128, 96, 64, 32};
+  for (int bm : cand) {
+    const double c = wgrad_launch_cost(a, M, bm);
+    if (c < bc * (1 - 1e-9)) { bc = c; best = bm; }
+  }
+  if (cost_out) *cost_out = bc;
+  return best;
+}
+static int wgrad_patch_bm(const gad_gemm_args* a) { return a->M % 4 == 0 ? wgrad_best_bm(a, a->M) : 128; }
 static int wgrad_patch_splits(const gad_gemm_args* a, int* bm_out = nullptr) {
   const gad_conv_geom& g = a->g;
   if (a->flags & GAD_GEMM_NO_PATCH) return 0;
@@ -2087,33 +2112,42 @@ static int wgrad_patch_splits(const gad_gemm_args* a, int* bm_out = nullptr) {
   if (!(g.Wo == 64 || g.Wo == 32 || g.Wo == 16 || g.Wo == 8) || (g.Ho * g.Wo) % BK != 0 || a->K % BK != 0 || g.C % BK != 0 || a->M % 32 != 0) return 0;
   if (a->batch > 1 || a->tile_hint == 2 || a->splitk_hint > 0 || a->lda % 4 != 0) return 0;
   if ((long)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.ldx >= (1L << 31)) return 0;
-  const int bm = a->tile_hint == 1 ? 128 : wgrad_patch_bm(a);      // tile_hint 1: 128-channel tiles (A/B, tests)
+  // tile_hint (A/B tools, tests): 1 / 4 / 5 / 6 = one launch on 128 / 96 / 64 / 32-channel tiles; >= 1000 is handled by
+  // wgrad_split_m (rows [0, hint - 1000) on 128-channel tiles, the rest planned)
+  const int bm = a->tile_hint == 1 ? 128 : a->tile_hint == 4 ? 96 : a->tile_hint == 5 ? 64 : a->tile_hint == 6 ? 32 : wgrad_patch_bm(a);
   if (bm_out) *bm_out = bm;
-  const long ksteps = a->K / BK, groups = gad_ceil_div(a->M, bm) * (g.C / BK);
-  long sp = 512 / groups;                 // one round of 2 workgroups per CU
-  if (sp > ksteps / 8) sp = ksteps / 8;   // >= 8 K steps per workgroup
-  if (sp < 1) sp = 1;
-  return (int)sp;
+  return (int)wgrad_sp(a->M, bm, g.C, a->K / BK);
 }
 
-// The same for the weight gradient's output channels (M): 224 = 128 + 96, 320 = 128 + 2 x 96, 448, 480 run as two launches
-// over disjoint row ranges (128-channel tiles, then 96-channel tiles) when the accumulator-unit model prefers it.
+// The same for the weight gradient's output channels (M): 224 = 128 + 96, 160 = 128 + 32, 320 = 256 + 64, 448 = 256 + 192,
+// 672 = 384 + 288 run as two launches over disjoint row ranges (128-channel tiles, then one narrower width) when the
+// launch model prefers that to the best single width by 2 % or more.
 static bool wgrad_split_m(const gad_gemm_args* a, int* m1_out) {
-  if (a->tile_hint != 0 || a->M % 32 != 0 || a->M < 224 || !wgrad_patch_splits(a)) return false;
-  const double single = fmin((double)gad_ceil_div(a->M, 128) * 9.0, (double)gad_ceil_div(a->M, 96) * 7.0 * 1.05);
-  for (int m2 = 96; m2 < a->M; m2 += 96) {
-    const int m1 = a->M - m2;
-    if (m1 % 128 != 0) continue;
-    if ((m1 / 128) * 9.0 + (m2 / 96) * 7.0 * 1.05 < 0.97 * single) {
-      *m1_out = m1;
-      return true;
-    }
+  if (a->tile_hint >= 1000) {                                // forced split point (A/B tools)
+    gad_gemm_args probe = *a;
+    probe.tile_hint = 0;
+    const int m1 = a->tile_hint - 1000;
+    if (m1 <= 0 || m1 >= a->M || m1 % 128 != 0 || (a->M - m1) % 32 != 0 || !wgrad_patch_splits(&probe)) return false;
+    *m1_out = m1;
+    return true;
   }
-  return false;
+  if (a->tile_hint != 0 || a->M % 32 != 0 || a->M < 160 || !wgrad_patch_splits(a)) return false;
+  double single;
+  wgrad_best_bm(a, a->M, &single);
+  double best = 0.98 * single;
+  bool found = false;
+  for (int m1 = 128; m1 < a->M; m1 += 128) {                  // 128-channel tiles first, the rest on its best single width
+    double c2;
+    wgrad_best_bm(a, a->M - m1, &c2);
+    const double c = wgrad_launch_cost(a, m1, 128) + c2;
+    if (c < best) { best = c; *m1_out = m1; found = true; }
+  }
+  return found;
 }
 static void wgrad_split_args(const gad_gemm_args* a, int m1, gad_gemm_args* lo, gad_gemm_args* hi) {
   *lo = *a;
   *hi = *a;
+  if (a->tile_hint >= 1000) lo->tile_hint = hi->tile_hint = 0;
   lo->M = m1;
   hi->M = a->M - m1;
   hi->A = a->A + m1;                       // A_MC: dy [pixels][Cout], the output channel is the contiguous index
@@ -2363,6 +2397,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
 #define GAD_WGRAD(W_)                                                                                   \
     do {                                                                                                \
       if (wbm == 96) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 96>), grid, block, 0, st, d);    \
+      else if (wbm == 64) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 64>), grid, block, 0, st, d);  \
+      else if (wbm == 32) hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 32>), grid, block, 0, st, d);  \
       else hipLaunchKernelGGL((wgrad3x3_patch_f32_kernel<W_, 128>), grid, block, 0, st, d);             \
     } while (0)
     if (a->g.Wo == 64) GAD_WGRAD(64);
