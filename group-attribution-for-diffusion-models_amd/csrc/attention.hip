@@ -741,17 +741,23 @@ __global__ __launch_bounds__(NT) void attn_bwd1_f32_kernel(const AttnDev p) {
     barrier_after_dma();
   }
 
-  // dQ of query tile `tq` from the dS image it left behind: output tile o = (i = o % NDV, t = o / NDV) -> wave o % 4
+  // dQ of `ntq` (1 or 2) consecutive 32-query tiles starting at tile tq0 from the dS images they left behind (tile tq in
+  // half tq & 1): output tile o = (i = o % NDV, t = o / NDV) with t counting 16-query sub-tiles -> wave o % 4.
+  // PAIR (an odd number of 16-wide head-dim tiles: d = 40 / 48 has 3, d = 80 has 5): 2 NDV output tiles per query tile do
+  // not split over four waves (6 -> 2, 2, 1, 1), so the product runs once per TWO query tiles (4 NDV tiles: 3 or 5 per
+  // wave) right after the second one's barrier, plus one barrier that keeps the next tile's dS writes behind these reads.
+  constexpr bool PAIR = (C::NDV % 2) == 1;
   const bool direct = p.nblk == 1;
-  auto dq_phase = [&](int tq) {
-    const float* dsb = dsimg + (tq & 1) * W::DSIMG;
+  auto dq_phase = [&](int tq0, int ntq) {
+    const int nout = 2 * ntq * C::NDV;
 #pragma unroll
-    for (int oo = 0; oo < (W::NOUT + 3) / 4; ++oo) {
+    for (int oo = 0; oo < (2 * (PAIR ? 2 : 1) * C::NDV + 3) / 4; ++oo) {
       const int o = wave + 4 * oo;
-      if (o >= W::NOUT) break;                       // wave-uniform
-      const int i = o % C::NDV, t = o / C::NDV;
+      if (o >= nout) break;                          // wave-uniform
+      const int i = o % C::NDV, t = o / C::NDV, tq = tq0 + (t >> 1);
+      const float* dsb = dsimg + (tq & 1) * W::DSIMG;
       f32x4 acc0 = f32x4{0.f, 0.f, 0.f, 0.f}, acc1 = f32x4{0.f, 0.f, 0.f, 0.f};      // two chains: the f32 MFMA's dependent latency
-      const float* brow = dsb + (16 * t + c) * SQ + 4 * g;          // dS[q = 16 t + c][keys 16 m + 4 g ..+3]
+      const float* brow = dsb + (16 * (t & 1) + c) * SQ + 4 * g;    // dS[q = 16 (t & 1) + c][keys 16 m + 4 g ..+3]
       const float* arow = kimg + (16 * i + c) * SQ + 4 * g;         // K^T[kdim = 16 i + c][the same keys]
 #pragma unroll 2
       for (int m = 0; m < KB / 16; m += 2) {
@@ -764,7 +770,7 @@ __global__ __launch_bounds__(NT) void attn_bwd1_f32_kernel(const AttnDev p) {
         }
       }
       const f32x4 acc = acc0 + acc1;
-      const int q = tq * KV + 16 * t + c;
+      const int q = tq * KV + 16 * (t & 1) + c;
       if (q < p.Tq) {
         if (direct) {
           store_cols<D, RG>(p.dq + b * p.sdq + h * p.d + (long)q * p.lddq, 16 * i + 4 * g, acc * p.scale, p.d);
@@ -787,7 +793,7 @@ __global__ __launch_bounds__(NT) void attn_bwd1_f32_kernel(const AttnDev p) {
       qs.issue(nb, Q, p.ldq, (it + 1) * KV, p.Tq, p.d);
       gs.issue(nb + C::TILE, DO, p.lddo, (it + 1) * KV, p.Tq, p.d);
     }
-    if (it > 0) dq_phase(it - 1);
+    if (!PAIR && it > 0) dq_phase(it - 1, 1);        // (deferred by one iteration: the loop's own barrier orders it)
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
       f32x4 pr[NK], ds[NK];
@@ -848,8 +854,13 @@ __global__ __launch_bounds__(NT) void attn_bwd1_f32_kernel(const AttnDev p) {
       gs.commit(nb + C::TILE);
     }
     barrier_after_dma();
+    if (PAIR && (it & 1)) {
+      dq_phase(it - 1, 2);
+      __syncthreads();                               // the next tile's dS goes where these reads were
+    }
   }
-  dq_phase(ntiles - 1);
+  if (!PAIR) dq_phase(ntiles - 1, 1);
+  else if (ntiles & 1) dq_phase(ntiles - 1, 1);
 #pragma unroll
   for (int j = 0; j < NK; ++j)
     if (kok[j]) {
