@@ -81,7 +81,9 @@ typedef struct gad_gemm_args {
   /* split-K workspace (caller owned). ws_bytes >= gad_gemm_workspace_bytes(args)            */
   void* ws;
   int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms) */
+  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms); 3x3 weight gradient:
+                             * 1 / 4 / 5 / 6 = 128 / 96 / 64 / 32 output channels per tile, 1000 + m1 = rows [0, m1) on 128-channel
+                             * tiles and the rest planned, as a second launch (A/B tools) */
   int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
   /* 0: fp32 operands on v_mfma_f32_32x32x2_f32 (exact products; the reference's default precision).
    * 1: A and B may be rounded to bf16 (RNE) in flight and multiplied on v_mfma_f32_32x32x16_bf16 with fp32
