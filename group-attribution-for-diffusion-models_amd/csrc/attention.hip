@@ -218,10 +218,10 @@ __device__ __forceinline__ void store_cols(float* rowptr, int col0, const f32x4&
 // k = 16 grp + 4 g + j (float4 per group), the 8-wide tail k = 16 G16 + 2 g + j (float2).  The SAME k assignment is
 // used for both operands of a product, which is all a contraction needs.
 template <int D>
-__device__ __forceinline__ void row_frag_lds(const float* tile, int r0, float (&f)[Cfg<D>::KS]) {
+__device__ __forceinline__ void row_frag_lds(const float* tile, int r0, float (&f)[Cfg<D>::KS], int stride = Cfg<D>::S) {
   using C = Cfg<D>;
   const int lane = threadIdx.x & 63, r = r0 + (lane & 15), g = lane >> 4;
-  const float* p = tile + r * C::S;
+  const float* p = tile + r * stride;
 #pragma unroll
   for (int grp = 0; grp < C::G16; ++grp) {
     const f32x4 v = *reinterpret_cast<const f32x4*>(p + 16 * grp + 4 * g);
@@ -411,6 +411,145 @@ __global__ __launch_bounds__(NT) void attn_fwd_f32_kernel(const AttnDev p) {
       for (int i = 0; i < C::NDV; ++i) store_cols<D, RG>(O + (long)row * p.ldo, 16 * i + 4 * g, o[i][t] * inv, p.d);
       if (g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m[t] + __builtin_amdgcn_logf(lt);   // v_log_f32 = log2
     }
+  }
+}
+
+// ------------------------------------------------------------------------------------------------------------------
+// forward for WIDE heads (d >= 160: one head of 256 / 192 on CIFAR, 160 on SD's deepest level): the kernel above holds a
+// query tile's whole head dim per wave (64 fragment + 64 accumulator registers at d = 256) and runs one wave per SIMD.
+// Here a workgroup is 8 waves = two per SIMD: wave (w4 = wave & 3, dh = wave >> 2) owns 16 queries and ONE HALF of the head
+// dim - half the contraction of S^T = K Q^T and half the output tiles of O^T = V^T P^T.  The two partial score tiles of a
+// query block meet through LDS (8 floats per lane, summed half 0 + half 1 by both partners, so both hold bit-identical
+// scores and take identical softmax decisions), each partner then multiplies the probabilities into its own dv half.
+// Registers halve (<= 128: two waves per SIMD hide each other's LDS reads and softmax), the K / V tiles in LDS are shared by
+// twice the waves.  Same arithmetic per element as the 4-wave kernel except the order of the score's k-sum (two halves).
+// ------------------------------------------------------------------------------------------------------------------
+constexpr int NTW = 512;
+template <int D>
+__global__ __launch_bounds__(NTW) void attn_fwd_wide_f32_kernel(const AttnDev p) {
+  using C = Cfg<D>;
+  using CH = Cfg<D / 2>;
+  static_assert(D % 32 == 0, "both halves are whole 16-wide tiles");
+  constexpr int KSH = C::KS / 2, NDVH = C::NDV / 2;
+  extern __shared__ __attribute__((aligned(16))) float lds[];     // [2][K tile | V tile] | exchange [2][4][64][8]
+  float* const xch = lds + 4 * C::TILE;
+  const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
+  const int w4 = wave & 3, dh = wave >> 2;
+  const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
+  const float* Q = p.q + b * p.sq + h * p.d + dh * (D / 2);
+  const float* K = p.k + b * p.sk + h * p.d;
+  const float* V = p.v + b * p.sv + h * p.d;
+  const int row = blk * 64 + w4 * 16 + c;
+
+  float qf[KSH];
+  row_frag_global<D / 2>(Q, p.ldq, row, row < p.Tq, p.scale * LOG2E, qf);
+  f32x4 o[NDVH];
+#pragma unroll
+  for (int i = 0; i < NDVH; ++i) o[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  float m = NEG_BIG, l = 0.f;
+
+  // 8-wave staging: piece (wave + 8 i) of a tile, fixed (row, column) per lane as in TilePlan
+  constexpr int NP8 = (C::NPIECE + 7) / 8;
+  int koff[NP8], voff[NP8];
+#pragma unroll
+  for (int i = 0; i < NP8; ++i) {
+    const int piece = wave + 8 * i;
+    const int f = (piece * 64 + lane) * 4;
+    const int r = f / C::S, col = f - r * C::S;
+    const bool ok = piece < C::NPIECE && r < KV && col < D;
+    koff[i] = ok ? r * p.ldk + col : -1;
+    voff[i] = ok ? r * p.ldv + col : -1;
+  }
+  const int wv = __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6));
+  auto stage = [&](float* buf, int row0) {
+    const bool whole = row0 + KV <= p.Tk;
+#pragma unroll
+    for (int i = 0; i < NP8; ++i) {
+      const int piece = wv + 8 * i;
+      if (piece < C::NPIECE) {
+        const int f = (piece * 64 + lane) * 4;
+        const int r = f / C::S;
+        const bool okk = koff[i] >= 0 && (whole || row0 + r < p.Tk);
+        glds16(okk ? K + (long)row0 * p.ldk + koff[i] : (const float*)g_attn_zero, buf + piece * 256);
+        glds16(okk ? V + (long)row0 * p.ldv + voff[i] : (const float*)g_attn_zero, buf + C::TILE + piece * 256);
+      }
+    }
+  };
+  const int ntiles = (p.Tk + KV - 1) / KV;
+  stage(lds, 0);
+  barrier_after_dma();
+
+  for (int it = 0; it < ntiles; ++it) {
+    const float* kt_ = lds + (it & 1) * (2 * C::TILE);
+    const float* vt_ = kt_ + C::TILE;
+    if (it + 1 < ntiles) stage(lds + ((it + 1) & 1) * (2 * C::TILE), (it + 1) * KV);
+    // partial S^T over this wave's half of the head dim
+    f32x4 s[2];
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt) {
+      float kf[KSH];
+      row_frag_lds<D / 2>(kt_ + dh * (D / 2), 16 * kt, kf, C::S);
+      s[kt] = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+      for (int st = 0; st < KSH; ++st) s[kt] = mfma16(kf[st], qf[st], s[kt]);
+    }
+    float* mine = xch + ((dh * 4 + w4) * 64 + lane) * 8;
+    *reinterpret_cast<f32x4*>(mine) = s[0];
+    *reinterpret_cast<f32x4*>(mine + 4) = s[1];
+    __builtin_amdgcn_s_waitcnt(0xC07F);            // lgkmcnt(0) only: the next tile's LDS-DMA stays in flight across this barrier
+    __builtin_amdgcn_s_barrier();
+    {
+      const float* h0 = xch + ((0 * 4 + w4) * 64 + lane) * 8;
+      const float* h1 = xch + ((1 * 4 + w4) * 64 + lane) * 8;
+      s[0] = *reinterpret_cast<const f32x4*>(h0) + *reinterpret_cast<const f32x4*>(h1);
+      s[1] = *reinterpret_cast<const f32x4*>(h0 + 4) + *reinterpret_cast<const f32x4*>(h1 + 4);
+    }
+    if ((it + 1) * KV > p.Tk) {
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e)
+          if (it * KV + 16 * kt + 4 * g + e >= p.Tk) s[kt][e] = -__builtin_inff();
+    }
+    {
+      float mx = fmaxf(fmaxf(fmaxf(s[0][0], s[0][1]), fmaxf(s[0][2], s[0][3])), fmaxf(fmaxf(s[1][0], s[1][1]), fmaxf(s[1][2], s[1][3])));
+      mx = xmax16_32(mx);
+      if (__builtin_amdgcn_ballot_w64(mx > m + RESCALE_SLACK) != 0) {
+        const float mn = fmaxf(m, mx);
+        const float alpha = ex2(m - mn);
+        m = mn;
+        l *= alpha;
+#pragma unroll
+        for (int i = 0; i < NDVH; ++i) o[i] *= alpha;
+      }
+      float ps = 0.f;
+#pragma unroll
+      for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = ex2(s[kt][e] - m);
+          s[kt][e] = pe;
+          ps += pe;
+        }
+      l += ps;
+    }
+#pragma unroll
+    for (int kt = 0; kt < 2; ++kt)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const float* vrow = vt_ + (16 * kt + 4 * g + e) * C::S + dh * (D / 2) + c;
+#pragma unroll
+        for (int i = 0; i < NDVH; ++i) o[i] = mfma16(vrow[16 * i], s[kt][e], o[i]);
+      }
+    barrier_after_dma();
+  }
+  float* O = p.o + b * p.so + h * p.d + dh * (D / 2);
+  const float lt = xsum16_32(l);
+  const float inv = 1.f / lt;
+  if (row < p.Tq) {
+#pragma unroll
+    for (int i = 0; i < NDVH; ++i) *reinterpret_cast<f32x4*>(O + (long)row * p.ldo + 16 * i + 4 * g) = o[i] * inv;
+    if (dh == 0 && g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m + __builtin_amdgcn_logf(lt);
   }
 }
 
@@ -1367,6 +1506,16 @@ static int launch_fwd(AttnDev d, hipStream_t st) {
   return 0;
 }
 
+template <int D>
+static int launch_fwd_wide(AttnDev d, hipStream_t st) {
+  static unsigned lds_set = 0;
+  const int bytes = (4 * Cfg<D>::TILE + 2 * 4 * 64 * 8) * (int)sizeof(float);
+  if (set_lds(attn_fwd_wide_f32_kernel<D>, bytes, "gad_attention_fwd", &lds_set)) return 1;
+  const dim3 grid = grid_of(d, d.Tq, 64);
+  hipLaunchKernelGGL((attn_fwd_wide_f32_kernel<D>), grid, dim3(NTW), bytes, st, d);
+  return 0;
+}
+
 template <int D, int NQ>
 static int launch_fwd_h(AttnDev d, hipStream_t st) {
   using C = CfgH<D>;
@@ -1469,13 +1618,14 @@ static int launch_bwd_h(AttnDev d, float* delta, hipStream_t st) {
 
 // one instance dim: pick the form (RG / bf16 / f32, queries per workgroup)
 template <int D>
-static int fwd_dim(const AttnDev& d, hipStream_t st, bool rg, bool bf16, bool wide) {
+static int fwd_dim(const AttnDev& d, hipStream_t st, bool rg, bool bf16, bool wide, bool two_kernel_legacy) {
   if (rg) return launch_fwd<D, 1, true>(d, st);
   if (bf16) {
     if constexpr (D <= 96) { if (wide) return launch_fwd_h<D, 2>(d, st); }
     return launch_fwd_h<D, 1>(d, st);
   }
   if constexpr (D <= 80) { if (wide) return launch_fwd<D, 2, false>(d, st); }
+  if constexpr (D >= 160 && D % 32 == 0) { if (!two_kernel_legacy) return launch_fwd_wide<D>(d, st); }
   return launch_fwd<D, 1, false>(d, st);
 }
 template <int D>
@@ -1508,7 +1658,7 @@ extern "C" int gad_attention_fwd(const gad_attention_args* a, void* stream) {
   const bool wide = gad_ceil_div(a->Tq, 128) * a->B * a->heads >= 512;
   int rc = 1;
   switch (instance_dim(a->d)) {
-#define X(DIM) case DIM: rc = fwd_dim<DIM>(d, st, rg, bf16, wide); break;
+#define X(DIM) case DIM: rc = fwd_dim<DIM>(d, st, rg, bf16, wide, (a->flags & GAD_ATTN_NARROW_FWD) != 0); break;
     GAD_ATTN_DIMS(X)
 #undef X
   }

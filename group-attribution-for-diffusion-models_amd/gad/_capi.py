@@ -60,7 +60,7 @@ class AttentionArgs(C.Structure):
                 ("ws", C.c_void_p), ("ws_bytes", C.c_int64), ("flags", C.c_int32)]
 
 
-ATTN_TWO_KERNEL_BWD = 1
+ATTN_TWO_KERNEL_BWD, ATTN_NARROW_FWD = 1, 2
 
 
 class AdamArgs(C.Structure):

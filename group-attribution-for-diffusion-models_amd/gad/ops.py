@@ -140,7 +140,7 @@ def set_operand_precision(name):
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
 # structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
-KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False}
+KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False, "narrow_attn_fwd": False}
 
 
 class kernel_flags:
@@ -149,8 +149,8 @@ class kernel_flags:
     rotated weights, see `dgrad_as_forward`)"""
 
     def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
-                 native_dgrad=False, two_kernel_attn_bwd=False):
-        self.native_dgrad, self.two_kernel_attn_bwd = native_dgrad, two_kernel_attn_bwd
+                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False):
+        self.native_dgrad, self.two_kernel_attn_bwd, self.narrow_attn_fwd = native_dgrad, two_kernel_attn_bwd, narrow_attn_fwd
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
                      | (_capi.GEMM_GENERAL_LOADERS if general_loaders else 0))
@@ -159,7 +159,7 @@ class kernel_flags:
     def __enter__(self):
         self.prev = dict(KERNEL_FLAGS)
         KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"], KERNEL_FLAGS["native_dgrad"] = self.gemm, self.gn, self.native_dgrad
-        KERNEL_FLAGS["two_kernel_attn_bwd"] = self.two_kernel_attn_bwd
+        KERNEL_FLAGS["two_kernel_attn_bwd"], KERNEL_FLAGS["narrow_attn_fwd"] = self.two_kernel_attn_bwd, self.narrow_attn_fwd
         return self
 
     def __exit__(self, *exc):
@@ -866,6 +866,7 @@ def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=Tru
     lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
     a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv, scale)
     a.operand_precision = OPERAND_PRECISION[0]         # bf16 mode: bf16-operand instance of the fused kernel
+    a.flags = _capi.ATTN_NARROW_FWD if KERNEL_FLAGS.get("narrow_attn_fwd") else 0
     if PROFILER is not None:
         PROFILER.attention(_capi.load().gad_attention_fwd, a, "fwd")
     else:

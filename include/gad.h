@@ -215,6 +215,7 @@ typedef struct gad_attention_args {
   int32_t flags;            /* GAD_ATTN_* */
 } gad_attention_args;
 #define GAD_ATTN_TWO_KERNEL_BWD 1   /* bwd: keep the recomputing dQ + dK/dV kernel pair (A/B tools, tests) */
+#define GAD_ATTN_NARROW_FWD 2       /* fwd: keep the 4-wave kernel for d >= 160 instead of the 8-wave split-head-dim kernel (A/B) */
 int64_t gad_attention_bwd_workspace_bytes(const gad_attention_args* a);
 int gad_attention_supported(int32_t d);      /* 1 if 1 <= d <= 256 */
 int gad_attention_uses_bf16(const gad_attention_args* a, int32_t backward);   /* 1 if this launch multiplies bf16 operands */

@@ -1,4 +1,6 @@
-"""Fused attention kernels timed at the reference's shapes (HIP events, median of interleaved rounds) next to the
+"""Fused attention kernels timed at the reference's shapes (routes: fused = the product's choice - for d >= 160 the 8-wave
+split-head-dim forward, for d <= 96 the single-pass backward; 2-kernel-bwd = 4-wave forward + the recomputing dQ + dK/dV pair;
+narrow-fwd = the 4-wave forward at d >= 160; 3-launch = batched GEMMs + softmax with S in HBM) (HIP events, median of interleaved rounds) next to the
 three-launch route (batched Q K^T -> softmax -> P V with S in HBM): TF/s against the 157.3 TF/s f32-MFMA roofline.
 usage: python tools/bench_attention.py [rounds]"""
 import os, sys
@@ -39,7 +41,10 @@ for name, B, Tq, Tk, h, d in SHAPES:
     res = {}
     def pair(*a):                      # fused forward, recomputing dQ + dK/dV backward pair (the round-2 backward)
         return ops.attention_core_fused(*a)
-    for route, fn in (("fused", ops.attention_core_fused if d <= 160 else ops.attention_core), ("2-kernel-bwd", pair), ("3-launch", ops.attention_core_unfused)):
+    for route, fn in (("fused", ops.attention_core_fused), ("2-kernel-bwd", pair),
+                      ("narrow-fwd", ops.attention_core_fused), ("3-launch", ops.attention_core_unfused)):
+        if route == "narrow-fwd" and d < 160:
+            continue                   # the 8-wave split-head-dim forward exists for d >= 160 only
         if route == "3-launch" and 4 * B * h * Tq * Tk * 3 > 40e9:
             continue
         if route == "2-kernel-bwd" and d > 96:
@@ -51,7 +56,8 @@ for name, B, Tq, Tk, h, d in SHAPES:
             def fwd():
                 global out_
                 out_ = fn(qq, kk, vv, h)
-            t1 = ev_time(fwd)
+            with ops.kernel_flags(narrow_attn_fwd=(route == "2-kernel-bwd" or (route == "narrow-fwd"))):
+                t1 = ev_time(fwd)
             with ops.kernel_flags(two_kernel_attn_bwd=(route == "2-kernel-bwd")):
                 t2 = ev_time(lambda: out_.backward(do))
             if r:
