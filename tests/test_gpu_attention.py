@@ -141,6 +141,24 @@ def test_single_pass_backward_vs_the_two_kernel_pair_and_fp64(B, Tq, Tk, heads, 
         assert (one - two).abs().max().item() < 6e-5 * max(1.0, scale)
 
 
+@pytest.mark.parametrize("B,Tq,Tk,heads,d", [(3, 256, 256, 1, 256), (2, 256, 256, 1, 192), (2, 100, 77, 2, 160), (1, 70, 130, 1, 224)])
+def test_wide_head_forward_8_wave_kernel_vs_the_4_wave_kernel(B, Tq, Tk, heads, d):
+    """d >= 160 runs the 8-wave forward (each wave half the head dim, partial scores exchanged through LDS); the 4-wave
+    kernel (`kernel_flags(narrow_attn_fwd=True)`) computes the same function with one k-sum instead of two halves - equal
+    to fp32 rounding, both equal to fp64, LSE included (the backward consumes either's)."""
+    from gad import ops
+    C = heads * d
+    q, k, v = rnd(B, Tq, C, seed=1, scale=0.7).to(dev), rnd(B, Tk, C, seed=2, scale=0.7).to(dev), rnd(B, Tk, C, seed=3).to(dev)
+    wide, lse_w = ops.attention_fwd_raw(q, k, v, B, heads, Tq, Tk, d, C, C, C)
+    with ops.kernel_flags(narrow_attn_fwd=True):
+        narrow, lse_n = ops.attention_fwd_raw(q, k, v, B, heads, Tq, Tk, d, C, C, C)
+    want = sdpa64(q.cpu().double(), k.cpu().double(), v.cpu().double(), heads)
+    assert (wide.cpu().double() - want).abs().max().item() < 3e-5 and (narrow.cpu().double() - want).abs().max().item() < 3e-5
+    assert (wide - narrow).abs().max().item() < 1e-5 and (lse_w - lse_n).abs().max().item() < 1e-4
+    again, _ = ops.attention_fwd_raw(q, k, v, B, heads, Tq, Tk, d, C, C, C)
+    assert torch.equal(again, wide)
+
+
 def test_attention_argument_contract():
     from gad import _capi, ops
     q = rnd(1, 8, 300, seed=1).to(dev)
