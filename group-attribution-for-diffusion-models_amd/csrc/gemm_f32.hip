@@ -1825,6 +1825,282 @@ static void launch_splitk_reduce(const DevArgs& d, int batch, hipStream_t st) {
   hipLaunchKernelGGL(splitk_reduce_kernel, dim3(blocks > 0 ? blocks : 1), dim3(256), 0, st, d, batch);
 }
 
+// ------------------------------------------------------------------------------------
+// Winograd F(2x2, 3x3) form of the 3x3 / stride 1 / pad 1 convolution: 16 multiplies per 2x2 output tile and channel
+// pair instead of 36 (2.25x fewer MFMA FLOPs), fp32 throughout.
+//   y_tile = A^T [ sum_c U[.,.][co][c] (.) V[.,.][tile][c] ] A,   U = G w G^T (per weight version, wino_weights_kernel),
+//   V = B^T d B (per launch, wino_input_kernel),   B^T = [1 0 -1 0; 0 1 1 0; 0 -1 1 0; 0 1 0 -1],
+//   G = [1 0 0; .5 .5 .5; .5 -.5 .5; 0 0 1],   A^T = [1 1 1 0; 0 1 -1 -1]           (Lavin & Gray 2016, standard points).
+// wino_gemm_kernel runs the 16 per-position products [tiles x Cin] x [Cin x Cout] of one (64 tiles x 128 channels) or
+// (128 x 64) block back to back as ONE K loop of 16 Cin/32 steps on the lean dense loaders (V and U are k-contiguous
+// rows: LDS-DMA, no masks); after the last step of a position the 32-register product block is folded into the four
+// output-pixel accumulators with the position's A^T (x) A^T coefficient (+1 / 0 / -1: exact), so M = U (.) V never
+// exists in memory, and the shared float4 epilogue (bias, time-embedding row, residual) writes the four pixels of
+// every tile.  Transforms add a rounding per add (the input transform has unit coefficients, the weight transform
+// halves): the result differs from the direct kernels' by fp32 reassociation noise of a few ulp of the accumulated
+// magnitude, not bit for bit.
+// ------------------------------------------------------------------------------------
+struct WinoIn {
+  const float* x;
+  float* V;
+  int H, W, C, ldx, up;      // source map H x W (before the fused nearest-2x upsample when up = 1), C channels
+  int TH, TW;                // tiles per image = (He / 2) x (We / 2)
+  long T;                    // B * TH * TW
+};
+
+__global__ __launch_bounds__(256) void wino_input_kernel(const WinoIn p) {
+  const int C4 = p.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.T * C4) return;
+  const long tile = idx / C4;
+  const int c = (int)(idx - tile * C4) * 4;
+  const int per = p.TH * p.TW;
+  const int n = (int)(tile / per);
+  const int r = (int)(tile - (long)n * per);
+  const int ty = r / p.TW, tx = r - ty * p.TW;
+  const int He = p.H << p.up, We = p.W << p.up;
+  const float* img = p.x + (long)n * p.H * p.W * p.ldx + c;
+  f32x4 t[4][4];
+#pragma unroll
+  for (int dx = 0; dx < 4; ++dx) {
+    const int xx = 2 * tx - 1 + dx;
+    const bool xok = xx >= 0 && xx < We;
+    f32x4 d[4];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) {
+      const int yy = 2 * ty - 1 + dy;
+      const bool ok = xok && yy >= 0 && yy < He;
+      d[dy] = ok ? ldg4(img + ((long)(yy >> p.up) * p.W + (xx >> p.up)) * p.ldx) : zero4();
+    }
+    t[0][dx] = d[0] - d[2];
+    t[1][dx] = d[1] + d[2];
+    t[2][dx] = d[2] - d[1];
+    t[3][dx] = d[1] - d[3];
+  }
+  const long pos_stride = p.T * p.C;
+  float* out = p.V + tile * p.C + c;
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    *reinterpret_cast<f32x4*>(out + (long)(4 * i + 0) * pos_stride) = t[i][0] - t[i][2];
+    *reinterpret_cast<f32x4*>(out + (long)(4 * i + 1) * pos_stride) = t[i][1] + t[i][2];
+    *reinterpret_cast<f32x4*>(out + (long)(4 * i + 2) * pos_stride) = t[i][2] - t[i][1];
+    *reinterpret_cast<f32x4*>(out + (long)(4 * i + 3) * pos_stride) = t[i][1] - t[i][3];
+  }
+}
+
+// U[pos][co][ci] = (G w G^T)[pos] for 32 x 32 (co, ci) tiles of the 3x3 weights listed in `table`
+// (rows {src offset, dst offset, Cout, Cin, co0, ci0} in floats; src storage [Cout][3][3][Cin])
+__global__ __launch_bounds__(256) void wino_weights_kernel(const float* src, float* dst, const long* table) {
+  const long* row = table + 6 * (long)blockIdx.x;
+  const long soff = row[0], doff = row[1];
+  const int Cout = (int)row[2], Cin = (int)row[3], co0 = (int)row[4], ci0 = (int)row[5];
+  const int ci = ci0 + (threadIdx.x & 31);
+  if (ci >= Cin) return;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int co = co0 + (threadIdx.x >> 5) + 8 * q;
+    if (co >= Cout) continue;
+    const float* w = src + soff + (long)co * 9 * Cin + ci;
+    float g[3][3];
+#pragma unroll
+    for (int r = 0; r < 3; ++r)
+#pragma unroll
+      for (int s = 0; s < 3; ++s) g[r][s] = w[(long)(r * 3 + s) * Cin];
+    float gg[4][3];                       // G g
+#pragma unroll
+    for (int s = 0; s < 3; ++s) {
+      gg[0][s] = g[0][s];
+      gg[1][s] = 0.5f * (g[0][s] + g[1][s] + g[2][s]);
+      gg[2][s] = 0.5f * (g[0][s] - g[1][s] + g[2][s]);
+      gg[3][s] = g[2][s];
+    }
+    float* u = dst + doff + (long)co * Cin + ci;
+    const long ps = (long)Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 4; ++i) {
+      u[(long)(4 * i + 0) * ps] = gg[i][0];
+      u[(long)(4 * i + 1) * ps] = 0.5f * (gg[i][0] + gg[i][1] + gg[i][2]);
+      u[(long)(4 * i + 2) * ps] = 0.5f * (gg[i][0] - gg[i][1] + gg[i][2]);
+      u[(long)(4 * i + 3) * ps] = gg[i][2];
+    }
+  }
+}
+
+// dense [row][k] rows by LDS-DMA with a 64-bit step offset (position x panel stride + k): rows beyond the operand clamp
+// to the last one (they feed outputs the epilogue never stores)
+template <int ROWS>
+struct WinoKC : KCSlots<ROWS> {
+  using S = KCSlots<ROWS>;
+  const float* ptr[S::NS];
+  long off;
+  __device__ void init(const float* b, int ld, int row0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < S::NS; ++i) {
+      int r = row0 + S::row(i);
+      r = r < nrows ? r : nrows - 1;
+      ptr[i] = b + (long)r * ld + S::kq4();
+    }
+    off = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const { return ptr[i] + off; }
+};
+
+// one output pixel (di, dj) of every 2x2 tile of the block: p.M counts TILES, p.fdHoWo / p.fdWo divide by the tiles per
+// image / per tile row, the pixel row is ((n Ho + 2 ty + di) Wo + 2 tx + dj); same arithmetic order as store_block
+template <int TM, int TN, int BM, int BN>
+__device__ __forceinline__ void store_block_wino(const DevArgs& p, const f32x16 (&acc)[TM][TN], int row0, int col0, int wm, int wn,
+                                                 int h, int l31, int di, int dj, float* scratch) {
+  const int lane = l31 + 32 * h;
+  const int rr = lane >> 3, c4 = (lane & 7) * 4;
+  const int tiles_img = (p.g.Ho >> 1) * (p.g.Wo >> 1), TW = p.g.Wo >> 1;
+#pragma unroll
+  for (int j = 0; j < TN; ++j) {
+    const int n = col0 + wn * (BN / 2) + j * 32 + c4;
+    const bool n_ok = n < p.N;
+    float b0 = 0.f, b1 = 0.f, b2 = 0.f, b3 = 0.f;
+    if (p.bias && n_ok) {
+      const f32x4 t = ldg4(p.bias + n);
+      b0 = t[0]; b1 = t[1]; b2 = t[2]; b3 = t[3];
+    }
+#pragma unroll
+    for (int i = 0; i < TM; ++i) {
+#pragma unroll
+      for (int e = 0; e < 16; ++e) scratch[((e & 3) + 8 * (e >> 2) + 4 * h) * EPI_LD + l31] = acc[i][j][e];
+#pragma unroll
+      for (int q = 0; q < 4; ++q) {
+        const int r = rr + 8 * q;
+        f32x4 v = *reinterpret_cast<const f32x4*>(scratch + r * EPI_LD + c4);
+        const int m = row0 + wm * (BM / 2) + i * 32 + r;
+        if (m >= p.M || !n_ok) continue;
+        const int img = p.fdHoWo.div(m), rem = m - img * tiles_img;
+        const int ty = p.fdWo.div(rem), tx = rem - ty * TW;
+        const long pix = ((long)img * p.g.Ho + 2 * ty + di) * p.g.Wo + 2 * tx + dj;
+        v = f32x4{__builtin_fmaf(v[0], p.alpha, b0), __builtin_fmaf(v[1], p.alpha, b1), __builtin_fmaf(v[2], p.alpha, b2),
+                  __builtin_fmaf(v[3], p.alpha, b3)};
+        if (p.rowadd) v += ldg4(p.rowadd + (long)img * p.ld_rowadd + n);
+        if (p.residual) v += ldg4(p.residual + pix * p.ldr + n);
+        *reinterpret_cast<f32x4*>(p.C + pix * p.ldc + n) = v;
+      }
+    }
+  }
+}
+
+// p.A = V [16][T][Cin] (p.sA0 = T Cin), p.B = U [16][Cout][Cin] (p.sB0 = Cout Cin), p.M = T tiles, p.N = Cout, p.K = Cin
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void wino_gemm_kernel(const DevArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using AL = WinoKC<BM>;
+  using BL = WinoKC<BN>;
+  constexpr int A_TILE = BK * BM;
+  constexpr int B_TILE = BK * BN;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+
+  const int t = xcd_remap(blockIdx.x, gridDim.x);
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int kc = p.K / BK;                       // K steps per position
+  const int nsteps = 16 * kc;
+
+  AL al;
+  BL bl;
+  al.init(p.A, p.lda, row0, p.M);
+  bl.init(p.B, p.ldb, col0, p.N);
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN], Y[4][TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[q][i][j][e] = 0.f;
+      }
+
+  auto stage_slot = [&](int piece, float* ta, float* tb) {
+    constexpr int NSA = AL::NS, NSB = BL::NS;
+    if (piece < NSA) glds16(al.src(piece), AL::dma_dst(ta, piece));
+    else if (piece < NSA + NSB) glds16(bl.src(piece - NSA), BL::dma_dst(tb, piece - NSA));
+  };
+#pragma unroll
+  for (int q = 0; q < AL::NS + BL::NS; ++q) stage_slot(q, lds, lds + A_TILE);
+  barrier_after_dma();
+
+  int pos = 0, kk = 0;                           // position and K step of the step being multiplied
+  for (int s = 0; s < nsteps; ++s) {
+    float* cur = lds + (s & 1) * (A_TILE + B_TILE);
+    float* nxt = lds + ((s + 1) & 1) * (A_TILE + B_TILE);
+    const float* la = cur;
+    const float* lb = cur + A_TILE;
+    {                                            // offsets of step s + 1 (the step past the end re-reads the last one)
+      int pn = pos, kn = kk + 1;
+      if (kn == kc) { kn = 0; ++pn; }
+      if (pn == 16) { pn = 15; kn = kc - 1; }
+      al.off = (long)pn * p.sA0 + kn * BK;
+      bl.off = (long)pn * p.sB0 + kn * BK;
+    }
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<true, BM>(la, wm * (BM / 2) + i * 32 + l31, 0, h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][q4], fb[g & 1][j][q4], acc[i][j], 0, 0, 0);
+        stage_slot(g * 4 + q4, nxt, nxt + A_TILE);
+        if (q4 == 1 && g < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = read_frag<true, BM>(la, wm * (BM / 2) + i * 32 + l31, g + 1, h);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+        }
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (++kk == kc) {                            // position done: fold its product block into the four output pixels
+      const int xi = pos >> 2, nu = pos & 3;
+      const float r0 = xi < 3 ? 1.f : 0.f, r1 = xi == 0 ? 0.f : (xi == 1 ? 1.f : -1.f);
+      const float c0 = nu < 3 ? 1.f : 0.f, c1 = nu == 0 ? 0.f : (nu == 1 ? 1.f : -1.f);
+      const float w00 = r0 * c0, w01 = r0 * c1, w10 = r1 * c0, w11 = r1 * c1;
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float a = acc[i][j][e];
+            Y[0][i][j][e] = __builtin_fmaf(w00, a, Y[0][i][j][e]);
+            Y[1][i][j][e] = __builtin_fmaf(w01, a, Y[1][i][j][e]);
+            Y[2][i][j][e] = __builtin_fmaf(w10, a, Y[2][i][j][e]);
+            Y[3][i][j][e] = __builtin_fmaf(w11, a, Y[3][i][j][e]);
+            acc[i][j][e] = 0.f;
+          }
+      kk = 0;
+      ++pos;
+    }
+    barrier_after_dma();
+  }
+
+  float* scratch = lds + (tid >> 6) * EPI_WAVE;
+#pragma unroll
+  for (int q = 0; q < 4; ++q) store_block_wino<TM, TN, BM, BN>(p, Y[q], row0, col0, wm, wn, h, l31, q >> 1, q & 1, scratch);
+}
+
 static FastDiv make_fastdiv(unsigned d) {
   FastDiv f;
   if (d == 0) d = 1;
@@ -2182,6 +2458,36 @@ static bool as_dense_1x1(const gad_gemm_args* a, gad_gemm_args* out) {
 }
 #define GAD_CANON(a) gad_gemm_args canon_; if (as_dense_1x1((a), &canon_)) (a) = &canon_
 
+// Winograd F(2x2, 3x3) route of the fp32 3x3 / stride 1 / pad 1 forward convolution (and, through ops.dgrad_as_forward, of
+// its data gradient): taken when the caller supplies the transformed weights (B_wino) and the launch has tiles enough to
+// fill the chip - small maps at small batch keep the direct LDS-patch kernels and their split-K.
+struct WinoPlan {
+  int bm, bn, tiles_m, tiles_n;
+  long T;
+  int64_t bytes;
+};
+static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
+  const gad_conv_geom& g = a->g;
+  if (!a->B_wino || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
+  const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
+  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 1) || (We & 1)) return false;
+  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || a->tile_hint != 0 || a->splitk_hint > 0 || a->batch > 1) return false;
+  if (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_SCALAR_EPILOGUE | GAD_GEMM_TAP_MAJOR_K)) return false;
+  if (a->rowadd && a->rows_per_group != g.Ho * g.Wo) return false;
+  if (a->M % (g.Ho * g.Wo) != 0) return false;
+  const bool vec_ok = gad_aligned16(a->A) && gad_aligned16(a->C) && a->ldc % 4 == 0 && (!a->bias || gad_aligned16(a->bias)) &&
+                      (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
+                      (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0));
+  if (!vec_ok) return false;
+  wp->T = (long)a->M / 4;
+  const long pad128 = gad_ceil_div(a->N, 128) * 128, pad64 = gad_ceil_div(a->N, 64) * 64;
+  if (pad64 < pad128) { wp->bm = 128; wp->bn = 64; } else { wp->bm = 64; wp->bn = 128; }
+  wp->tiles_m = (int)gad_ceil_div(wp->T, wp->bm);
+  wp->tiles_n = (int)gad_ceil_div(a->N, wp->bn);
+  wp->bytes = (int64_t)16 * wp->T * g.C * (int64_t)sizeof(float);
+  return (long)wp->tiles_m * wp->tiles_n >= 256 && wp->T < (1L << 30);
+}
+
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
   if (!a) return 0;
   GAD_CANON(a);
@@ -2191,6 +2497,7 @@ extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
 extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
   GAD_CANON(a);
+  if (WinoPlan wp; use_wino(a, &wp)) return 5;
   if (use_fewout_conv(a)) return 4;
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
@@ -2204,7 +2511,10 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   GAD_CANON(a);
   *vec = pick_vec(a);
   PatchPlan pp;
-  if (use_fewout_conv(a)) {                      // vector-ALU kernel: 256 pixels x all (<= 4) output channels
+  if (WinoPlan wp; use_wino(a, &wp)) {           // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn)
+    *tile = wp.bn;
+    *splitk = 1;
+  } else if (use_fewout_conv(a)) {               // vector-ALU kernel: 256 pixels x all (<= 4) output channels
     *tile = 256;
     *splitk = 1;
   } else if (int bm = 0; int sp = wgrad_patch_splits(a, &bm)) {   // patch weight gradient: 128 / 96 output channels x pixel splits
@@ -2223,8 +2533,24 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   return 0;
 }
 
+extern "C" int64_t gad_gemm_wino_bytes(const gad_gemm_args* a) {
+  if (!a) return 0;
+  GAD_CANON(a);
+  WinoPlan wp;
+  return use_wino(a, &wp) ? wp.bytes : 0;
+}
+
+extern "C" int gad_wino_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream) {
+  GAD_CHECK(src && dst && table && n_tiles > 0 && n_tiles < (1L << 31), "gad_wino_weights: bad arguments");
+  static_assert(sizeof(long) == sizeof(int64_t), "table rows are 64-bit");
+  hipLaunchKernelGGL(wino_weights_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, (const long*)table);
+  GAD_LAUNCH_CHECK("gad_wino_weights");
+  return 0;
+}
+
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   GAD_CANON(a);
+  if (WinoPlan wp; use_wino(a, &wp)) return 0;
   if (use_fewout_conv(a)) return 0;
   if (int m1 = 0; wgrad_split_m(a, &m1)) {
     gad_gemm_args lo, hi;
@@ -2247,7 +2573,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   GAD_CHECK(a && a->A && a->B && a->C, "gad_gemm: null pointer");
   GAD_CANON(a);
   GAD_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gad_gemm: bad shape M=%d N=%d K=%d", a->M, a->N, a->K);
-  if (int n1 = 0; patch_split_n(a, &n1)) {          // 224 / 448 output channels: 128-wide tiles, then 96-wide tiles
+  WinoPlan wino_first;
+  if (int n1 = 0; !use_wino(a, &wino_first) && patch_split_n(a, &n1)) {          // 224 / 448 output channels: 128-wide tiles, then 96-wide tiles
     gad_gemm_args lo = *a, hi = *a;
     lo.N = n1;
     hi.N = a->N - n1;
@@ -2369,6 +2696,32 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (WinoPlan wp; use_wino(a, &wp)) {
+    GAD_CHECK(a->wino_ws && a->wino_ws_bytes >= wp.bytes && gad_aligned16(a->wino_ws) && gad_aligned16(a->B_wino),
+              "gad_gemm: Winograd workspace too small or misaligned (%lld < %lld)", (long long)a->wino_ws_bytes, (long long)wp.bytes);
+    const gad_conv_geom& g = a->g;
+    WinoIn wi;
+    wi.x = a->A; wi.V = (float*)a->wino_ws;
+    wi.H = g.H; wi.W = g.W; wi.C = g.C; wi.ldx = g.ldx; wi.up = g.upsample ? 1 : 0;
+    wi.TH = g.Ho / 2; wi.TW = g.Wo / 2; wi.T = wp.T;
+    const long items = wp.T * (g.C / 4);
+    GAD_CHECK(gad_ceil_div(items, 256) < (1L << 31), "gad_gemm: Winograd input transform grid too large");
+    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
+    GAD_LAUNCH_CHECK("gad_gemm(winograd input transform)");
+    DevArgs w = d;
+    w.A = wi.V; w.B = a->B_wino;
+    w.M = (int)wp.T; w.N = a->N; w.K = g.C;
+    w.lda = g.C; w.ldb = g.C;
+    w.sA0 = wp.T * (long)g.C; w.sB0 = (long)a->N * g.C;
+    w.fdHoWo = make_fastdiv((unsigned)(wi.TH * wi.TW));
+    w.fdWo = make_fastdiv((unsigned)wi.TW);
+    w.tiles_m = wp.tiles_m; w.tiles_n = wp.tiles_n;
+    dim3 grid((unsigned)((long)wp.tiles_m * wp.tiles_n)), block(NTHREADS);
+    if (wp.bm == 64) hipLaunchKernelGGL((wino_gemm_kernel<64, 128>), grid, block, 0, st, w);
+    else hipLaunchKernelGGL((wino_gemm_kernel<128, 64>), grid, block, 0, st, w);
+    GAD_LAUNCH_CHECK("gad_gemm(winograd)");
+    return 0;
+  }
   if (use_fewout_conv(a)) {
     dim3 grid((unsigned)(a->M / 256)), block(NTHREADS);
 #define GAD_FEWOUT(W_)                                                                          \

@@ -36,7 +36,8 @@ class GemmArgs(C.Structure):
                 ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32), ("operand_precision", C.c_int32),
                 ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p),
                 ("A_k2", C.c_void_p), ("B_k2", C.c_void_p), ("lda_k2", C.c_int32), ("ldb_k2", C.c_int32),
-                ("k_split", C.c_int32), ("flags", C.c_int32)]
+                ("k_split", C.c_int32), ("flags", C.c_int32),
+                ("B_wino", C.c_void_p), ("wino_ws", C.c_void_p), ("wino_ws_bytes", C.c_int64)]
 
 
 class GroupNormArgs(C.Structure):
@@ -71,6 +72,7 @@ class AdamArgs(C.Structure):
 
 
 GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GEMM_SCALAR_EPILOGUE, GEMM_GENERAL_LOADERS, GN_TWO_PASS = 1, 2, 4, 8, 1
+GEMM_NO_WINO = 16
 A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
 B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 
@@ -84,6 +86,8 @@ SIGNATURES = {
     "gad_gemm": (C.c_int, [C.POINTER(GemmArgs), _vp]),
     "gad_gemm_uses_bf16": (C.c_int, [C.POINTER(GemmArgs)]),
     "gad_gemm_kernel_id": (C.c_int, [C.POINTER(GemmArgs)]),
+    "gad_gemm_wino_bytes": (_i64, [C.POINTER(GemmArgs)]),
+    "gad_wino_weights": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "gad_groupnorm_one_pass": (C.c_int, [C.POINTER(GroupNormArgs)]),
     "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),

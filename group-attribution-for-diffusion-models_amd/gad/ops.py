@@ -149,9 +149,10 @@ class kernel_flags:
     rotated weights, see `dgrad_as_forward`)"""
 
     def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
-                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False):
+                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False, no_wino=False):
         self.native_dgrad, self.two_kernel_attn_bwd, self.narrow_attn_fwd = native_dgrad, two_kernel_attn_bwd, narrow_attn_fwd
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
+                     | (_capi.GEMM_NO_WINO if no_wino else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
                      | (_capi.GEMM_GENERAL_LOADERS if general_loaders else 0))
         self.gn = _capi.GN_TWO_PASS if gn_two_pass else 0
@@ -170,7 +171,7 @@ class kernel_flags:
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0):
+             A_k2=None, B_k2=None, k_split=0, B_wino=None):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -200,6 +201,14 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     if A_k2 is not None:            # K-concatenated operands (fused LoRA): k >= k_split reads A_k2 / B_k2
         a.A_k2, a.B_k2, a.k_split = A_k2.data_ptr(), B_k2.data_ptr(), k_split
         a.lda_k2, a.ldb_k2 = A_k2.shape[-1], B_k2.shape[-1]
+    if B_wino is not None:          # Winograd route: the planner says whether this launch takes it and how much scratch V needs
+        a.B_wino = B_wino.data_ptr()
+        need = lib.gad_gemm_wino_bytes(C.byref(a))
+        if need:
+            V = torch.empty(need, dtype=torch.uint8, device=A.device)      # stream-ordered: safe to drop after the launch
+            a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
+        else:
+            a.B_wino = None
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -223,7 +232,7 @@ class GemmProfiler:
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
-        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}")[kid]
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", f"_wino_w{a.g.Wo}")[kid]
         if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)
@@ -297,6 +306,8 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
              tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
+             B_wino=wino_weight(w) if (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint == 0
+                                       and splitk_hint == 0 and tuple(pad) == (1, 1, 1, 1)) else None,
              B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
                                        and not torch.cuda.is_current_stream_capturing()) else None)
     return y
@@ -377,6 +388,7 @@ def rotated_weight(w):
             stale = True
         if stale and tiles:
             shadow = cached[1] if cached is not None else torch.empty_like(flat)
+            shadow._gad_conv3x3 = [(o_, b, a) for o_, a, b in _conv3x3_residents(flat)]      # rotated: [Cin][3][3][Cout]
             check(_capi.load().gad_rotate_conv3x3(flat.data_ptr(), shadow.data_ptr(), table.data_ptr(), tiles, _stream()),
                   "gad_rotate_conv3x3")
             shadow._gad_epoch = getattr(shadow, "_gad_epoch", 0) + 1         # its residents changed (bf16_weight's key)
@@ -396,6 +408,84 @@ def rotated_weight(w):
         cached = (key, store.permute(0, 3, 1, 2))
         w._gad_rot = cached
     return cached[1]
+
+
+def _conv3x3_residents(flat):
+    """[(offset, Cout, Cin)] of the 3x3 conv weights stored in a flat parameter buffer ([Cout][3][3][Cin] each); a rotated
+    shadow (`rotated_weight`) carries the list of its source with the channel roles swapped."""
+    r = getattr(flat, "_gad_conv3x3", None)
+    if r is None:
+        r = [(off, p_.shape[0], p_.shape[1]) for p_, off, _ in getattr(flat, "_gad_params", ())
+             if p_.ndim == 4 and tuple(p_.shape[2:]) == (3, 3)]
+        flat._gad_conv3x3 = r
+    return r
+
+
+def _wino_ok(co, ci):
+    return ci % 32 == 0 and co % 4 == 0 and co >= 64
+
+
+def _wino_transform(src, items):
+    """items [(src offset, Cout, Cin)] -> (U buffer, {src offset: (dst offset, floats)}, table, tiles)"""
+    rows, where, doff = [], {}, 0
+    for off, co, ci in items:
+        where[off] = (doff, 16 * co * ci)
+        rows += [(off, doff, co, ci, a, b) for a in range(0, co, 32) for b in range(0, ci, 32)]
+        doff += 16 * co * ci
+    U = torch.empty(max(doff, 1), device=src.device, dtype=torch.float32)
+    table = torch.tensor(rows, dtype=torch.int64, device=src.device)
+    return U, where, table, len(rows)
+
+
+def wino_weight(w):
+    """U[16][Cout][Cin] = G w G^T, the Winograd F(2x2, 3x3) form of a 3x3 conv weight (`gad_wino_weights`), or None for a
+    weight the Winograd kernels do not take (Cin % 32, Cout % 4, < 64 output channels, bf16-operand mode, the no_wino
+    switch).  A weight living in a flat parameter buffer - or in the rotated shadow of one, for the data gradients - is
+    served from ONE transformed shadow of that buffer, refreshed by a single launch when the weights changed (the keys of
+    `bf16_weight`); any other weight caches its own transform per version."""
+    co, ci = w.shape[0], w.shape[1]
+    if (tuple(w.shape[2:]) != (3, 3) or not _wino_ok(co, ci) or OPERAND_PRECISION[0] == 1
+            or KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K)):
+        return None
+    lib = _capi.load()
+    if _in_flat_buffer(w):
+        flat, off, n = w._gad_flat
+        key = (flat._version, WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
+        cached = getattr(flat, "_gad_wino", None)
+        if cached is None:
+            items = [(o_, a, b) for o_, a, b in _conv3x3_residents(flat) if _wino_ok(a, b)]
+            cached = [None, *_wino_transform(flat, items), {}]
+            flat._gad_wino = cached
+        _, U, where, table, tiles, versions = cached
+        if off not in where:
+            return None
+        stale = cached[0] != key or versions.get(off, w._version) != w._version
+        if stale:
+            check(lib.gad_wino_weights(flat.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
+            cached[0] = key
+            cached[5] = {o_: p_._version for p_, o_, _ in getattr(flat, "_gad_params", ())}
+        d0, dn = where[off]
+        return U[d0:d0 + dn]
+    key = weight_key(w)
+    cached = getattr(w, "_gad_wino", None)
+    if cached is None or cached[0] != key:
+        src = weight_krsc(w).detach()
+        if cached is None:
+            U, _, table, tiles = _wino_transform(src, [(0, co, ci)])
+        else:
+            U, table, tiles = cached[1], cached[2], cached[3]
+        check(lib.gad_wino_weights(src.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
+        cached = (key, U, table, tiles)
+        w._gad_wino = cached
+    return cached[1]
+
+
+def refresh_wino(module):
+    """Bring the Winograd shadows of every 3x3 weight of `module` up to date NOW - before replaying a captured graph, whose
+    launches read the shadow at a fixed address but cannot notice that the weights moved since the capture."""
+    for p in module.parameters():
+        if p.ndim == 4 and tuple(p.shape[2:]) == (3, 3):
+            wino_weight(p)
 
 
 def two_source_ok(c1: int, c2: int) -> bool:

@@ -72,6 +72,7 @@ class DDPMPipeline:
                 g.eps = self.unet.forward_nhwc(g.x, g.t)
             self._graphs[key] = g
         g.x.copy_(x)
+        ops.refresh_wino(self.unet)            # derived weights the captured launches read at fixed addresses
         for t in sch.timesteps.tolist():
             g.t.fill_(t)
             g.graph.replay()

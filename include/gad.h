@@ -113,8 +113,17 @@ typedef struct gad_gemm_args {
   /* kernel-family switches for A/B tests and invariance checks (0 in production): GAD_GEMM_* bits below.  They
    * travel with the call - the library reads no environment variable and keeps no process-global switch. */
   int32_t flags;
+  /* Winograd F(2x2, 3x3) route of the fp32 3x3 / stride 1 / pad 1 forward convolution (A_CONV x B_KC, even output maps,
+   * Cin % 32 == 0, N % 4 == 0, launches with >= 256 blocks of 64 tiles x 128 channels): B_wino = the transformed weights
+   * U[16][Cout][Cin] = G w G^T made by gad_wino_weights from the [Cout][3][3][Cin] storage B points at; wino_ws = scratch
+   * of gad_gemm_wino_bytes(args) bytes for the transformed input V[16][tiles][Cin].  B_wino == NULL (or a launch the
+   * planner keeps on the direct kernels: gad_gemm_wino_bytes returns 0): the direct kernels run and both are ignored. */
+  const float* B_wino;
+  void* wino_ws;
+  int64_t wino_ws_bytes;
 } gad_gemm_args;
 enum gad_gemm_flags {
+  GAD_GEMM_NO_WINO = 16,      /* never take the Winograd route even when B_wino is given                              */
   GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
   GAD_GEMM_TAP_MAJOR_K = 2,   /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
   GAD_GEMM_SCALAR_EPILOGUE = 4, /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */
@@ -132,7 +141,14 @@ int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would mult
  * 2 conv3x3_patch_f32_kernel / wgrad3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 convs whose
  * 128-pixel tiles are whole image rows: input patch resident in LDS), 4 conv3x3_fewout_kernel (<= 4 output channels:
  * vector ALUs, weights through the scalar cache) */
-int gad_gemm_kernel_id(const gad_gemm_args* a);
+int gad_gemm_kernel_id(const gad_gemm_args* a);   /* ... 5 wino_input_kernel + wino_gemm_kernel (Winograd F(2x2, 3x3)) */
+/* bytes of wino_ws the Winograd route of gad_gemm(a) needs; 0 when gad_gemm(a) runs a direct kernel (set B_wino first) */
+int64_t gad_gemm_wino_bytes(const gad_gemm_args* a);
+/* Winograd weight transform U = G w G^T for the 3x3 weights listed in `table`: n_tiles rows of six int64
+ * {src offset, dst offset, Cout, Cin, co0, ci0} (offsets in floats from src / dst; one 32 x 32 (co, ci) tile per row);
+ * src storage [Cout][3][3][Cin] (diffusers Conv2d weight in channels_last: ResnetBlock2D.conv1/conv2, Up/Downsample2D.conv,
+ * SURVEY Appendix A), dst storage [16][Cout][Cin].  One launch transforms every 3x3 weight of a flat parameter buffer. */
+int gad_wino_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in

@@ -138,16 +138,17 @@ def test_fused_sampler_at_bench_width_equals_per_batch_launches():
 
 
 def test_whole_model_is_kernel_family_invariant():
-    """Full-width U-Net at the training batch: forward, loss, gradient norm and the updated weights with the LDS-patch
-    kernels (forward, dgrad, wgrad) against the same step on the generic im2col kernels (ops.kernel_flags(no_patch=True)): only
-    fp32 summation order may differ."""
+    """Full-width U-Net at the training batch: forward, loss, gradient norm and the updated weights with the production
+    kernels (Winograd F(2x2,3x3) + LDS-patch forward / dgrad, patch wgrad), with the direct LDS-patch kernels only
+    (ops.kernel_flags(no_wino=True)) and on the generic im2col kernels (no_patch=True): only fp32 summation order (and, for
+    Winograd, the rounding of its transforms) may differ."""
     import gad
     from src.ddpm_config import DDPMConfig
     cfg = DDPMConfig.cifar100_config
     outs = []
     from gad import ops as O
-    for no_patch in (False, True):
-        with O.kernel_flags(no_patch=no_patch):
+    for flags in (dict(), dict(no_wino=True), dict(no_patch=True)):
+        with O.kernel_flags(**flags):
             torch.manual_seed(0)
             net = gad.UNet2DModel(**cfg["unet_config"]).to(dev)
             tr = gad.FusedTrainer(net, gad.DDPMScheduler(**cfg["scheduler_config"]), gad.EMAModel(net.parameters()), lr=1e-4)
@@ -160,10 +161,13 @@ def test_whole_model_is_kernel_family_invariant():
             loss = tr.step(x, n, t).item()
             outs.append((y, loss, tr.grad_norm().item(), tr.flat.clone()))
             del net, tr
-    (y0, l0, g0, w0), (y1, l1, g1, w1) = outs
-    assert (y0 - y1).abs().max().item() < 1e-4 * max(1.0, y1.abs().max().item())
-    assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1
-    assert (w0 - w1).abs().max().item() < 2e-6            # one Adam step of lr 1e-4: updates are +-1e-4, signs must agree
+    y1, l1, g1, w1 = outs[-1]
+    for y0, l0, g0, w0 in outs[:-1]:
+        assert (y0 - y1).abs().max().item() < 1e-4 * max(1.0, y1.abs().max().item())
+        assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1
+        # one Adam step of lr 1e-4: updates are lr g / (|g| + 1e-8) = +-1e-4 except where |g| ~ eps; signs must agree
+        assert (w0 - w1).abs().max().item() < 1e-5
+    assert not torch.equal(outs[0][0], outs[1][0])        # the Winograd route really ran in the default configuration
 
 
 def test_full_width_training_step_matches_cpu_oracle():
