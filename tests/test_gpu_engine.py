@@ -237,3 +237,37 @@ def test_ldm_pipeline_decode_protocol():
     want = np.clip(raw / 0.5 / 2 + 0.5, 0, 1)
     inside = (lat > 1e-6) & (lat < 1 - 1e-6)
     assert np.allclose(img[:, ::2, ::2][inside], want[inside], atol=1e-5)
+
+
+def test_graph_replay_reads_the_current_winograd_weights():
+    """The captured U-Net forward reads the Winograd-transformed weights at a fixed address: a pipeline whose weights
+    change between two calls (EMA copy, the next coalition's checkpoint) must sample from the NEW weights on replay
+    (pipelines.DDPMPipeline._run_steps refreshes the shadows before replaying)."""
+    import gad
+    from gad import ops
+    from src.ddpm_config import DDPMConfig
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**dict(DDPMConfig.cifar100_config["unet_config"], block_out_channels=[64, 64, 128, 128])).to(dev).eval()
+    sch = gad.DDIMScheduler(**DDPMConfig.cifar100_config["scheduler_config"])
+    pipe = gad.DDPMPipeline(net, sch)
+    B = 128                                                     # 32 x 32 maps of 64 channels: 128 x 256 tiles -> the Winograd route
+    call = lambda p: p(batch_size=B, num_inference_steps=2, output_type="tensor", generator=torch.Generator().manual_seed(3)).images
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        with torch.no_grad():
+            net.forward_nhwc(torch.zeros(B, 32, 32, 3, device=dev), torch.zeros(B, device=dev, dtype=torch.int64))
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    assert any(k[0].startswith("conv_fwd_wino") for k in prof.summary())
+    a = call(pipe)
+    with torch.no_grad():
+        for p in net.parameters():
+            if p.ndim == 4:
+                p.mul_(0.5)
+    b = call(pipe)                                              # replays the captured graph
+    eager = gad.DDPMPipeline(net, sch)
+    eager.use_graph = False
+    want = call(eager)
+    assert not torch.equal(a, b)
+    assert torch.equal(b, want)

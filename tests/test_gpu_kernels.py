@@ -199,7 +199,8 @@ def test_conv_patch_split_channel_ranges_224_448(ops, B, Cin, Cout, H):
     want = conv_ref(x, w, b, 1, (1, 1, 1, 1), False) + temb.double()[:, :, None, None] + res.double()
     ops.PROFILER = prof = ops.GemmProfiler()
     try:
-        y = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), 1, (1, 1, 1, 1), False, rowadd=temb.to(dev), residual=nhwc(res))
+        with ops.kernel_flags(no_wino=True):           # the direct LDS-patch kernels (the default here is the Winograd route)
+            y = ops.conv2d_fwd_raw(nhwc(x), cl_weight(w), b.to(dev), 1, (1, 1, 1, 1), False, rowadd=temb.to(dev), residual=nhwc(res))
         torch.cuda.synchronize()
     finally:
         ops.PROFILER = None
@@ -215,6 +216,115 @@ def test_conv_patch_split_channel_ranges_224_448(ops, B, Cin, Cout, H):
     conv_ref(xd, wd, None, 1, (1, 1, 1, 1), False).backward(dy.double())
     dw = ops.conv2d_wgrad_raw(nhwc(dy), nhwc(x), cl_weight(w), 1, (1, 1, 1, 1), False)
     close(dw, wd.grad, atol=3e-5 * math.sqrt(B * H * H / 16))
+
+
+WINO_CASES = [
+    # B, Cin, Cout, H, W, upsample, epilogue            (launches of >= 256 blocks: the planner takes the Winograd route)
+    (64, 64, 128, 32, 32, False, True),        # 64 tiles x 128 channels
+    (256, 96, 192, 16, 16, False, True),       # pruned widths: 128 tiles x 64 channels
+    (128, 256, 256, 8, 8, True, True),         # behind the fused nearest-2x upsample
+    (65, 32, 68, 34, 30, False, True),         # tiles per image / per row not powers of two, tile rows and channels ragged
+    (128, 128, 320, 16, 16, False, False),     # SD width, no epilogue terms
+    (2, 64, 1024, 64, 64, False, True),        # few images, many channel blocks
+]
+
+
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ups,epi", WINO_CASES)
+def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi):
+    """Winograd F(2x2, 3x3) route (wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U = G w G^T) against fp64 -
+    with bias, the time-embedding row and the residual in its epilogue - and against the direct LDS-patch kernels on the
+    same inputs: same tolerance as every fp32 contraction, not bit-identical (the transforms round)."""
+    x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(Cin * 9)), rnd(Cout, seed=3)
+    want = conv_ref(x, w, b if epi else None, 1, (1, 1, 1, 1), ups)
+    temb, res = rnd(B, Cout, seed=4), rnd(*want.shape, seed=5)
+    if epi:
+        want = want + temb.double()[:, :, None, None] + res.double()
+    kw = dict(rowadd=temb.to(dev), residual=nhwc(res)) if epi else {}
+    xg, wg, bg = nhwc(x), cl_weight(w), b.to(dev) if epi else None
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    assert [k[0] for k in prof.summary()] == [f"conv_fwd_wino_w{W * (2 if ups else 1)}"], list(prof.summary())
+    y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
+    close(y.permute(0, 3, 1, 2), want, atol=3e-5)
+    with ops.kernel_flags(no_wino=True):
+        y0 = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
+    assert not torch.equal(y, y0)
+    close(y, y0, rtol=3e-5, atol=3e-5)
+    assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw))        # deterministic
+
+
+def test_winograd_is_not_taken_where_it_does_not_apply(ops):
+    """Small launches, stride 2, two-source gathers, forced tiles, bf16-operand mode and Cin % 32 != 0 stay on the direct
+    kernels: bit-identical to no_wino."""
+    import gad
+    cases = [dict(B=2, Cin=128, Cout=128, H=16), dict(B=64, Cin=48, Cout=128, H=32), dict(B=64, Cin=64, Cout=128, H=32, stride=2),
+             dict(B=64, Cin=64, Cout=128, H=32, tile=1), dict(B=64, Cin=64, Cout=128, H=32, bf16=True), dict(B=64, Cin=64, Cout=32, H=32)]
+    for c in cases:
+        x = nhwc(rnd(c["B"], c["Cin"], c["H"], c["H"], seed=1))
+        w = cl_weight(rnd(c["Cout"], c["Cin"], 3, 3, seed=2, scale=0.05))
+        run = lambda: ops.conv2d_fwd_raw(x, w, None, c.get("stride", 1), (1, 1, 1, 1), False, tile_hint=c.get("tile", 0))
+        with gad.operand_precision("bf16" if c.get("bf16") else "f32"):
+            y = run()
+            with ops.kernel_flags(no_wino=True):
+                y0 = run()
+        assert torch.equal(y, y0), c
+
+
+def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
+    """Weights in a flat parameter buffer: ONE gad_wino_weights launch transforms every eligible 3x3 weight (and, for the
+    data gradients, every weight of the rotated shadow); forward and data gradient through Conv2dFn equal fp64 autograd
+    before and after an optimizer-style rewrite (epoch bump) and a write through torch (version bump of one parameter)."""
+    from gad.training import flatten_params
+    shapes = [(128, 64, False, 32), (192, 96, True, 16), (64, 128, False, 32), (128, 3, False, 32)]     # Cout, Cin, upsample, H
+    ws = [torch.nn.Parameter(rnd(co, ci, 3, 3, seed=10 + i, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last))
+          for i, (co, ci, _, _) in enumerate(shapes)]
+    extra = torch.nn.Parameter(rnd(77, seed=20).to(dev))
+    flat, _ = flatten_params([ws[0], extra] + ws[1:])
+    Bn = 128
+
+    def check_all():
+        for w, (co, ci, up, H) in zip(ws[:3], shapes[:3]):
+            x = rnd(Bn, H, H, ci, seed=3).to(dev).requires_grad_(True)
+            ops.PROFILER = prof = ops.GemmProfiler()
+            try:
+                y = ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), up)
+                dy = rnd(*y.shape, seed=4).to(dev)
+                y.backward(dy)
+                torch.cuda.synchronize()
+            finally:
+                ops.PROFILER = None
+            names = [k[0] for k in prof.summary()]
+            assert sum(n.startswith("conv_fwd_wino") for n in names) == 2, names          # forward and data gradient
+            xr = x.detach().permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
+            xe = F.interpolate(xr, scale_factor=2.0, mode="nearest") if up else xr
+            yr = F.conv2d(xe, w.detach().double().cpu(), padding=1)
+            yr.backward(dy.permute(0, 3, 1, 2).double().cpu())
+            y = ops.Conv2dFn.apply(x, w, None, None, None, 1, (1, 1, 1, 1), up)
+            x.grad = None
+            y.backward(dy)
+            close(y.permute(0, 3, 1, 2), yr, atol=3e-5)
+            close(x.grad, xr.grad.permute(0, 2, 3, 1), atol=3e-5)
+            w.grad = None
+
+    check_all()
+    U = flat._gad_wino[1]
+    assert ws[3]._gad_flat[1] not in flat._gad_wino[2]                          # Cin = 3: not transformed
+    d0, dn = flat._gad_wino[2][ws[1]._gad_flat[1]]
+    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
+    want = torch.einsum("ar,orsi,bs->aboi", G, ops.weight_krsc(ws[1]).detach().double().cpu(), G).reshape(16, 192, 96)
+    close(U[d0:d0 + dn].view(16, 192, 96), want, rtol=1e-6, atol=1e-6)
+    with torch.no_grad():
+        flat.detach().mul_(1.5)
+    flat._gad_epoch = getattr(flat, "_gad_epoch", 0) + 1
+    check_all()
+    with torch.no_grad():
+        ws[2].copy_(ws[2] * 0.25)
+    check_all()
+    assert flat._gad_wino[1] is U
 
 
 def test_conv_autograd_function(ops):
