@@ -2471,7 +2471,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   if (!a->B_wino || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
   const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 1) || (We & 1)) return false;
-  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || a->tile_hint != 0 || a->splitk_hint > 0 || a->batch > 1) return false;
+  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7) || a->splitk_hint > 0 || a->batch > 1) return false;
   if (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_SCALAR_EPILOGUE | GAD_GEMM_TAP_MAJOR_K)) return false;
   if (a->rowadd && a->rows_per_group != g.Ho * g.Wo) return false;
   if (a->M % (g.Ho * g.Wo) != 0) return false;
@@ -2485,7 +2485,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   wp->tiles_m = (int)gad_ceil_div(wp->T, wp->bm);
   wp->tiles_n = (int)gad_ceil_div(a->N, wp->bn);
   wp->bytes = (int64_t)16 * wp->T * g.C * (int64_t)sizeof(float);
-  return (long)wp->tiles_m * wp->tiles_n >= 256 && wp->T < (1L << 30);
+  return ((long)wp->tiles_m * wp->tiles_n >= 256 || a->tile_hint == 7) && wp->T < (1L << 30);       // tile_hint 7: A/B tools force the route
 }
 
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {

@@ -306,7 +306,7 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
              tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
-             B_wino=wino_weight(w) if (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint == 0
+             B_wino=wino_weight(w) if (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7)
                                        and splitk_hint == 0 and tuple(pad) == (1, 1, 1, 1)) else None,
              B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
                                        and not torch.cuda.is_current_stream_capturing()) else None)
