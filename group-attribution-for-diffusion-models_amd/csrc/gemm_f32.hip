@@ -2480,14 +2480,31 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
                       (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0));
   if (!vec_ok) return false;
   wp->T = (long)a->M / 4;
-  const long pad128 = gad_ceil_div(a->N, 128) * 128, pad64 = gad_ceil_div(a->N, 64) * 64;
-  if (pad64 < pad128) { wp->bm = 128; wp->bn = 64; } else { wp->bm = 64; wp->bn = 128; }
-  wp->tiles_m = (int)gad_ceil_div(wp->T, wp->bm);
-  wp->tiles_n = (int)gad_ceil_div(a->N, wp->bn);
+  if (wp->T >= (1L << 30)) return false;
   wp->bytes = (int64_t)16 * wp->T * g.C * (int64_t)sizeof(float);
-  return ((long)wp->tiles_m * wp->tiles_n >= 256 || a->tile_hint == 7) && wp->T < (1L << 30);       // tile_hint 7: A/B tools force the route
+  // Modelled times (calibrated on tools/ab_winograd.py, profiles/r03_ab_winograd.txt).  Winograd: the input transform moves
+  // |x| + |V| = 5 |x| bytes (17 |x| behind the fused upsample) at ~4.9 TB/s; a CU runs the 16-position product of one block at ~0.46 TF/s whether it holds one block or two,
+  // so the GEMM takes ceil(blocks / 256) block times.  Direct: the patch plan's rounds of 512 workgroups at ~0.26 TF/s each.
+  const double x_bytes = 4.0 * (double)(a->M / (g.Ho * g.Wo)) * g.H * g.W * g.C;
+  double best = 1e30;
+  for (int v = 0; v < 2; ++v) {
+    const int bm = v ? 128 : 64, bn = v ? 64 : 128;
+    const long tm = gad_ceil_div(wp->T, bm), tn = gad_ceil_div(a->N, bn);
+    const double t = (double)gad_ceil_div(tm * tn, 256) * (16.0 * bm * bn * g.C * 2.0) / 0.46e12;
+    if (t < best) { best = t; wp->bm = bm; wp->bn = bn; wp->tiles_m = (int)tm; wp->tiles_n = (int)tn; }
+  }
+  if (a->tile_hint == 7) return true;            // A/B tools force the route
+  const double t_wino = best + (x_bytes + (double)wp->bytes) / 4.9e12 + 6e-6;
+  double t_direct;
+  PatchPlan pp;
+  if (use_patch_conv_f32(a, &pp)) {
+    t_direct = (double)gad_ceil_div(pp.blocks, 512) * pp.chunks_per_split * 9.0 * (128.0 * pp.bn * 64.0) / 0.264e12;
+    if (pp.splitk > 1) t_direct += 4e-6 + (double)a->M * a->N * 4.0 * (pp.splitk + 1) / 3.0e12;
+  } else {
+    t_direct = 2.0 * a->M * (double)a->N * a->K / 110e12;
+  }
+  return t_wino < 0.9 * t_direct;
 }
-
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
   if (!a) return 0;
   GAD_CANON(a);

@@ -219,21 +219,23 @@ def test_conv_patch_split_channel_ranges_224_448(ops, B, Cin, Cout, H):
 
 
 WINO_CASES = [
-    # B, Cin, Cout, H, W, upsample, epilogue            (launches of >= 256 blocks: the planner takes the Winograd route)
-    (64, 64, 128, 32, 32, False, True),        # 64 tiles x 128 channels
-    (256, 96, 192, 16, 16, False, True),       # pruned widths: 128 tiles x 64 channels
-    (128, 256, 256, 8, 8, True, True),         # behind the fused nearest-2x upsample
-    (65, 32, 68, 34, 30, False, True),         # tiles per image / per row not powers of two, tile rows and channels ragged
-    (128, 128, 320, 16, 16, False, False),     # SD width, no epilogue terms
-    (2, 64, 1024, 64, 64, False, True),        # few images, many channel blocks
+    # B, Cin, Cout, H, W, upsample, epilogue
+    (8, 64, 128, 32, 32, False, True),         # 64 tiles x 128 channels
+    (6, 96, 192, 16, 16, False, True),         # pruned widths: 128 tiles x 64 channels
+    (3, 256, 256, 8, 8, True, True),           # behind the fused nearest-2x upsample
+    (5, 32, 68, 34, 30, False, True),          # tiles per image / per row not powers of two, tile rows and channels ragged
+    (4, 128, 320, 16, 16, False, False),       # SD width, no epilogue terms
+    (1, 64, 1024, 64, 64, False, True),        # one image, many channel blocks
+    (1, 32, 64, 2, 2, False, True),            # a single tile
 ]
 
 
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ups,epi", WINO_CASES)
 def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi):
-    """Winograd F(2x2, 3x3) route (wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U = G w G^T) against fp64 -
-    with bias, the time-embedding row and the residual in its epilogue - and against the direct LDS-patch kernels on the
-    same inputs: same tolerance as every fp32 contraction, not bit-identical (the transforms round)."""
+    """Winograd F(2x2, 3x3) route (wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U = G w G^T; tile_hint 7 forces
+    it whatever the launch size) against fp64 - with bias, the time-embedding row and the residual in its epilogue - and
+    against the direct kernels on the same inputs: same tolerance as every fp32 contraction, not bit-identical (the
+    transforms round), deterministic."""
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(Cin * 9)), rnd(Cout, seed=3)
     want = conv_ref(x, w, b if epi else None, 1, (1, 1, 1, 1), ups)
     temb, res = rnd(B, Cout, seed=4), rnd(*want.shape, seed=5)
@@ -243,18 +245,35 @@ def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi):
     xg, wg, bg = nhwc(x), cl_weight(w), b.to(dev) if epi else None
     ops.PROFILER = prof = ops.GemmProfiler()
     try:
-        y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
+        y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw)
         torch.cuda.synchronize()
     finally:
         ops.PROFILER = None
     assert [k[0] for k in prof.summary()] == [f"conv_fwd_wino_w{W * (2 if ups else 1)}"], list(prof.summary())
-    y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
+    y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw)
     close(y.permute(0, 3, 1, 2), want, atol=3e-5)
     with ops.kernel_flags(no_wino=True):
         y0 = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
     assert not torch.equal(y, y0)
     close(y, y0, rtol=3e-5, atol=3e-5)
-    assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw))        # deterministic
+    assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw))        # deterministic
+
+
+def test_winograd_planner_takes_the_large_launches(ops):
+    """The planner's modelled times (input transform + ceil(blocks / 256) block times against the direct plan's rounds): the
+    sampler's and the trainer's big 3x3 launches go to the Winograd route, small maps at small batch stay direct."""
+    def route(B, H, Cin, Cout):
+        x, w = torch.zeros(B, H, H, Cin, device=dev), cl_weight(rnd(Cout, Cin, 3, 3, seed=2, scale=0.05))
+        ops.PROFILER = prof = ops.GemmProfiler()
+        try:
+            ops.conv2d_fwd_raw(x, w, None)
+            torch.cuda.synchronize()
+        finally:
+            ops.PROFILER = None
+        return ["wino" if "wino" in k[0] else "direct" for k in prof.summary()]
+    assert route(128, 32, 128, 128) == ["wino"] and route(128, 16, 256, 256) == ["wino"] and route(1024, 8, 256, 256) == ["wino"]
+    assert route(16, 64, 320, 320) == ["wino"] and route(32, 32, 448, 448) == ["wino"]
+    assert route(128, 8, 256, 256) == ["direct"] and route(16, 8, 1280, 1280) == ["direct"] and route(128, 4, 256, 256) == ["direct"]
 
 
 def test_winograd_is_not_taken_where_it_does_not_apply(ops):
@@ -279,7 +298,7 @@ def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
     data gradients, every weight of the rotated shadow); forward and data gradient through Conv2dFn equal fp64 autograd
     before and after an optimizer-style rewrite (epoch bump) and a write through torch (version bump of one parameter)."""
     from gad.training import flatten_params
-    shapes = [(128, 64, False, 32), (192, 96, True, 16), (64, 128, False, 32), (128, 3, False, 32)]     # Cout, Cin, upsample, H
+    shapes = [(128, 128, False, 32), (256, 128, True, 16), (128, 256, False, 32), (128, 3, False, 32)]     # Cout, Cin, upsample, H
     ws = [torch.nn.Parameter(rnd(co, ci, 3, 3, seed=10 + i, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last))
           for i, (co, ci, _, _) in enumerate(shapes)]
     extra = torch.nn.Parameter(rnd(77, seed=20).to(dev))
@@ -297,8 +316,8 @@ def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
                 torch.cuda.synchronize()
             finally:
                 ops.PROFILER = None
-            names = [k[0] for k in prof.summary()]
-            assert sum(n.startswith("conv_fwd_wino") for n in names) == 2, names          # forward and data gradient
+            summ = prof.summary()
+            assert sum(v["launches"] for k, v in summ.items() if k[0].startswith("conv_fwd_wino")) == 2, list(summ)   # forward and data gradient
             xr = x.detach().permute(0, 3, 1, 2).double().cpu().requires_grad_(True)
             xe = F.interpolate(xr, scale_factor=2.0, mode="nearest") if up else xr
             yr = F.conv2d(xe, w.detach().double().cpu(), padding=1)
@@ -315,8 +334,8 @@ def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
     assert ws[3]._gad_flat[1] not in flat._gad_wino[2]                          # Cin = 3: not transformed
     d0, dn = flat._gad_wino[2][ws[1]._gad_flat[1]]
     G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
-    want = torch.einsum("ar,orsi,bs->aboi", G, ops.weight_krsc(ws[1]).detach().double().cpu(), G).reshape(16, 192, 96)
-    close(U[d0:d0 + dn].view(16, 192, 96), want, rtol=1e-6, atol=1e-6)
+    want = torch.einsum("ar,orsi,bs->aboi", G, ops.weight_krsc(ws[1]).detach().double().cpu(), G).reshape(16, 256, 128)
+    close(U[d0:d0 + dn].view(16, 256, 128), want, rtol=1e-6, atol=1e-6)
     with torch.no_grad():
         flat.detach().mul_(1.5)
     flat._gad_epoch = getattr(flat, "_gad_epoch", 0) + 1
