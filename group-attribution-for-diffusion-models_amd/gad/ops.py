@@ -232,7 +232,7 @@ class GemmProfiler:
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
-        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", f"_wino_w{a.g.Wo}")[kid]
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino")[kid]   # (the Winograd kernels are one instance for every map width)
         if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)

@@ -81,7 +81,8 @@ typedef struct gad_gemm_args {
   /* split-K workspace (caller owned). ws_bytes >= gad_gemm_workspace_bytes(args)            */
   void* ws;
   int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms); 3x3 weight gradient:
+  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms); 7 = a forward 3x3 convolution
+                             * with B_wino takes the Winograd route whatever the planner models (tests, A/B tools); 3x3 weight gradient:
                              * 1 / 4 / 5 / 6 = 128 / 96 / 64 / 32 output channels per tile, 1000 + m1 = rows [0, m1) on 128-channel
                              * tiles and the rest planned, as a second launch (A/B tools) */
   int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
@@ -114,10 +115,13 @@ typedef struct gad_gemm_args {
    * travel with the call - the library reads no environment variable and keeps no process-global switch. */
   int32_t flags;
   /* Winograd F(2x2, 3x3) route of the fp32 3x3 / stride 1 / pad 1 forward convolution (A_CONV x B_KC, even output maps,
-   * Cin % 32 == 0, N % 4 == 0, launches with >= 256 blocks of 64 tiles x 128 channels): B_wino = the transformed weights
+   * Cin % 32 == 0, N % 4 == 0, N >= 64, single source, float4-addressable epilogue operands): B_wino = the transformed weights
    * U[16][Cout][Cin] = G w G^T made by gad_wino_weights from the [Cout][3][3][Cin] storage B points at; wino_ws = scratch
    * of gad_gemm_wino_bytes(args) bytes for the transformed input V[16][tiles][Cin].  B_wino == NULL (or a launch the
-   * planner keeps on the direct kernels: gad_gemm_wino_bytes returns 0): the direct kernels run and both are ignored. */
+   * planner models no faster than the direct kernels: gad_gemm_wino_bytes returns 0): the direct kernels run and both are
+   * ignored.  fp32 throughout; equal to the direct kernels up to fp32 reassociation / transform rounding, deterministic.
+   * Replaces what cuDNN's own algorithm choice does for these convolutions in the reference (torch.nn.Conv2d of
+   * diffusers' ResnetBlock2D.conv1 / conv2, Upsample2D.conv). */
   const float* B_wino;
   void* wino_ws;
   int64_t wino_ws_bytes;
