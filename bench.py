@@ -374,6 +374,9 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
         else:
             tiles_ = "128- then 96-channel tiles, two launches" if dom_key[1] == 224 else f"{dom_key[1]}-channel tiles"
             kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {'128 | 96' if dom_key[1] == 224 else dom_key[1]}> ({nm}, {tiles_})"
+    elif "_wino4" in nm:      # Winograd F(4x4,3x3): input transform + 36 batched products + output transform, bracketed together
+        kname = (f"wino4_input_kernel + gemm_kernel<24, 25, 128, 128, 4, 1> (36 batched products) + wino4_output_kernel ({nm}: "
+                 "the three launches are one convolution; time = all of them)")
     elif "_wino" in nm:       # Winograd F(2x2,3x3): input transform + the 16-position MFMA loop, bracketed together
         kname = (f"wino_input_kernel + wino_gemm_kernel<{'64, 128' if dom_key[1] == 128 else '128, 64'}> ({nm}: the pair is one "
                  "convolution; time = both launches)")
@@ -393,13 +396,16 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
             "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "share_of_step_time": d["ms"] / (dt * 1e3)}
     if "_wino" in nm:
         # `achieved` stays the ALGORITHMIC rate (2 x 9 Cin Cout per output pixel, the direct-convolution count every other
-        # line uses) and may exceed the MFMA peak: the Winograd form executes 16/36 of those multiplies.
-        roof["mfma_executed"] = {"gflop_per_launch": roof["algorithmic_gflop_per_launch"] * 16.0 / 36.0,
-                                 "tflops": roof["achieved"] * 16.0 / 36.0, "frac_of_peak": roof["frac"] * 16.0 / 36.0,
-                                 "note": "Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and channel pair instead of "
-                                         "36; frac = algorithmic FLOPs / time / peak (> 1 is possible), frac_of_peak here = the MFMA "
-                                         "work actually issued / the same time (input transform launch included) / peak"}
-        if traffic is not None and "wino" not in json.dumps(j.get("dominant_kernel", "")):
+        # line uses) and may exceed the MFMA peak: the Winograd forms execute 16/36 (F(2x2)) or 36/144 (F(4x4)) of those multiplies.
+        ex = 36.0 / 144.0 if "_wino4" in nm else 16.0 / 36.0
+        roof["mfma_executed"] = {"gflop_per_launch": roof["algorithmic_gflop_per_launch"] * ex,
+                                 "tflops": roof["achieved"] * ex, "frac_of_peak": roof["frac"] * ex,
+                                 "note": ("Winograd F(4x4,3x3) executes 36 multiplies per 4x4 output tile and channel pair instead of 144"
+                                          if "_wino4" in nm else
+                                          "Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and channel pair instead of 36")
+                                         + "; frac = algorithmic FLOPs / time / peak (> 1 is possible), frac_of_peak here = the MFMA "
+                                           "work actually issued / the same time (transform launches included) / peak"}
+        if traffic is not None and ("wino4" in nm) != ("wino4" in json.dumps(j.get("dominant_kernel", ""))):
             roof["traffic"], roof["traffic_source"] = None, None          # the stored counter pass is of another kernel
     all_ms = sum(v["ms"] for v in summ.values())
     all_fl = sum(v["flops"] for v in summ.values())

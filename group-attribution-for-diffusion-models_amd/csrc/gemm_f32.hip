@@ -841,7 +841,8 @@ __device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int g, int
   }
 }
 
-template <int AM, int BMODE, int BM, int BN, int VEC>
+// TAG only names an instance apart in profiles (1: the 36 batched products of the F(4x4) Winograd route)
+template <int AM, int BMODE, int BM, int BN, int VEC, int TAG = 0>
 __global__ __launch_bounds__(NTHREADS) void gemm_kernel(const DevArgs p) {
   constexpr int TM = BM / 64, TN = BN / 64;
   using AL = ALoader<AM, BM, VEC>;
@@ -2101,6 +2102,165 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_gemm_kernel(const DevArgs p)
   for (int q = 0; q < 4; ++q) store_block_wino<TM, TN, BM, BN>(p, Y[q], row0, col0, wm, wn, h, l31, q >> 1, q & 1, scratch);
 }
 
+// ------------------------------------------------------------------------------------
+// Winograd F(4x4, 3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 (4x fewer MFMA FLOPs) and a
+// transformed input of only 2.25x the input.  Sixteen output-pixel accumulator sets do not fit a wave, so the element-wise
+// products M[36][tiles][Cout] go through memory: wino4_input_kernel (V = B^T d B, 6x6 patches), the generic engine as ONE
+// batched launch of 36 [tiles x Cin] x [Cin x Cout] products on its 128 x 128 lean tiles, wino4_output_kernel (y = A^T M A
+// + the fused epilogue).  Standard points {0, +-1, +-2, inf}:
+//   B^T = [4 0 -5 0 1 0; 0 -4 -4 1 1 0; 0 4 -4 -1 1 0; 0 -2 -1 2 1 0; 0 2 -1 -2 1 0; 0 4 0 -5 0 1]
+//   G   = [1/4 0 0; -1/6 -1/6 -1/6; -1/6 1/6 -1/6; 1/24 1/12 1/6; 1/24 -1/12 1/6; 0 0 1]
+//   A^T = [1 1 1 1 1 0; 0 1 -1 2 -2 0; 0 1 1 4 4 0; 0 1 -1 8 -8 1]
+// fp32 throughout; the larger transform coefficients cost about a decimal digit against the direct kernels (measured
+// max error 4e-6 of the output scale vs 4e-7), still an order of magnitude inside the contraction tolerance of the tests.
+// ------------------------------------------------------------------------------------
+__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&t)[6]) {
+  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
+  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
+  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
+  t[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
+  t[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
+  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_input_kernel(const WinoIn p) {   // p.TH / p.TW / p.T count 4x4 tiles
+  const int C4 = p.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.T * C4) return;
+  const long tile = idx / C4;
+  const int c = (int)(idx - tile * C4) * 4;
+  const int per = p.TH * p.TW;
+  const int n = (int)(tile / per);
+  const int r = (int)(tile - (long)n * per);
+  const int ty = r / p.TW, tx = r - ty * p.TW;
+  const int He = p.H << p.up, We = p.W << p.up;
+  const float* img = p.x + (long)n * p.H * p.W * p.ldx + c;
+  f32x4 t[6][6];                                 // t[i][dx] = (B^T d)[i][dx]
+#pragma unroll
+  for (int dx = 0; dx < 6; ++dx) {
+    const int xx = 4 * tx - 1 + dx;
+    const bool xok = xx >= 0 && xx < We;
+    f32x4 d[6], col[6];
+#pragma unroll
+    for (int dy = 0; dy < 6; ++dy) {
+      const int yy = 4 * ty - 1 + dy;
+      const bool ok = xok && yy >= 0 && yy < He;
+      d[dy] = ok ? ldg4(img + ((long)(yy >> p.up) * p.W + (xx >> p.up)) * p.ldx) : zero4();
+    }
+    wino4_bt(d, col);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][dx] = col[i];
+  }
+  const long pos_stride = p.T * p.C;
+  float* out = p.V + tile * p.C + c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x4 v[6];
+    wino4_bt(t[i], v);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(out + (long)(6 * i + j) * pos_stride) = v[j];
+  }
+}
+
+// U[36][co][ci] = G w G^T, 32 x 32 (co, ci) tiles as in wino_weights_kernel (dst region of 36 Cout Cin floats per weight)
+__global__ __launch_bounds__(256) void wino4_weights_kernel(const float* src, float* dst, const long* table) {
+  const long* row = table + 6 * (long)blockIdx.x;
+  const long soff = row[0], doff = row[1];
+  const int Cout = (int)row[2], Cin = (int)row[3], co0 = (int)row[4], ci0 = (int)row[5];
+  const int ci = ci0 + (threadIdx.x & 31);
+  if (ci >= Cin) return;
+  auto gmul = [](float a, float b, float c, float (&o)[6]) {      // G [a b c]^T
+    o[0] = 0.25f * a;
+    o[1] = (-1.f / 6.f) * (a + b + c);
+    o[2] = (-1.f / 6.f) * (a - b + c);
+    o[3] = (1.f / 24.f) * a + (1.f / 12.f) * b + (1.f / 6.f) * c;
+    o[4] = (1.f / 24.f) * a - (1.f / 12.f) * b + (1.f / 6.f) * c;
+    o[5] = c;
+  };
+#pragma unroll
+  for (int q = 0; q < 4; ++q) {
+    const int co = co0 + (threadIdx.x >> 5) + 8 * q;
+    if (co >= Cout) continue;
+    const float* w = src + soff + (long)co * 9 * Cin + ci;
+    float gg[6][3];                               // G g (columns s = 0..2)
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) {
+      float o[6];
+      gmul(w[(long)(0 * 3 + sx) * Cin], w[(long)(1 * 3 + sx) * Cin], w[(long)(2 * 3 + sx) * Cin], o);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) gg[i][sx] = o[i];
+    }
+    float* u = dst + doff + (long)co * Cin + ci;
+    const long ps = (long)Cout * Cin;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      float o[6];
+      gmul(gg[i][0], gg[i][1], gg[i][2], o);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) u[(long)(6 * i + j) * ps] = o[j];
+    }
+  }
+}
+
+struct WinoOut {
+  const float* Mb;           // [36][T][N]
+  float* y;
+  const float* bias;
+  const float* rowadd;
+  const float* residual;
+  int N, ldc, ldr, ld_rowadd, Ho, Wo, TH, TW;
+  long T;
+  float alpha;
+};
+
+__device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
+  const f32x4 s12 = m[1] + m[2], d12 = m[1] - m[2], s34 = m[3] + m[4], d34 = m[3] - m[4];
+  y[0] = m[0] + s12 + s34;
+  y[1] = d12 + 2.f * d34;
+  y[2] = s12 + 4.f * s34;
+  y[3] = d12 + 8.f * d34 + m[5];
+}
+
+__global__ __launch_bounds__(256) void wino4_output_kernel(const WinoOut p) {
+  const int N4 = p.N >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.T * N4) return;
+  const long tile = idx / N4;
+  const int n = (int)(idx - tile * N4) * 4;
+  const int per = p.TH * p.TW;
+  const int img = (int)(tile / per);
+  const int r = (int)(tile - (long)img * per);
+  const int ty = r / p.TW, tx = r - ty * p.TW;
+  const long pos_stride = p.T * p.N;
+  const float* src = p.Mb + tile * p.N + n;
+  f32x4 t[4][6];                                 // t[i][nu] = (A^T M)[i][nu]
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    f32x4 m[6], col[4];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) m[xi] = ldg4(src + (long)(6 * xi + nu) * pos_stride);
+    wino4_at(m, col);
+#pragma unroll
+    for (int i = 0; i < 4; ++i) t[i][nu] = col[i];
+  }
+  const f32x4 b = p.bias ? ldg4(p.bias + n) : zero4();
+  const f32x4 ra = p.rowadd ? ldg4(p.rowadd + (long)img * p.ld_rowadd + n) : zero4();
+#pragma unroll
+  for (int i = 0; i < 4; ++i) {
+    f32x4 y[4];
+    wino4_at(t[i], y);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const long pix = ((long)img * p.Ho + 4 * ty + i) * p.Wo + 4 * tx + j;
+      f32x4 v = f32x4{__builtin_fmaf(y[j][0], p.alpha, b[0]), __builtin_fmaf(y[j][1], p.alpha, b[1]),
+                      __builtin_fmaf(y[j][2], p.alpha, b[2]), __builtin_fmaf(y[j][3], p.alpha, b[3])};
+      if (p.rowadd) v += ra;
+      if (p.residual) v += ldg4(p.residual + pix * p.ldr + n);
+      *reinterpret_cast<f32x4*>(p.y + pix * p.ldc + n) = v;
+    }
+  }
+}
+
 static FastDiv make_fastdiv(unsigned d) {
   FastDiv f;
   if (d == 0) d = 1;
@@ -2212,7 +2372,7 @@ static Plan make_plan(const gad_gemm_args* a) {
   return pl;
 }
 
-template <int AM, int BMODE, int VEC>
+template <int AM, int BMODE, int VEC, int TAG = 0>
 static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
   dim3 grid((unsigned)pl.nblocks), block(NTHREADS);
   if (pl.bm == 128 && pl.bn == 64) {
@@ -2221,11 +2381,11 @@ static void launch_mode(const DevArgs& d, const Plan& pl, hipStream_t st) {
                                (AM == A_KC2 && (BMODE == B_KC2 || BMODE == B_MC2)) ||
                                (AM == A_KC_L && (BMODE == B_KC_L || BMODE == B_MC_L)) || (AM == A_MC_L && BMODE == B_MC_L) ||
                                (AM == A_KC2_L && (BMODE == B_KC2_L || BMODE == B_MC2_L))))
-      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 64, VEC>), grid, block, 0, st, d);
+      hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 64, VEC, TAG>), grid, block, 0, st, d);
   } else if (pl.bm == 128)
-    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC>), grid, block, 0, st, d);
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 128, 128, VEC, TAG>), grid, block, 0, st, d);
   else
-    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC>), grid, block, 0, st, d);
+    hipLaunchKernelGGL((gemm_kernel<AM, BMODE, 64, 64, VEC, TAG>), grid, block, 0, st, d);
 }
 
 template <int AM, int BMODE>
@@ -2461,17 +2621,19 @@ static bool as_dense_1x1(const gad_gemm_args* a, gad_gemm_args* out) {
 // Winograd F(2x2, 3x3) route of the fp32 3x3 / stride 1 / pad 1 forward convolution (and, through ops.dgrad_as_forward, of
 // its data gradient): taken when the caller supplies the transformed weights (B_wino) and the launch has tiles enough to
 // fill the chip - small maps at small batch keep the direct LDS-patch kernels and their split-K.
+constexpr int GAD_GEMM_INTERNAL_WINO4 = 1 << 30;   // set by gad_gemm on its own batched sub-launch (names the kernel instance apart)
 struct WinoPlan {
+  int f;                     // 2: F(2x2,3x3) fused kernels; 4: F(4x4,3x3) through the batched engine
   int bm, bn, tiles_m, tiles_n;
-  long T;
-  int64_t bytes;
+  long T;                    // tiles (2x2 or 4x4 output pixels each)
+  int64_t bytes;             // scratch: V (f = 2), V + M (f = 4)
 };
 static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   const gad_conv_geom& g = a->g;
-  if (!a->B_wino || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
+  if ((!a->B_wino && !a->B_wino4) || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
   const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 1) || (We & 1)) return false;
-  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7) || a->splitk_hint > 0 || a->batch > 1) return false;
+  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7 && a->tile_hint != 8) || a->splitk_hint > 0 || a->batch > 1) return false;
   if (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_SCALAR_EPILOGUE | GAD_GEMM_TAP_MAJOR_K)) return false;
   if (a->rowadd && a->rows_per_group != g.Ho * g.Wo) return false;
   if (a->M % (g.Ho * g.Wo) != 0) return false;
@@ -2479,22 +2641,43 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
                       (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
                       (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0));
   if (!vec_ok) return false;
-  wp->T = (long)a->M / 4;
-  if (wp->T >= (1L << 30)) return false;
-  wp->bytes = (int64_t)16 * wp->T * g.C * (int64_t)sizeof(float);
-  // Modelled times (calibrated on tools/ab_winograd.py, profiles/r03_ab_winograd.txt).  Winograd: the input transform moves
-  // |x| + |V| = 5 |x| bytes (17 |x| behind the fused upsample) at ~4.9 TB/s; a CU runs the 16-position product of one block at ~0.46 TF/s whether it holds one block or two,
-  // so the GEMM takes ceil(blocks / 256) block times.  Direct: the patch plan's rounds of 512 workgroups at ~0.26 TF/s each.
+  const bool f2_ok = a->B_wino != nullptr && (long)a->M / 4 < (1L << 30) && a->tile_hint != 8;
+  const bool f4_ok = a->B_wino4 != nullptr && (He & 3) == 0 && (We & 3) == 0 && a->tile_hint != 7;
+  // Modelled times (calibrated on tools/ab_winograd.py, profiles/r03_ab_winograd.txt).  Transform launches stream their bytes
+  // at ~4.9 TB/s.  F(2x2): a CU runs the 16-position product of one block at ~0.43 TF/s whether it holds one block or two,
+  // so the GEMM takes ceil(blocks / 256) block times.  F(4x4): 36 batched products on 128 x 128 tiles, rounds of 512
+  // workgroups, (K steps + 1) step times each.  Direct: the patch plan's rounds of 512 workgroups at ~0.26 TF/s each.
   const double x_bytes = 4.0 * (double)(a->M / (g.Ho * g.Wo)) * g.H * g.W * g.C;
-  double best = 1e30;
-  for (int v = 0; v < 2; ++v) {
-    const int bm = v ? 128 : 64, bn = v ? 64 : 128;
-    const long tm = gad_ceil_div(wp->T, bm), tn = gad_ceil_div(a->N, bn);
-    const double t = (double)gad_ceil_div(tm * tn, 256) * (16.0 * bm * bn * g.C * 2.0) / 0.46e12;
-    if (t < best) { best = t; wp->bm = bm; wp->bn = bn; wp->tiles_m = (int)tm; wp->tiles_n = (int)tn; }
+  const double y_bytes = 4.0 * (double)a->M * a->N * (a->residual ? 2.0 : 1.0);
+  double t2 = 1e30, t4 = 1e30;
+  WinoPlan p2{}, p4{};
+  if (f2_ok) {
+    p2.f = 2;
+    p2.T = (long)a->M / 4;
+    p2.bytes = (int64_t)16 * p2.T * g.C * (int64_t)sizeof(float);
+    double best = 1e30;
+    for (int v = 0; v < 2; ++v) {
+      const int bm = v ? 128 : 64, bn = v ? 64 : 128;
+      const long tm = gad_ceil_div(p2.T, bm), tn = gad_ceil_div(a->N, bn);
+      const double t = (double)gad_ceil_div(tm * tn, 256) * (16.0 * bm * bn * g.C * 2.0) / 0.43e12;
+      if (t < best) { best = t; p2.bm = bm; p2.bn = bn; p2.tiles_m = (int)tm; p2.tiles_n = (int)tn; }
+    }
+    t2 = best + (x_bytes + (double)p2.bytes) / 4.9e12 + 6e-6;
   }
-  if (a->tile_hint == 7) return true;            // A/B tools force the route
-  const double t_wino = best + (x_bytes + (double)wp->bytes) / 4.9e12 + 6e-6;
+  if (f4_ok) {
+    p4.f = 4;
+    p4.T = (long)a->M / 16;
+    const double vb = 36.0 * p4.T * g.C * 4.0, mb = 36.0 * p4.T * a->N * 4.0;
+    p4.bytes = (int64_t)(vb + mb);
+    const long blocks = gad_ceil_div(p4.T, 128) * gad_ceil_div(a->N, 128) * 36;
+    const double t_gemm = (double)gad_ceil_div(blocks, 512) * (g.C / BK + 1) * (128.0 * 128.0 * BK * 2.0) / 0.254e12;
+    t4 = (x_bytes + vb) / 4.9e12 + t_gemm + (mb + y_bytes) / 4.9e12 + 18e-6;
+  }
+  if (a->tile_hint == 7 || a->tile_hint == 8) {  // A/B tools force a route
+    if (a->tile_hint == 7 && f2_ok) { *wp = p2; return true; }
+    if (a->tile_hint == 8 && f4_ok) { *wp = p4; return true; }
+    return false;
+  }
   double t_direct;
   PatchPlan pp;
   if (use_patch_conv_f32(a, &pp)) {
@@ -2503,8 +2686,12 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   } else {
     t_direct = 2.0 * a->M * (double)a->N * a->K / 110e12;
   }
-  return t_wino < 0.9 * t_direct;
+  const double tw = t2 < t4 ? t2 : t4;
+  if (!(tw < 0.9 * t_direct)) return false;
+  *wp = t2 < t4 ? p2 : p4;
+  return true;
 }
+
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
   if (!a) return 0;
   GAD_CANON(a);
@@ -2514,7 +2701,7 @@ extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
 extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
   GAD_CANON(a);
-  if (WinoPlan wp; use_wino(a, &wp)) return 5;
+  if (WinoPlan wp; use_wino(a, &wp)) return wp.f == 2 ? 5 : 6;
   if (use_fewout_conv(a)) return 4;
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
@@ -2528,8 +2715,8 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   GAD_CANON(a);
   *vec = pick_vec(a);
   PatchPlan pp;
-  if (WinoPlan wp; use_wino(a, &wp)) {           // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn)
-    *tile = wp.bn;
+  if (WinoPlan wp; use_wino(a, &wp)) {           // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn); F(4x4): 128
+    *tile = wp.f == 2 ? wp.bn : 128;
     *splitk = 1;
   } else if (use_fewout_conv(a)) {               // vector-ALU kernel: 256 pixels x all (<= 4) output channels
     *tile = 256;
@@ -2565,9 +2752,25 @@ extern "C" int gad_wino_weights(const float* src, float* dst, const int64_t* tab
   return 0;
 }
 
+extern "C" int gad_wino4_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream) {
+  GAD_CHECK(src && dst && table && n_tiles > 0 && n_tiles < (1L << 31), "gad_wino4_weights: bad arguments");
+  hipLaunchKernelGGL(wino4_weights_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, dst, (const long*)table);
+  GAD_LAUNCH_CHECK("gad_wino4_weights");
+  return 0;
+}
+
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   GAD_CANON(a);
-  if (WinoPlan wp; use_wino(a, &wp)) return 0;
+  if (WinoPlan wp; use_wino(a, &wp)) {
+    if (wp.f == 2) return 0;
+    gad_gemm_args sub = *a;                      // the 36 batched products may split K on small launches
+    sub.B_wino = nullptr; sub.B_wino4 = nullptr;
+    sub.a_mode = GAD_A_KC; sub.b_mode = GAD_B_KC;
+    sub.M = (int32_t)wp.T; sub.K = a->g.C; sub.lda = a->g.C; sub.ldb = a->g.C; sub.ldc = a->N;
+    sub.batch = 36; sub.batch_inner = 1; sub.tile_hint = 0;
+    sub.bias = nullptr; sub.rowadd = nullptr; sub.residual = nullptr; sub.alpha = 1.f;
+    return gad_gemm_workspace_bytes(&sub);
+  }
   if (use_fewout_conv(a)) return 0;
   if (int m1 = 0; wgrad_split_m(a, &m1)) {
     gad_gemm_args lo, hi;
@@ -2714,15 +2917,42 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
   if (WinoPlan wp; use_wino(a, &wp)) {
-    GAD_CHECK(a->wino_ws && a->wino_ws_bytes >= wp.bytes && gad_aligned16(a->wino_ws) && gad_aligned16(a->B_wino),
+    GAD_CHECK(a->wino_ws && a->wino_ws_bytes >= wp.bytes && gad_aligned16(a->wino_ws) && gad_aligned16(wp.f == 2 ? a->B_wino : a->B_wino4),
               "gad_gemm: Winograd workspace too small or misaligned (%lld < %lld)", (long long)a->wino_ws_bytes, (long long)wp.bytes);
     const gad_conv_geom& g = a->g;
     WinoIn wi;
     wi.x = a->A; wi.V = (float*)a->wino_ws;
     wi.H = g.H; wi.W = g.W; wi.C = g.C; wi.ldx = g.ldx; wi.up = g.upsample ? 1 : 0;
-    wi.TH = g.Ho / 2; wi.TW = g.Wo / 2; wi.T = wp.T;
+    wi.TH = g.Ho / wp.f; wi.TW = g.Wo / wp.f; wi.T = wp.T;
     const long items = wp.T * (g.C / 4);
     GAD_CHECK(gad_ceil_div(items, 256) < (1L << 31), "gad_gemm: Winograd input transform grid too large");
+    if (wp.f == 4) {
+      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
+      GAD_LAUNCH_CHECK("gad_gemm(winograd F4 input transform)");
+      float* Mb = wi.V + 36 * wp.T * (long)g.C;
+      gad_gemm_args sub = *a;
+      sub.A = wi.V; sub.B = a->B_wino4; sub.C = Mb;
+      sub.B_wino = nullptr; sub.B_wino4 = nullptr; sub.wino_ws = nullptr; sub.wino_ws_bytes = 0;
+      sub.a_mode = GAD_A_KC; sub.b_mode = GAD_B_KC;
+      sub.M = (int32_t)wp.T; sub.N = a->N; sub.K = g.C;
+      sub.lda = g.C; sub.ldb = g.C; sub.ldc = a->N;
+      sub.batch = 36; sub.batch_inner = 1;
+      sub.strideA0 = wp.T * (int64_t)g.C; sub.strideA1 = 0;
+      sub.strideB0 = (int64_t)a->N * g.C; sub.strideB1 = 0;
+      sub.strideC0 = wp.T * (int64_t)a->N; sub.strideC1 = 0;
+      sub.alpha = 1.f; sub.bias = nullptr; sub.rowadd = nullptr; sub.residual = nullptr;
+      sub.tile_hint = 0; sub.splitk_hint = 0;
+      sub.flags = GAD_GEMM_INTERNAL_WINO4;
+      if (const int rc = gad_gemm(&sub, stream)) return rc;
+      WinoOut wo;
+      wo.Mb = Mb; wo.y = a->C; wo.bias = a->bias; wo.rowadd = a->rowadd; wo.residual = a->residual;
+      wo.N = a->N; wo.ldc = a->ldc; wo.ldr = a->ldr; wo.ld_rowadd = a->ld_rowadd;
+      wo.Ho = g.Ho; wo.Wo = g.Wo; wo.TH = wi.TH; wo.TW = wi.TW; wo.T = wp.T; wo.alpha = a->alpha;
+      const long oitems = wp.T * (a->N / 4);
+      hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)gad_ceil_div(oitems, 256)), dim3(256), 0, st, wo);
+      GAD_LAUNCH_CHECK("gad_gemm(winograd F4 output transform)");
+      return 0;
+    }
     hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
     GAD_LAUNCH_CHECK("gad_gemm(winograd input transform)");
     DevArgs w = d;
@@ -2868,7 +3098,10 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       if (am == GAD_A_KC && bmode == GAD_B_KC) launch_bf16<A_KC_L, B_KC_L>(d, pl, st);
       else if (am == GAD_A_KC) launch_bf16<A_KC_L, B_MC_L>(d, pl, st);
       else launch_bf16<A_MC_L, B_MC_L>(d, pl, st);
-    } else if (am == GAD_A_KC && bmode == GAD_B_KC) launch_mode<A_KC_L, B_KC_L, 4>(d, pl, st);
+    } else if (am == GAD_A_KC && bmode == GAD_B_KC) {
+      if (a->flags & GAD_GEMM_INTERNAL_WINO4) launch_mode<A_KC_L, B_KC_L, 4, 1>(d, pl, st);
+      else launch_mode<A_KC_L, B_KC_L, 4>(d, pl, st);
+    }
     else if (am == GAD_A_KC) launch_mode<A_KC_L, B_MC_L, 4>(d, pl, st);
     else launch_mode<A_MC_L, B_MC_L, 4>(d, pl, st);
   } else

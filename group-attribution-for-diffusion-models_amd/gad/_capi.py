@@ -37,7 +37,7 @@ class GemmArgs(C.Structure):
                 ("A2", C.c_void_p), ("a_split", C.c_int32), ("ldx2", C.c_int32), ("B_bf16", C.c_void_p),
                 ("A_k2", C.c_void_p), ("B_k2", C.c_void_p), ("lda_k2", C.c_int32), ("ldb_k2", C.c_int32),
                 ("k_split", C.c_int32), ("flags", C.c_int32),
-                ("B_wino", C.c_void_p), ("wino_ws", C.c_void_p), ("wino_ws_bytes", C.c_int64)]
+                ("B_wino", C.c_void_p), ("wino_ws", C.c_void_p), ("wino_ws_bytes", C.c_int64), ("B_wino4", C.c_void_p)]
 
 
 class GroupNormArgs(C.Structure):
@@ -88,6 +88,7 @@ SIGNATURES = {
     "gad_gemm_kernel_id": (C.c_int, [C.POINTER(GemmArgs)]),
     "gad_gemm_wino_bytes": (_i64, [C.POINTER(GemmArgs)]),
     "gad_wino_weights": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gad_wino4_weights": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "gad_groupnorm_one_pass": (C.c_int, [C.POINTER(GroupNormArgs)]),
     "gad_gemm_plan": (C.c_int, [C.POINTER(GemmArgs), C.POINTER(_i32), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),

@@ -140,7 +140,7 @@ def set_operand_precision(name):
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
 # structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
-KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False, "narrow_attn_fwd": False}
+KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False, "narrow_attn_fwd": False, "no_wino4": False}
 
 
 class kernel_flags:
@@ -149,8 +149,8 @@ class kernel_flags:
     rotated weights, see `dgrad_as_forward`)"""
 
     def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
-                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False, no_wino=False):
-        self.native_dgrad, self.two_kernel_attn_bwd, self.narrow_attn_fwd = native_dgrad, two_kernel_attn_bwd, narrow_attn_fwd
+                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False, no_wino=False, no_wino4=False):
+        self.native_dgrad, self.two_kernel_attn_bwd, self.narrow_attn_fwd, self.no_wino4 = native_dgrad, two_kernel_attn_bwd, narrow_attn_fwd, no_wino4
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
                      | (_capi.GEMM_NO_WINO if no_wino else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
@@ -161,6 +161,7 @@ class kernel_flags:
         self.prev = dict(KERNEL_FLAGS)
         KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"], KERNEL_FLAGS["native_dgrad"] = self.gemm, self.gn, self.native_dgrad
         KERNEL_FLAGS["two_kernel_attn_bwd"], KERNEL_FLAGS["narrow_attn_fwd"] = self.two_kernel_attn_bwd, self.narrow_attn_fwd
+        KERNEL_FLAGS["no_wino4"] = self.no_wino4
         return self
 
     def __exit__(self, *exc):
@@ -171,7 +172,7 @@ class kernel_flags:
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0, B_wino=None):
+             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -201,14 +202,14 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     if A_k2 is not None:            # K-concatenated operands (fused LoRA): k >= k_split reads A_k2 / B_k2
         a.A_k2, a.B_k2, a.k_split = A_k2.data_ptr(), B_k2.data_ptr(), k_split
         a.lda_k2, a.ldb_k2 = A_k2.shape[-1], B_k2.shape[-1]
-    if B_wino is not None:          # Winograd route: the planner says whether this launch takes it and how much scratch V needs
-        a.B_wino = B_wino.data_ptr()
+    if B_wino is not None or B_wino4 is not None:      # Winograd routes: the planner says whether this launch takes one and how much scratch it needs
+        a.B_wino, a.B_wino4 = _ptr(B_wino), _ptr(B_wino4)
         need = lib.gad_gemm_wino_bytes(C.byref(a))
         if need:
             V = torch.empty(need, dtype=torch.uint8, device=A.device)      # stream-ordered: safe to drop after the launch
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
         else:
-            a.B_wino = None
+            a.B_wino = a.B_wino4 = None
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -232,7 +233,7 @@ class GemmProfiler:
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
-        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino")[kid]   # (the Winograd kernels are one instance for every map width)
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino", "_wino4")[kid]   # (the Winograd kernels are one instance for every map width)
         if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)
@@ -303,11 +304,16 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     g = ConvGeom(H, W, Cin, C1, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     if residual is not None:
         _req(residual, "conv residual")
+    # Winograd forms of the weight: F(4x4) wherever the output map is a multiple of 4 (it measured faster than F(2x2) at every
+    # shape of tools/ab_winograd.py), F(2x2) for the other even maps; the library's planner still decides per launch
+    wino_ok = (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7, 8) and splitk_hint == 0
+               and tuple(pad) == (1, 1, 1, 1))
+    f4_maps = Ho % 4 == 0 and Wo % 4 == 0 and not KERNEL_FLAGS.get("no_wino4")
     gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
              tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
-             B_wino=wino_weight(w) if (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7)
-                                       and splitk_hint == 0 and tuple(pad) == (1, 1, 1, 1)) else None,
+             B_wino=wino_weight(w, 2) if (wino_ok and (tile_hint == 7 or (tile_hint == 0 and not f4_maps))) else None,
+             B_wino4=wino_weight(w, 4) if (wino_ok and tile_hint != 7 and f4_maps) else None,
              B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
                                        and not torch.cuda.is_current_stream_capturing()) else None)
     return y
@@ -425,58 +431,61 @@ def _wino_ok(co, ci):
     return ci % 32 == 0 and co % 4 == 0 and co >= 64
 
 
-def _wino_transform(src, items):
-    """items [(src offset, Cout, Cin)] -> (U buffer, {src offset: (dst offset, floats)}, table, tiles)"""
+def _wino_transform(src, items, npos):
+    """items [(src offset, Cout, Cin)] -> (U buffer, {src offset: (dst offset, floats)}, table, tiles); npos = 16 or 36"""
     rows, where, doff = [], {}, 0
     for off, co, ci in items:
-        where[off] = (doff, 16 * co * ci)
+        where[off] = (doff, npos * co * ci)
         rows += [(off, doff, co, ci, a, b) for a in range(0, co, 32) for b in range(0, ci, 32)]
-        doff += 16 * co * ci
+        doff += npos * co * ci
     U = torch.empty(max(doff, 1), device=src.device, dtype=torch.float32)
     table = torch.tensor(rows, dtype=torch.int64, device=src.device)
     return U, where, table, len(rows)
 
 
-def wino_weight(w):
-    """U[16][Cout][Cin] = G w G^T, the Winograd F(2x2, 3x3) form of a 3x3 conv weight (`gad_wino_weights`), or None for a
-    weight the Winograd kernels do not take (Cin % 32, Cout % 4, < 64 output channels, bf16-operand mode, the no_wino
-    switch).  A weight living in a flat parameter buffer - or in the rotated shadow of one, for the data gradients - is
-    served from ONE transformed shadow of that buffer, refreshed by a single launch when the weights changed (the keys of
-    `bf16_weight`); any other weight caches its own transform per version."""
+def wino_weight(w, f=2):
+    """The Winograd form U = G w G^T of a 3x3 conv weight: [16][Cout][Cin] for F(2x2, 3x3) (`gad_wino_weights`, f = 2) or
+    [36][Cout][Cin] for F(4x4, 3x3) (`gad_wino4_weights`, f = 4); None for a weight the Winograd kernels do not take
+    (Cin % 32, Cout % 4, < 64 output channels, bf16-operand mode, the no_wino switch).  A weight living in a flat parameter
+    buffer - or in the rotated shadow of one, for the data gradients - is served from ONE transformed shadow of that buffer
+    per form, refreshed by a single launch when the weights changed (the keys of `bf16_weight`); any other weight caches its
+    own transform per version."""
     co, ci = w.shape[0], w.shape[1]
     if (tuple(w.shape[2:]) != (3, 3) or not _wino_ok(co, ci) or OPERAND_PRECISION[0] == 1
-            or KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K)):
+            or KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K)
+            or (f == 4 and KERNEL_FLAGS.get("no_wino4"))):
         return None
     lib = _capi.load()
+    launch, npos, attr = (lib.gad_wino_weights, 16, "_gad_wino") if f == 2 else (lib.gad_wino4_weights, 36, "_gad_wino4")
     if _in_flat_buffer(w):
         flat, off, n = w._gad_flat
         key = (flat._version, WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
-        cached = getattr(flat, "_gad_wino", None)
+        cached = getattr(flat, attr, None)
         if cached is None:
             items = [(o_, a, b) for o_, a, b in _conv3x3_residents(flat) if _wino_ok(a, b)]
-            cached = [None, *_wino_transform(flat, items), {}]
-            flat._gad_wino = cached
+            cached = [None, *_wino_transform(flat, items, npos), {}]
+            setattr(flat, attr, cached)
         _, U, where, table, tiles, versions = cached
         if off not in where:
             return None
         stale = cached[0] != key or versions.get(off, w._version) != w._version
         if stale:
-            check(lib.gad_wino_weights(flat.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
+            check(launch(flat.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
             cached[0] = key
             cached[5] = {o_: p_._version for p_, o_, _ in getattr(flat, "_gad_params", ())}
         d0, dn = where[off]
         return U[d0:d0 + dn]
     key = weight_key(w)
-    cached = getattr(w, "_gad_wino", None)
+    cached = getattr(w, attr, None)
     if cached is None or cached[0] != key:
         src = weight_krsc(w).detach()
         if cached is None:
-            U, _, table, tiles = _wino_transform(src, [(0, co, ci)])
+            U, _, table, tiles = _wino_transform(src, [(0, co, ci)], npos)
         else:
             U, table, tiles = cached[1], cached[2], cached[3]
-        check(lib.gad_wino_weights(src.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
+        check(launch(src.data_ptr(), U.data_ptr(), table.data_ptr(), tiles, _stream()), "gad_wino_weights")
         cached = (key, U, table, tiles)
-        w._gad_wino = cached
+        setattr(w, attr, cached)
     return cached[1]
 
 
@@ -485,7 +494,10 @@ def refresh_wino(module):
     launches read the shadow at a fixed address but cannot notice that the weights moved since the capture."""
     for p in module.parameters():
         if p.ndim == 4 and tuple(p.shape[2:]) == (3, 3):
-            wino_weight(p)
+            home = p._gad_flat[0] if _in_flat_buffer(p) else p
+            for f, attr in ((2, "_gad_wino"), (4, "_gad_wino4")):
+                if getattr(home, attr, None) is not None:            # a shadow some launch has used
+                    wino_weight(p, f)
 
 
 def two_source_ok(c1: int, c2: int) -> bool:

@@ -81,8 +81,8 @@ typedef struct gad_gemm_args {
   /* split-K workspace (caller owned). ws_bytes >= gad_gemm_workspace_bytes(args)            */
   void* ws;
   int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms); 7 = a forward 3x3 convolution
-                             * with B_wino takes the Winograd route whatever the planner models (tests, A/B tools); 3x3 weight gradient:
+  int32_t tile_hint;        /* 0 = auto, 1 = force 128x128, 2 = force 64x64, 3 = 128x64 (dense fp32 forms); 7 / 8 = a forward 3x3 convolution
+                             * with B_wino / B_wino4 takes the F(2x2) / F(4x4) Winograd route whatever the planner models (tests, A/B tools); 3x3 weight gradient:
                              * 1 / 4 / 5 / 6 = 128 / 96 / 64 / 32 output channels per tile, 1000 + m1 = rows [0, m1) on 128-channel
                              * tiles and the rest planned, as a second launch (A/B tools) */
   int32_t splitk_hint;      /* 0 = auto, >0 = force                                          */
@@ -125,6 +125,12 @@ typedef struct gad_gemm_args {
   const float* B_wino;
   void* wino_ws;
   int64_t wino_ws_bytes;
+  /* the F(4x4, 3x3) form of the same route (output maps that are multiples of 4): B_wino4 = U[36][Cout][Cin] made by
+   * gad_wino4_weights.  With both forms given the planner takes whichever models fastest (or neither); wino_ws then holds the
+   * transformed input AND the 36 product panels (gad_gemm_wino_bytes covers both), ws may be needed for a split of the batched
+   * products (gad_gemm_workspace_bytes as usual).  4x fewer multiplies than the direct form; about one decimal digit less
+   * accurate than the direct fp32 kernels (still ~4e-6 of the output scale). */
+  const float* B_wino4;
 } gad_gemm_args;
 enum gad_gemm_flags {
   GAD_GEMM_NO_WINO = 16,      /* never take the Winograd route even when B_wino is given                              */
@@ -145,7 +151,7 @@ int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would mult
  * 2 conv3x3_patch_f32_kernel / wgrad3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 convs whose
  * 128-pixel tiles are whole image rows: input patch resident in LDS), 4 conv3x3_fewout_kernel (<= 4 output channels:
  * vector ALUs, weights through the scalar cache) */
-int gad_gemm_kernel_id(const gad_gemm_args* a);   /* ... 5 wino_input_kernel + wino_gemm_kernel (Winograd F(2x2, 3x3)) */
+int gad_gemm_kernel_id(const gad_gemm_args* a);   /* ... 5 wino_input_kernel + wino_gemm_kernel (Winograd F(2x2, 3x3)), 6 wino4_input_kernel + batched gemm_kernel + wino4_output_kernel (F(4x4, 3x3)) */
 /* bytes of wino_ws the Winograd route of gad_gemm(a) needs; 0 when gad_gemm(a) runs a direct kernel (set B_wino first) */
 int64_t gad_gemm_wino_bytes(const gad_gemm_args* a);
 /* Winograd weight transform U = G w G^T for the 3x3 weights listed in `table`: n_tiles rows of six int64
@@ -153,6 +159,8 @@ int64_t gad_gemm_wino_bytes(const gad_gemm_args* a);
  * src storage [Cout][3][3][Cin] (diffusers Conv2d weight in channels_last: ResnetBlock2D.conv1/conv2, Up/Downsample2D.conv,
  * SURVEY Appendix A), dst storage [16][Cout][Cin].  One launch transforms every 3x3 weight of a flat parameter buffer. */
 int gad_wino_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream);
+/* the same for F(4x4, 3x3): dst storage [36][Cout][Cin] */
+int gad_wino4_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream);
 
 /* ------------------------------------------------------------------------------
  * GroupNorm (+ optional SiLU), NHWC.  Replaces ATen native_group_norm + SiLU in

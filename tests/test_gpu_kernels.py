@@ -223,19 +223,24 @@ WINO_CASES = [
     (8, 64, 128, 32, 32, False, True),         # 64 tiles x 128 channels
     (6, 96, 192, 16, 16, False, True),         # pruned widths: 128 tiles x 64 channels
     (3, 256, 256, 8, 8, True, True),           # behind the fused nearest-2x upsample
-    (5, 32, 68, 34, 30, False, True),          # tiles per image / per row not powers of two, tile rows and channels ragged
+    (5, 32, 68, 34, 30, False, True),          # tiles per image / per row not powers of two, ragged channels; F(2x2) only (30 % 4)
+    (2, 96, 68, 20, 12, False, True),          # the same for 4x4 tiles
     (4, 128, 320, 16, 16, False, False),       # SD width, no epilogue terms
     (1, 64, 1024, 64, 64, False, True),        # one image, many channel blocks
-    (1, 32, 64, 2, 2, False, True),            # a single tile
+    (1, 32, 64, 4, 4, False, True),            # a single 4x4 tile / four 2x2 tiles
 ]
 
 
+@pytest.mark.parametrize("form", [2, 4])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ups,epi", WINO_CASES)
-def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi):
-    """Winograd F(2x2, 3x3) route (wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U = G w G^T; tile_hint 7 forces
-    it whatever the launch size) against fp64 - with bias, the time-embedding row and the residual in its epilogue - and
-    against the direct kernels on the same inputs: same tolerance as every fp32 contraction, not bit-identical (the
-    transforms round), deterministic."""
+def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi, form):
+    """Winograd routes against fp64 - with bias, the time-embedding row and the residual in the epilogue - and against the
+    direct kernels on the same inputs.  F(2x2, 3x3): wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U (tile_hint 7
+    forces it); F(4x4, 3x3): wino4_input_kernel + 36 batched products on the generic engine + wino4_output_kernel on
+    gad_wino4_weights' U (tile_hint 8).  Same tolerance as every fp32 contraction (F(4x4) measures ~4e-6 of the output scale,
+    a decimal digit more than the direct kernels), not bit-identical, deterministic."""
+    if form == 4 and ((H * (2 if ups else 1)) % 4 or (W * (2 if ups else 1)) % 4):
+        pytest.skip("F(4x4) needs output maps that are multiples of 4")
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(Cin * 9)), rnd(Cout, seed=3)
     want = conv_ref(x, w, b if epi else None, 1, (1, 1, 1, 1), ups)
     temb, res = rnd(B, Cout, seed=4), rnd(*want.shape, seed=5)
@@ -243,37 +248,39 @@ def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi):
         want = want + temb.double()[:, :, None, None] + res.double()
     kw = dict(rowadd=temb.to(dev), residual=nhwc(res)) if epi else {}
     xg, wg, bg = nhwc(x), cl_weight(w), b.to(dev) if epi else None
+    hint = 7 if form == 2 else 8
     ops.PROFILER = prof = ops.GemmProfiler()
     try:
-        y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw)
+        y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw)
         torch.cuda.synchronize()
     finally:
         ops.PROFILER = None
-    assert [k[0] for k in prof.summary()] == ["conv_fwd_wino"], list(prof.summary())
-    y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw)
+    assert [k[0] for k in prof.summary()] == ["conv_fwd_wino" if form == 2 else "conv_fwd_wino4"], list(prof.summary())
+    y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw)
     close(y.permute(0, 3, 1, 2), want, atol=3e-5)
     with ops.kernel_flags(no_wino=True):
         y0 = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, **kw)
     assert not torch.equal(y, y0)
     close(y, y0, rtol=3e-5, atol=3e-5)
-    assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=7, **kw))        # deterministic
+    assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw))        # deterministic
 
 
 def test_winograd_planner_takes_the_large_launches(ops):
-    """The planner's modelled times (input transform + ceil(blocks / 256) block times against the direct plan's rounds): the
-    sampler's and the trainer's big 3x3 launches go to the Winograd route, small maps at small batch stay direct."""
-    def route(B, H, Cin, Cout):
-        x, w = torch.zeros(B, H, H, Cin, device=dev), cl_weight(rnd(Cout, Cin, 3, 3, seed=2, scale=0.05))
+    """The planner's modelled times against the direct plan's: maps that are multiples of 4 go to F(4x4) down to small
+    launches, other even maps to F(2x2) when the launch is large, tiny launches stay direct."""
+    def route(B, H, W, Cin, Cout):
+        x, w = torch.zeros(B, H, W, Cin, device=dev), cl_weight(rnd(Cout, Cin, 3, 3, seed=2, scale=0.05))
         ops.PROFILER = prof = ops.GemmProfiler()
         try:
             ops.conv2d_fwd_raw(x, w, None)
             torch.cuda.synchronize()
         finally:
             ops.PROFILER = None
-        return ["wino" if "wino" in k[0] else "direct" for k in prof.summary()]
-    assert route(128, 32, 128, 128) == ["wino"] and route(128, 16, 256, 256) == ["wino"] and route(1024, 8, 256, 256) == ["wino"]
-    assert route(16, 64, 320, 320) == ["wino"] and route(32, 32, 448, 448) == ["wino"]
-    assert route(128, 8, 256, 256) == ["direct"] and route(16, 8, 1280, 1280) == ["direct"] and route(128, 4, 256, 256) == ["direct"]
+        return [k[0].replace("conv_fwd_", "").split("_")[0] for k in prof.summary()]
+    assert route(128, 32, 32, 128, 128) == ["wino4"] and route(128, 16, 16, 256, 256) == ["wino4"] and route(1024, 8, 8, 256, 256) == ["wino4"]
+    assert route(16, 64, 64, 320, 320) == ["wino4"] and route(16, 8, 8, 1280, 1280) == ["wino4"] and route(128, 8, 8, 256, 256) == ["wino4"]
+    assert route(128, 34, 30, 128, 128) == ["wino"]
+    assert route(1, 8, 8, 64, 64)[0] not in ("wino", "wino4") and route(2, 18, 18, 64, 64)[0] not in ("wino", "wino4")
 
 
 def test_winograd_is_not_taken_where_it_does_not_apply(ops):
@@ -330,12 +337,13 @@ def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
             w.grad = None
 
     check_all()
-    U = flat._gad_wino[1]
-    assert ws[3]._gad_flat[1] not in flat._gad_wino[2]                          # Cin = 3: not transformed
-    d0, dn = flat._gad_wino[2][ws[1]._gad_flat[1]]
-    G = torch.tensor([[1, 0, 0], [.5, .5, .5], [.5, -.5, .5], [0, 0, 1]], dtype=torch.float64)
-    want = torch.einsum("ar,orsi,bs->aboi", G, ops.weight_krsc(ws[1]).detach().double().cpu(), G).reshape(16, 256, 128)
-    close(U[d0:d0 + dn].view(16, 256, 128), want, rtol=1e-6, atol=1e-6)
+    U = flat._gad_wino4[1]                                                      # 32 x 32 maps: the F(4x4) form
+    assert ws[3]._gad_flat[1] not in flat._gad_wino4[2]                         # Cin = 3: not transformed
+    d0, dn = flat._gad_wino4[2][ws[1]._gad_flat[1]]
+    G = torch.tensor([[1 / 4, 0, 0], [-1 / 6, -1 / 6, -1 / 6], [-1 / 6, 1 / 6, -1 / 6], [1 / 24, 1 / 12, 1 / 6], [1 / 24, -1 / 12, 1 / 6],
+                      [0, 0, 1]], dtype=torch.float64)
+    want = torch.einsum("ar,orsi,bs->aboi", G, ops.weight_krsc(ws[1]).detach().double().cpu(), G).reshape(36, 256, 128)
+    close(U[d0:d0 + dn].view(36, 256, 128), want, rtol=1e-6, atol=1e-6)
     with torch.no_grad():
         flat.detach().mul_(1.5)
     flat._gad_epoch = getattr(flat, "_gad_epoch", 0) + 1
@@ -343,7 +351,7 @@ def test_winograd_shadow_of_a_flat_buffer_follows_the_weights(ops):
     with torch.no_grad():
         ws[2].copy_(ws[2] * 0.25)
     check_all()
-    assert flat._gad_wino[1] is U
+    assert flat._gad_wino4[1] is U
 
 
 def test_conv_autograd_function(ops):

@@ -34,14 +34,13 @@ for B, H, Cin, Cout in SHAPES:
     ops.conv2d_fwd_raw(x, w, b)
     torch.cuda.synchronize()
     ops.PROFILER = None
-    took = "winograd" if any("wino" in k[0] for k in prof.summary()) else "direct  "
+    took = "F(4x4)  " if any("wino4" in k[0] for k in prof.summary()) else ("F(2x2)  " if any("wino" in k[0] for k in prof.summary()) else "direct  ")
     t1 = ev(lambda: ops.conv2d_fwd_raw(x, w, b))
     with ops.kernel_flags(no_wino=True):
         t0 = ev(lambda: ops.conv2d_fwd_raw(x, w, b))
     fl = 2.0 * B * H * H * Cout * 9 * Cin
-    forced = ""
-    if took.startswith("direct"):
-        tf = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=7))
-        forced = f" | forced winograd {tf:7.3f} ms (x{t0 / tf:.2f})"
+    t2 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=7))
+    t4 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=8)) if H % 4 == 0 else float("nan")
+    forced = f" | forced F(2x2) {t2:7.3f} ms (x{t0 / t2:.2f}) F(4x4) {t4:7.3f} ms (x{t0 / t4:.2f})"
     print(f"B{B:5d} {H:2d}x{H:<2d} {Cin:4d}->{Cout:<4d}: planner {took} {t1:7.3f} ms ({fl / t1 / 1e9:6.1f} TF/s) | direct kernels {t0:7.3f} ms "
           f"({fl / t0 / 1e9:6.1f} TF/s) | x{t0 / t1:.2f}" + forced, flush=True)
