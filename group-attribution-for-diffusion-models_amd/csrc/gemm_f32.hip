@@ -2102,6 +2102,134 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino_gemm_kernel(const DevArgs p)
   for (int q = 0; q < 4; ++q) store_block_wino<TM, TN, BM, BN>(p, Y[q], row0, col0, wm, wn, h, l31, q >> 1, q & 1, scratch);
 }
 
+// F(4x4, 3x3) products with the output transform's nu direction folded in: block (xi, tile_m, tile_n) runs the SIX products
+// M[xi][nu] = V[6 xi + nu] U[6 xi + nu]^T of its tile back to back as one K loop and folds each finished product block into four
+// accumulators with A^T's column nu ([1 0 0 0], [1 1 1 1], [1 -1 1 -1], [1 2 4 8], [1 -2 4 -8], [0 0 0 1]), then stores
+// Mh[4 xi + j][tile][n] raw: 24 values per tile and channel reach memory instead of 36, one pipeline prologue serves six products.
+// p.A = V [36][T][Cin] (p.sA0 = T Cin), p.B = U [36][Cout][Cin] (p.sB0 = Cout Cin), p.C = Mh [24][T][Cout] (p.sC0 = T Cout), p.M = T, p.N = Cout, p.K = Cin
+template <int BM, int BN>
+__global__ __launch_bounds__(NTHREADS, 2) void wino4_gemm_kernel(const DevArgs p) {
+  constexpr int TM = BM / 64, TN = BN / 64;
+  using AL = WinoKC<BM>;
+  using BL = WinoKC<BN>;
+  constexpr int A_TILE = BK * BM;
+  constexpr int B_TILE = BK * BN;
+  __shared__ __attribute__((aligned(16))) float lds[2 * (A_TILE + B_TILE)];
+
+  const int t0 = xcd_remap(blockIdx.x, gridDim.x);
+  const int per_xi = p.tiles_m * p.tiles_n;
+  const int xi6 = t0 / per_xi, t = t0 - xi6 * per_xi;          // xi slowest: neighbouring blocks share the V rows / U panel
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int kc = p.K / BK;                       // K steps per position
+  const int nsteps = 6 * kc;
+  const int pos0 = 6 * xi6;
+
+  AL al;
+  BL bl;
+  al.init(p.A, p.lda, row0, p.M);
+  bl.init(p.B, p.ldb, col0, p.N);
+  al.off = (long)pos0 * p.sA0;
+  bl.off = (long)pos0 * p.sB0;
+
+  const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
+  const int wm = wave >> 1, wn = wave & 1, h = lane >> 5, l31 = lane & 31;
+
+  f32x16 acc[TM][TN], Y[4][TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) {
+        acc[i][j][e] = 0.f;
+#pragma unroll
+        for (int q = 0; q < 4; ++q) Y[q][i][j][e] = 0.f;
+      }
+
+  auto stage_slot = [&](int piece, float* ta, float* tb) {
+    constexpr int NSA = AL::NS, NSB = BL::NS;
+    if (piece < NSA) glds16(al.src(piece), AL::dma_dst(ta, piece));
+    else if (piece < NSA + NSB) glds16(bl.src(piece - NSA), BL::dma_dst(tb, piece - NSA));
+  };
+#pragma unroll
+  for (int q = 0; q < AL::NS + BL::NS; ++q) stage_slot(q, lds, lds + A_TILE);
+  barrier_after_dma();
+
+  int pos = 0, kk = 0;                           // position and K step of the step being multiplied
+  for (int s = 0; s < nsteps; ++s) {
+    float* cur = lds + (s & 1) * (A_TILE + B_TILE);
+    float* nxt = lds + ((s + 1) & 1) * (A_TILE + B_TILE);
+    const float* la = cur;
+    const float* lb = cur + A_TILE;
+    {                                            // offsets of step s + 1 (the step past the end re-reads the last one)
+      int pn = pos, kn = kk + 1;
+      if (kn == kc) { kn = 0; ++pn; }
+      if (pn == 6) { pn = 5; kn = kc - 1; }
+      al.off = (long)(pos0 + pn) * p.sA0 + kn * BK;
+      bl.off = (long)(pos0 + pn) * p.sB0 + kn * BK;
+    }
+    f32x4 fa[2][TM], fb[2][TN];
+#pragma unroll
+    for (int i = 0; i < TM; ++i) fa[0][i] = read_frag<true, BM>(la, wm * (BM / 2) + i * 32 + l31, 0, h);
+#pragma unroll
+    for (int j = 0; j < TN; ++j) fb[0][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, 0, h);
+#pragma unroll
+    for (int g = 0; g < 4; ++g) {
+#pragma unroll
+      for (int q4 = 0; q4 < 4; ++q4) {
+#pragma unroll
+        for (int i = 0; i < TM; ++i)
+#pragma unroll
+          for (int j = 0; j < TN; ++j)
+            acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x2f32(fa[g & 1][i][q4], fb[g & 1][j][q4], acc[i][j], 0, 0, 0);
+        stage_slot(g * 4 + q4, nxt, nxt + A_TILE);
+        if (q4 == 1 && g < 3) {
+#pragma unroll
+          for (int i = 0; i < TM; ++i) fa[(g + 1) & 1][i] = read_frag<true, BM>(la, wm * (BM / 2) + i * 32 + l31, g + 1, h);
+#pragma unroll
+          for (int j = 0; j < TN; ++j) fb[(g + 1) & 1][j] = read_frag<true, BN>(lb, wn * (BN / 2) + j * 32 + l31, g + 1, h);
+        }
+#pragma unroll
+        for (int q = 0; q < TM * TN; ++q) {
+          __builtin_amdgcn_sched_group_barrier(0x008, 1, 0);
+          __builtin_amdgcn_sched_group_barrier(0x002, 7, 0);
+        }
+        __builtin_amdgcn_sched_barrier(0);
+      }
+    }
+    if (++kk == kc) {                            // position done: fold its product block into the four output pixels
+      // A^T column of nu = pos: [1 0 0 0], [1 1 1 1], [1 -1 1 -1], [1 2 4 8], [1 -2 4 -8], [0 0 0 1]
+      const float sg = (pos == 2 || pos == 4) ? -1.f : 1.f, two = pos >= 3 ? 2.f : 1.f;
+      const float w00 = pos == 5 ? 0.f : 1.f;
+      const float w01 = (pos == 0 || pos == 5) ? 0.f : sg * two;
+      const float w10 = (pos == 0 || pos == 5) ? 0.f : two * two;
+      const float w11 = pos == 0 ? 0.f : (pos == 5 ? 1.f : sg * two * two * two);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j)
+#pragma unroll
+          for (int e = 0; e < 16; ++e) {
+            const float a = acc[i][j][e];
+            Y[0][i][j][e] = __builtin_fmaf(w00, a, Y[0][i][j][e]);
+            Y[1][i][j][e] = __builtin_fmaf(w01, a, Y[1][i][j][e]);
+            Y[2][i][j][e] = __builtin_fmaf(w10, a, Y[2][i][j][e]);
+            Y[3][i][j][e] = __builtin_fmaf(w11, a, Y[3][i][j][e]);
+            acc[i][j][e] = 0.f;
+          }
+      kk = 0;
+      ++pos;
+    }
+    barrier_after_dma();
+  }
+
+  float* scratch = lds + (tid >> 6) * EPI_WAVE;
+#pragma unroll
+  for (int q = 0; q < 4; ++q)
+    store_block<TM, TN, BM, BN>(p, Y[q], row0, col0, wm, wn, h, l31, p.C + (long)(4 * xi6 + q) * p.sC0, p.N, nullptr, false, scratch);
+}
+
 // ------------------------------------------------------------------------------------
 // Winograd F(4x4, 3x3): 36 multiplies per 4x4 output tile and channel pair instead of 144 (4x fewer MFMA FLOPs) and a
 // transformed input of only 2.25x the input.  Sixteen output-pixel accumulator sets do not fit a wave, so the element-wise
@@ -2221,6 +2349,8 @@ __device__ __forceinline__ void wino4_at(const f32x4 (&m)[6], f32x4 (&y)[4]) {
   y[3] = d12 + 8.f * d34 + m[5];
 }
 
+// half = true: Mb holds the 24 half-transformed panels Mh[4 xi + j] of wino4_gemm_kernel (nu direction already folded)
+template <bool HALF>
 __global__ __launch_bounds__(256) void wino4_output_kernel(const WinoOut p) {
   const int N4 = p.N >> 2;
   const long idx = (long)blockIdx.x * 256 + threadIdx.x;
@@ -2233,12 +2363,12 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const WinoOut p) {
   const int ty = r / p.TW, tx = r - ty * p.TW;
   const long pos_stride = p.T * p.N;
   const float* src = p.Mb + tile * p.N + n;
-  f32x4 t[4][6];                                 // t[i][nu] = (A^T M)[i][nu]
+  f32x4 t[4][HALF ? 4 : 6];                      // t[i][nu] = (A^T M)[i][nu]   (HALF: t[i][j] = y[i][j] already)
 #pragma unroll
-  for (int nu = 0; nu < 6; ++nu) {
+  for (int nu = 0; nu < (HALF ? 4 : 6); ++nu) {
     f32x4 m[6], col[4];
 #pragma unroll
-    for (int xi = 0; xi < 6; ++xi) m[xi] = ldg4(src + (long)(6 * xi + nu) * pos_stride);
+    for (int xi = 0; xi < 6; ++xi) m[xi] = ldg4(src + (long)((HALF ? 4 : 6) * xi + nu) * pos_stride);
     wino4_at(m, col);
 #pragma unroll
     for (int i = 0; i < 4; ++i) t[i][nu] = col[i];
@@ -2248,7 +2378,15 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const WinoOut p) {
 #pragma unroll
   for (int i = 0; i < 4; ++i) {
     f32x4 y[4];
-    wino4_at(t[i], y);
+    if constexpr (HALF) {
+#pragma unroll
+      for (int j = 0; j < 4; ++j) y[j] = t[i][j];
+    } else {
+      f32x4 row6[6];
+#pragma unroll
+      for (int j = 0; j < 6; ++j) row6[j] = t[i][HALF ? 0 : j];
+      wino4_at(row6, y);
+    }
 #pragma unroll
     for (int j = 0; j < 4; ++j) {
       const long pix = ((long)img * p.Ho + 4 * ty + i) * p.Wo + 4 * tx + j;
@@ -2623,7 +2761,8 @@ static bool as_dense_1x1(const gad_gemm_args* a, gad_gemm_args* out) {
 // fill the chip - small maps at small batch keep the direct LDS-patch kernels and their split-K.
 constexpr int GAD_GEMM_INTERNAL_WINO4 = 1 << 30;   // set by gad_gemm on its own batched sub-launch (names the kernel instance apart)
 struct WinoPlan {
-  int f;                     // 2: F(2x2,3x3) fused kernels; 4: F(4x4,3x3) through the batched engine
+  int f;                     // 2: F(2x2,3x3) fused kernels; 4: F(4x4,3x3)
+  int fused4;                // f = 4: the six-position product kernel (24 half-transformed panels) instead of 36 batched products
   int bm, bn, tiles_m, tiles_n;
   long T;                    // tiles (2x2 or 4x4 output pixels each)
   int64_t bytes;             // scratch: V (f = 2), V + M (f = 4)
@@ -2667,7 +2806,15 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   if (f4_ok) {
     p4.f = 4;
     p4.T = (long)a->M / 16;
-    const double vb = 36.0 * p4.T * g.C * 4.0, mb = 36.0 * p4.T * a->N * 4.0;
+    // large launches: the six-position product kernel (one block per (xi, 64 x 128 tile): -5..13 % at >= 1024 blocks, where the
+    // round quantisation of its one-block-per-CU rate is small); others: 36 batched products on the engine's own plan (64 x 64
+    // tiles, split K) - profiles/r03_ab_winograd.txt
+    const long pad128 = gad_ceil_div(a->N, 128) * 128, pad64 = gad_ceil_div(a->N, 64) * 64;
+    if (pad64 < pad128) { p4.bm = 128; p4.bn = 64; } else { p4.bm = 64; p4.bn = 128; }
+    p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm);
+    p4.tiles_n = (int)gad_ceil_div(a->N, p4.bn);
+    p4.fused4 = ((long)p4.tiles_m * p4.tiles_n * 6 >= 1024 && !(a->flags & GAD_GEMM_GENERAL_LOADERS)) ? 1 : 0;   // >= 4 rounds of one block per CU
+    const double vb = 36.0 * p4.T * g.C * 4.0, mb = (p4.fused4 ? 24.0 : 36.0) * p4.T * a->N * 4.0;
     p4.bytes = (int64_t)(vb + mb);
     const long blocks = gad_ceil_div(p4.T, 128) * gad_ceil_div(a->N, 128) * 36;
     const double t_gemm = (double)gad_ceil_div(blocks, 512) * (g.C / BK + 1) * (128.0 * 128.0 * BK * 2.0) / 0.254e12;
@@ -2762,7 +2909,7 @@ extern "C" int gad_wino4_weights(const float* src, float* dst, const int64_t* ta
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   GAD_CANON(a);
   if (WinoPlan wp; use_wino(a, &wp)) {
-    if (wp.f == 2) return 0;
+    if (wp.f == 2 || wp.fused4) return 0;
     gad_gemm_args sub = *a;                      // the 36 batched products may split K on small launches
     sub.B_wino = nullptr; sub.B_wino4 = nullptr;
     sub.a_mode = GAD_A_KC; sub.b_mode = GAD_B_KC;
@@ -2930,6 +3077,28 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
       GAD_LAUNCH_CHECK("gad_gemm(winograd F4 input transform)");
       float* Mb = wi.V + 36 * wp.T * (long)g.C;
+      WinoOut wo;
+      wo.Mb = Mb; wo.y = a->C; wo.bias = a->bias; wo.rowadd = a->rowadd; wo.residual = a->residual;
+      wo.N = a->N; wo.ldc = a->ldc; wo.ldr = a->ldr; wo.ld_rowadd = a->ld_rowadd;
+      wo.Ho = g.Ho; wo.Wo = g.Wo; wo.TH = wi.TH; wo.TW = wi.TW; wo.T = wp.T; wo.alpha = a->alpha;
+      const long oitems = wp.T * (a->N / 4);
+      if (wp.fused4) {
+        DevArgs w = d;
+        w.A = wi.V; w.B = a->B_wino4; w.C = Mb;
+        w.M = (int)wp.T; w.N = a->N; w.K = g.C;
+        w.lda = g.C; w.ldb = g.C; w.ldc = a->N;
+        w.sA0 = wp.T * (long)g.C; w.sB0 = (long)a->N * g.C; w.sC0 = wp.T * (long)a->N;
+        w.tiles_m = wp.tiles_m; w.tiles_n = wp.tiles_n;
+        w.splitk = 1; w.bias = nullptr; w.rowadd = nullptr; w.residual = nullptr; w.alpha = 1.f;
+        w.epi_vec = 1;                             // Mh is 16-byte aligned scratch, N % 4 == 0
+        dim3 grid((unsigned)((long)wp.tiles_m * wp.tiles_n * 6)), block(NTHREADS);
+        if (wp.bm == 64) hipLaunchKernelGGL((wino4_gemm_kernel<64, 128>), grid, block, 0, st, w);
+        else hipLaunchKernelGGL((wino4_gemm_kernel<128, 64>), grid, block, 0, st, w);
+        GAD_LAUNCH_CHECK("gad_gemm(winograd F4 products)");
+        hipLaunchKernelGGL(wino4_output_kernel<true>, dim3((unsigned)gad_ceil_div(oitems, 256)), dim3(256), 0, st, wo);
+        GAD_LAUNCH_CHECK("gad_gemm(winograd F4 output transform)");
+        return 0;
+      }
       gad_gemm_args sub = *a;
       sub.A = wi.V; sub.B = a->B_wino4; sub.C = Mb;
       sub.B_wino = nullptr; sub.B_wino4 = nullptr; sub.wino_ws = nullptr; sub.wino_ws_bytes = 0;
@@ -2944,12 +3113,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       sub.tile_hint = 0; sub.splitk_hint = 0;        // tile shapes measured within 4 % of each other here: the engine's own plan
       sub.flags = GAD_GEMM_INTERNAL_WINO4;
       if (const int rc = gad_gemm(&sub, stream)) return rc;
-      WinoOut wo;
-      wo.Mb = Mb; wo.y = a->C; wo.bias = a->bias; wo.rowadd = a->rowadd; wo.residual = a->residual;
-      wo.N = a->N; wo.ldc = a->ldc; wo.ldr = a->ldr; wo.ld_rowadd = a->ld_rowadd;
-      wo.Ho = g.Ho; wo.Wo = g.Wo; wo.TH = wi.TH; wo.TW = wi.TW; wo.T = wp.T; wo.alpha = a->alpha;
-      const long oitems = wp.T * (a->N / 4);
-      hipLaunchKernelGGL(wino4_output_kernel, dim3((unsigned)gad_ceil_div(oitems, 256)), dim3(256), 0, st, wo);
+      hipLaunchKernelGGL(wino4_output_kernel<false>, dim3((unsigned)gad_ceil_div(oitems, 256)), dim3(256), 0, st, wo);
       GAD_LAUNCH_CHECK("gad_gemm(winograd F4 output transform)");
       return 0;
     }

@@ -228,6 +228,8 @@ WINO_CASES = [
     (4, 128, 320, 16, 16, False, False),       # SD width, no epilogue terms
     (1, 64, 1024, 64, 64, False, True),        # one image, many channel blocks
     (1, 32, 64, 4, 4, False, True),            # a single 4x4 tile / four 2x2 tiles
+    (176, 64, 128, 32, 32, False, True),       # F(4x4): >= 1024 blocks -> the six-position product kernel (24 half-transformed panels)
+    (40, 96, 192, 32, 32, True, True),         #         the same on 128 x 64 blocks, behind the upsample
 ]
 
 
