@@ -375,7 +375,8 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
             tiles_ = "128- then 96-channel tiles, two launches" if dom_key[1] == 224 else f"{dom_key[1]}-channel tiles"
             kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {'128 | 96' if dom_key[1] == 224 else dom_key[1]}> ({nm}, {tiles_})"
     elif "_wino4" in nm:      # Winograd F(4x4,3x3): input transform + 36 batched products + output transform, bracketed together
-        kname = (f"wino4_input_kernel + gemm_kernel<20, 22, tile, tile, 4, 1> (36 batched products; tile 64 or 128 by the engine's plan) + wino4_output_kernel ({nm}: "
+        kname = (f"wino4_input_kernel + wino4_gemm_kernel<64, 128> / <128, 64> (six-position products; small launches: 36 batched products on "
+                 f"gemm_kernel<20, 22, tile, tile, 4, 1>) + wino4_output_kernel ({nm}: "
                  "the three launches are one convolution; time = all of them)")
     elif "_wino" in nm:       # Winograd F(2x2,3x3): input transform + the 16-position MFMA loop, bracketed together
         kname = (f"wino_input_kernel + wino_gemm_kernel<{'64, 128' if dom_key[1] == 128 else '128, 64'}> ({nm}: the pair is one "

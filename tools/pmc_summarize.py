@@ -1,5 +1,5 @@
 """Average a PMC counter over the launches of one kernel from a rocprofv3 `--pmc X --kernel-trace` run.
-usage: pmc_summarize.py <dir with *_counter_collection.csv> <kernel name substring> <counter> -> JSON on stdout.
+usage: pmc_summarize.py <dir with *_counter_collection.csv> <kernel name substring[|substring...]> <counter> -> JSON on stdout.
 Counter rows are summed per dispatch (one row per XCD / instance) and then averaged over dispatches."""
 import csv
 import glob
@@ -12,7 +12,7 @@ files = glob.glob(f"{d}/**/*counter_collection.csv", recursive=True)
 per = defaultdict(float)
 for f in files:
     for r in csv.DictReader(open(f)):
-        if kern in r["Kernel_Name"] and r["Counter_Name"] == counter:
+        if any(k in r["Kernel_Name"] for k in kern.split("|")) and r["Counter_Name"] == counter:
             per[(f, r["Dispatch_Id"])] += float(r["Counter_Value"])
 vals = list(per.values())
 print(json.dumps({"kernel": kern, "counter": counter, "launches": len(vals),

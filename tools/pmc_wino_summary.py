@@ -16,8 +16,8 @@ out = {
  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv (two SEPARATE passes, tools/prof_round.sh via "
            "tools/evidence_round.sh) -- python3 bench.py --workload cifar20 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing "
            "--no-train-rate ; tools/pmc_summarize.py, tools/pmc_wino_summary.py",
- "dominant_kernel": "wino4_input_kernel + gemm_kernel<20, 22, 64, 64, 4, 1> (36 batched products) + wino4_output_kernel (Winograd F(4x4,3x3) = "
-                    "one 3x3 convolution): every launch of the run - sampler forward at B=1024, training forward at B=128 and the data "
+ "dominant_kernel": "wino4_input_kernel + wino4_gemm_kernel<64, 128> (six-position products; small launches: 36 batched products on "
+                    "gemm_kernel<20, 22, 64, 64, 4, 1>) + wino4_output_kernel (Winograd F(4x4,3x3) = one 3x3 convolution): every launch of the run - sampler forward at B=1024, training forward at B=128 and the data "
                     "gradients on the rotated weights",
  **parts,
  "dominant_kernel_hbm_bytes_per_launch": total,
