@@ -2399,6 +2399,89 @@ __global__ __launch_bounds__(256) void wino4_output_kernel(const WinoOut p) {
   }
 }
 
+// ------------------------------------------------------------------------------------
+// Weight gradient of the same convolutions in F(4x4, 3x3) form (the transposed algorithm):
+//   dW = G^T [ sum_tiles (A dy A^T) (.) (B^T x B) ] G        per (co, ci)
+// wino4_dy_kernel transforms the 4x4 output-gradient tiles (A = (A^T)^T, 6 x 4), wino4_input_kernel the 6x6 input patches as
+// in the forward pass, the generic engine runs the 36 products [Cout x tiles] x [tiles x Cin] (K = tiles: long, split) as one
+// batched launch, wino4_dw_kernel applies G^T . G and writes the [Cout][3][3][Cin] gradient.  36 multiplies per tile and
+// channel pair instead of 144.
+// ------------------------------------------------------------------------------------
+__global__ __launch_bounds__(256) void wino4_dy_kernel(const WinoIn p) {      // p.x = dy [B][H][W][C], p.V = Wy [36][T][C]
+  const int C4 = p.C >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= p.T * C4) return;
+  const long tile = idx / C4;
+  const int c = (int)(idx - tile * C4) * 4;
+  const int per = p.TH * p.TW;
+  const int n = (int)(tile / per);
+  const int r = (int)(tile - (long)n * per);
+  const int ty = r / p.TW, tx = r - ty * p.TW;
+  const float* img = p.x + ((long)n * p.H * p.W + (long)(4 * ty) * p.W + 4 * tx) * p.ldx + c;
+  auto amul = [](const f32x4 (&d)[4], f32x4 (&t)[6]) {        // A d: [1 0 0 0; 1 1 1 1; 1 -1 1 -1; 1 2 4 8; 1 -2 4 -8; 0 0 0 1]
+    const f32x4 s02 = d[0] + d[2], s13 = d[1] + d[3], a = d[0] + 4.f * d[2], b = 2.f * d[1] + 8.f * d[3];
+    t[0] = d[0];
+    t[1] = s02 + s13;
+    t[2] = s02 - s13;
+    t[3] = a + b;
+    t[4] = a - b;
+    t[5] = d[3];
+  };
+  f32x4 t[6][4];                                 // t[i][dx] = (A d)[i][dx]
+#pragma unroll
+  for (int dx = 0; dx < 4; ++dx) {
+    f32x4 d[4], col[6];
+#pragma unroll
+    for (int dy = 0; dy < 4; ++dy) d[dy] = ldg4(img + ((long)dy * p.W + dx) * p.ldx);
+    amul(d, col);
+#pragma unroll
+    for (int i = 0; i < 6; ++i) t[i][dx] = col[i];
+  }
+  const long pos_stride = p.T * p.C;
+  float* out = p.V + tile * p.C + c;
+#pragma unroll
+  for (int i = 0; i < 6; ++i) {
+    f32x4 v[6];
+    amul(t[i], v);
+#pragma unroll
+    for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(out + (long)(6 * i + j) * pos_stride) = v[j];
+  }
+}
+
+// dW[co][r][s][ci] = (G^T dU G)[r][s] from dU [36][Cout][Cin]; one thread per (co, 4 ci)
+__global__ __launch_bounds__(256) void wino4_dw_kernel(const float* dU, float* dW, int Cout, int Cin, int ldc) {
+  const int C4 = Cin >> 2;
+  const long idx = (long)blockIdx.x * 256 + threadIdx.x;
+  if (idx >= (long)Cout * C4) return;
+  const int co = (int)(idx / C4), ci = (int)(idx - (long)co * C4) * 4;
+  const long ps = (long)Cout * Cin;
+  const float* src = dU + (long)co * Cin + ci;
+  auto gt = [](const f32x4 (&m)[6], f32x4 (&o)[3]) {          // G^T m
+    const f32x4 s12 = m[1] + m[2], d21 = m[2] - m[1], s34 = m[3] + m[4], d34 = m[3] - m[4];
+    o[0] = 0.25f * m[0] - (1.f / 6.f) * s12 + (1.f / 24.f) * s34;
+    o[1] = (1.f / 6.f) * d21 + (1.f / 12.f) * d34;
+    o[2] = (1.f / 6.f) * (s34 - s12) + m[5];
+  };
+  f32x4 t[3][6];                                 // t[r][nu] = (G^T dU)[r][nu]
+#pragma unroll
+  for (int nu = 0; nu < 6; ++nu) {
+    f32x4 m[6], col[3];
+#pragma unroll
+    for (int xi = 0; xi < 6; ++xi) m[xi] = ldg4(src + (long)(6 * xi + nu) * ps);
+    gt(m, col);
+#pragma unroll
+    for (int r = 0; r < 3; ++r) t[r][nu] = col[r];
+  }
+  float* dst = dW + (long)co * ldc + ci;
+#pragma unroll
+  for (int r = 0; r < 3; ++r) {
+    f32x4 o[3];
+    gt(t[r], o);
+#pragma unroll
+    for (int sx = 0; sx < 3; ++sx) *reinterpret_cast<f32x4*>(dst + (long)(r * 3 + sx) * Cin) = o[sx];
+  }
+}
+
 static FastDiv make_fastdiv(unsigned d) {
   FastDiv f;
   if (d == 0) d = 1;
@@ -2759,7 +2842,9 @@ static bool as_dense_1x1(const gad_gemm_args* a, gad_gemm_args* out) {
 // Winograd F(2x2, 3x3) route of the fp32 3x3 / stride 1 / pad 1 forward convolution (and, through ops.dgrad_as_forward, of
 // its data gradient): taken when the caller supplies the transformed weights (B_wino) and the launch has tiles enough to
 // fill the chip - small maps at small batch keep the direct LDS-patch kernels and their split-K.
-constexpr int GAD_GEMM_INTERNAL_WINO4 = 1 << 30;   // set by gad_gemm on its own batched sub-launch (names the kernel instance apart)
+constexpr int GAD_GEMM_INTERNAL_WINO4 = 1 << 30;
+// (GAD_GEMM_WINO_WGRAD = 32 is public: gad.h)
+   // set by gad_gemm on its own batched sub-launch (names the kernel instance apart)
 struct WinoPlan {
   int f;                     // 2: F(2x2,3x3) fused kernels; 4: F(4x4,3x3)
   int fused4;                // f = 4: the six-position product kernel (24 half-transformed panels) instead of 36 batched products
@@ -2839,6 +2924,52 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   return true;
 }
 
+// Winograd F(4x4, 3x3) weight gradient: opted into by the caller (GAD_GEMM_WINO_WGRAD + wino_ws), taken when it models >= 10 %
+// faster than the direct kernels (transform bytes at 4.9 TB/s + the 36 batched products at ~100 TF/s + three small launches)
+struct WinoWgradPlan {
+  long T;
+  int64_t wy_bytes, v_bytes, du_bytes, bytes;
+};
+static bool use_wino_wgrad(const gad_gemm_args* a, WinoWgradPlan* wq) {
+  const gad_conv_geom& g = a->g;
+  if (!(a->flags & GAD_GEMM_WINO_WGRAD) || (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_INTERNAL_WINO4))) return false;
+  if (a->operand_precision != 0 || a->a_mode != GAD_A_MC || a->b_mode != GAD_B_CONV || a->A2 || a->A_k2 || a->batch > 1) return false;
+  const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
+  if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 3) || (We & 3)) return false;
+  if (g.C % 4 != 0 || g.ldx % 4 != 0 || a->M % 4 != 0 || a->lda % 4 != 0 || a->N != 9 * g.C || a->ldc % 4 != 0) return false;
+  if ((a->tile_hint != 0 && a->tile_hint != 8) || a->splitk_hint > 0 || a->K % (g.Ho * g.Wo) != 0) return false;
+  if (a->alpha != 1.f || a->bias || a->rowadd || a->residual) return false;
+  if (!(gad_aligned16(a->A) && gad_aligned16(a->B) && gad_aligned16(a->C))) return false;
+  wq->T = (long)a->K / 16;
+  wq->wy_bytes = (int64_t)36 * wq->T * a->M * 4;
+  wq->v_bytes = (int64_t)36 * wq->T * g.C * 4;
+  wq->du_bytes = (int64_t)36 * a->M * g.C * 4;
+  wq->bytes = wq->wy_bytes + wq->v_bytes + wq->du_bytes;
+  if (a->tile_hint == 8) return true;
+  const double dy_bytes = 4.0 * a->K * a->M, x_bytes = 4.0 * (double)(a->K / (g.Ho * g.Wo)) * g.H * g.W * g.C;
+  const double t_w = (dy_bytes + x_bytes + (double)wq->wy_bytes + (double)wq->v_bytes) / 4.9e12 + 36.0 * wq->T * a->M * (double)g.C * 2.0 / 100e12 +
+                     3.0 * (double)wq->du_bytes / 3.0e12 + 30e-6;
+  const double t_direct = 2.0 * a->K * (double)a->M * a->N / 115e12;
+  return t_w < 0.9 * t_direct;
+}
+
+// the 36 batched products dU[pos] = Wy[pos]^T V[pos] of the Winograd weight gradient as a launch of the generic engine
+static void wino_wgrad_sub(const gad_gemm_args* a, const WinoWgradPlan& wq, float* Wy, float* V, float* dU, gad_gemm_args* sub) {
+  *sub = *a;
+  sub->A = Wy; sub->B = V; sub->C = dU;
+  sub->a_mode = GAD_A_MC; sub->b_mode = GAD_B_MC;
+  sub->M = a->M; sub->N = a->g.C; sub->K = (int32_t)wq.T;
+  sub->lda = a->M; sub->ldb = a->g.C; sub->ldc = a->g.C;
+  sub->batch = 36; sub->batch_inner = 1;
+  sub->strideA0 = wq.T * (int64_t)a->M; sub->strideA1 = 0;
+  sub->strideB0 = wq.T * (int64_t)a->g.C; sub->strideB1 = 0;
+  sub->strideC0 = (int64_t)a->M * a->g.C; sub->strideC1 = 0;
+  sub->tile_hint = 0; sub->splitk_hint = 0;
+  sub->flags = GAD_GEMM_INTERNAL_WINO4;
+  sub->B_wino = nullptr; sub->B_wino4 = nullptr; sub->wino_ws = nullptr; sub->wino_ws_bytes = 0;
+  sub->A2 = nullptr;
+}
+
 extern "C" int gad_gemm_uses_bf16(const gad_gemm_args* a) {
   if (!a) return 0;
   GAD_CANON(a);
@@ -2849,6 +2980,7 @@ extern "C" int gad_gemm_kernel_id(const gad_gemm_args* a) {
   if (!a) return -1;
   GAD_CANON(a);
   if (WinoPlan wp; use_wino(a, &wp)) return wp.f == 2 ? 5 : 6;
+  if (WinoWgradPlan wq; use_wino_wgrad(a, &wq)) return 7;
   if (use_fewout_conv(a)) return 4;
   if (wgrad_patch_splits(a)) return 2;
   if (use_patch_conv(a)) return 3;
@@ -2862,7 +2994,10 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
   GAD_CANON(a);
   *vec = pick_vec(a);
   PatchPlan pp;
-  if (WinoPlan wp; use_wino(a, &wp)) {           // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn); F(4x4): 128
+  if (WinoWgradPlan wq; use_wino_wgrad(a, &wq)) {   // Winograd weight gradient: 36 batched products on the engine's own plan
+    *tile = 128;
+    *splitk = 1;
+  } else if (WinoPlan wp; use_wino(a, &wp)) {    // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn); F(4x4): 128
     *tile = wp.f == 2 ? wp.bn : 128;
     *splitk = 1;
   } else if (use_fewout_conv(a)) {               // vector-ALU kernel: 256 pixels x all (<= 4) output channels
@@ -2888,7 +3023,9 @@ extern "C" int64_t gad_gemm_wino_bytes(const gad_gemm_args* a) {
   if (!a) return 0;
   GAD_CANON(a);
   WinoPlan wp;
-  return use_wino(a, &wp) ? wp.bytes : 0;
+  if (use_wino(a, &wp)) return wp.bytes;
+  WinoWgradPlan wq;
+  return use_wino_wgrad(a, &wq) ? wq.bytes : 0;
 }
 
 extern "C" int gad_wino_weights(const float* src, float* dst, const int64_t* table, int64_t n_tiles, void* stream) {
@@ -2908,6 +3045,11 @@ extern "C" int gad_wino4_weights(const float* src, float* dst, const int64_t* ta
 
 extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
   GAD_CANON(a);
+  if (WinoWgradPlan wq; use_wino_wgrad(a, &wq)) {
+    gad_gemm_args sub;
+    wino_wgrad_sub(a, wq, nullptr, nullptr, nullptr, &sub);
+    return gad_gemm_workspace_bytes(&sub);
+  }
   if (WinoPlan wp; use_wino(a, &wp)) {
     if (wp.f == 2 || wp.fused4) return 0;
     gad_gemm_args sub = *a;                      // the 36 batched products may split K on small launches
@@ -2953,7 +3095,8 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     const int rc = gad_gemm(&lo, stream);
     return rc ? rc : gad_gemm(&hi, stream);
   }
-  if (int m1 = 0; wgrad_split_m(a, &m1)) {
+  WinoWgradPlan wgrad_first;
+  if (int m1 = 0; !use_wino_wgrad(a, &wgrad_first) && wgrad_split_m(a, &m1)) {
     gad_gemm_args lo, hi;
     wgrad_split_args(a, m1, &lo, &hi);
     const int rc = gad_gemm(&lo, stream);
@@ -3063,6 +3206,34 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   hipStream_t st = (hipStream_t)stream;
   GAD_CHECK(a->operand_precision == 0 || a->operand_precision == 1, "gad_gemm: operand_precision must be 0 (f32) or 1 (bf16 allowed)");
   const bool bf16 = use_bf16(a) && vec == 4;
+  if (WinoWgradPlan wq; use_wino_wgrad(a, &wq)) {
+    GAD_CHECK(a->wino_ws && a->wino_ws_bytes >= wq.bytes && gad_aligned16(a->wino_ws),
+              "gad_gemm: Winograd weight-gradient workspace too small or misaligned (%lld < %lld)", (long long)a->wino_ws_bytes, (long long)wq.bytes);
+    const gad_conv_geom& g = a->g;
+    float* Wy = (float*)a->wino_ws;
+    float* V = Wy + wq.wy_bytes / 4;
+    float* dU = V + wq.v_bytes / 4;
+    WinoIn wy;                                     // dy [B][Ho][Wo][Cout] -> Wy
+    wy.x = a->A; wy.V = Wy;
+    wy.H = g.Ho; wy.W = g.Wo; wy.C = a->M; wy.ldx = a->lda; wy.up = 0;
+    wy.TH = g.Ho / 4; wy.TW = g.Wo / 4; wy.T = wq.T;
+    WinoIn wi;                                     // x -> V, as in the forward pass
+    wi.x = a->B; wi.V = V;
+    wi.H = g.H; wi.W = g.W; wi.C = g.C; wi.ldx = g.ldx; wi.up = g.upsample ? 1 : 0;
+    wi.TH = wy.TH; wi.TW = wy.TW; wi.T = wq.T;
+    const long iy = wq.T * (a->M / 4), ix = wq.T * (g.C / 4);
+    GAD_CHECK(gad_ceil_div(iy, 256) < (1L << 31) && gad_ceil_div(ix, 256) < (1L << 31), "gad_gemm: Winograd transform grid too large");
+    hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)gad_ceil_div(iy, 256)), dim3(256), 0, st, wy);
+    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(ix, 256)), dim3(256), 0, st, wi);
+    GAD_LAUNCH_CHECK("gad_gemm(winograd wgrad transforms)");
+    gad_gemm_args sub;
+    wino_wgrad_sub(a, wq, Wy, V, dU, &sub);
+    if (const int rc = gad_gemm(&sub, stream)) return rc;
+    const long items = (long)a->M * (g.C / 4);
+    hipLaunchKernelGGL(wino4_dw_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, dU, a->C, a->M, g.C, a->ldc);
+    GAD_LAUNCH_CHECK("gad_gemm(winograd wgrad output transform)");
+    return 0;
+  }
   if (WinoPlan wp; use_wino(a, &wp)) {
     GAD_CHECK(a->wino_ws && a->wino_ws_bytes >= wp.bytes && gad_aligned16(a->wino_ws) && gad_aligned16(wp.f == 2 ? a->B_wino : a->B_wino4),
               "gad_gemm: Winograd workspace too small or misaligned (%lld < %lld)", (long long)a->wino_ws_bytes, (long long)wp.bytes);

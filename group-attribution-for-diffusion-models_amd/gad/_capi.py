@@ -73,6 +73,7 @@ class AdamArgs(C.Structure):
 
 GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GEMM_SCALAR_EPILOGUE, GEMM_GENERAL_LOADERS, GN_TWO_PASS = 1, 2, 4, 8, 1
 GEMM_NO_WINO = 16
+GEMM_WINO_WGRAD = 32
 A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
 B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 

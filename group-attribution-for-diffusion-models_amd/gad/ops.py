@@ -172,7 +172,7 @@ class kernel_flags:
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None):
+             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False):
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -210,6 +210,14 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
         else:
             a.B_wino = a.B_wino4 = None
+    if wino_wgrad:                   # 3x3 weight gradient: the F(4x4) Winograd form where the planner models it faster
+        a.flags |= _capi.GEMM_WINO_WGRAD
+        need = lib.gad_gemm_wino_bytes(C.byref(a))
+        if need:
+            V = torch.empty(need, dtype=torch.uint8, device=A.device)
+            a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
+        else:
+            a.flags &= ~_capi.GEMM_WINO_WGRAD
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
         return
@@ -233,7 +241,7 @@ class GemmProfiler:
         check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
         e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
-        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino", "_wino4")[kid]   # (the Winograd kernels are one instance for every map width)
+        name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino", "_wino4", "_wino4")[kid]   # (the Winograd kernels are one instance for every map width)
         if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
         key = (name, tile.value, sk.value, vec.value)
@@ -544,8 +552,12 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
         gemm_raw(dy, x, dwk, A_MC, B_MC, Cout, Cin, Bn * H * W, Cout, Cin, Cin, tile_hint=tile_hint, splitk_hint=splitk_hint)   # dW = dy^T x
         return dwk.permute(0, 3, 1, 2)
     g = ConvGeom(H, W, Cin, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
+    wino = (KH == 3 and KW == 3 and stride == 1 and tuple(pad) == (1, 1, 1, 1) and tile_hint in (0, 8) and splitk_hint == 0
+            and Ho % 4 == 0 and Wo % 4 == 0 and OPERAND_PRECISION[0] == 0 and not KERNEL_FLAGS.get("no_wino4")
+            and not KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K
+                                            | _capi.GEMM_GENERAL_LOADERS))
     gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
-             tile_hint=tile_hint, splitk_hint=splitk_hint)
+             tile_hint=tile_hint, splitk_hint=splitk_hint, wino_wgrad=wino)
     return dwk.permute(0, 3, 1, 2)
 
 

@@ -134,6 +134,9 @@ typedef struct gad_gemm_args {
 } gad_gemm_args;
 enum gad_gemm_flags {
   GAD_GEMM_NO_WINO = 16,      /* never take the Winograd route even when B_wino is given                              */
+  GAD_GEMM_WINO_WGRAD = 32,   /* a 3x3 / stride 1 / pad 1 weight gradient (A_MC x B_CONV, output maps multiples of 4) may run in Winograd
+                               * F(4x4, 3x3) form: dW = G^T [sum_tiles (A dy A^T) (.) (B^T x B)] G; wino_ws = gad_gemm_wino_bytes(args) bytes
+                               * of scratch (transformed dy and x, the 36 product panels); the planner decides (tile_hint 8 forces) */
   GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
   GAD_GEMM_TAP_MAJOR_K = 2,   /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
   GAD_GEMM_SCALAR_EPILOGUE = 4, /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */
@@ -151,7 +154,8 @@ int gad_gemm_uses_bf16(const gad_gemm_args* a);   /* 1 if gad_gemm(a) would mult
  * 2 conv3x3_patch_f32_kernel / wgrad3x3_patch_f32_kernel, 3 conv3x3_patch_bf16_kernel (3x3 / stride 1 / pad 1 convs whose
  * 128-pixel tiles are whole image rows: input patch resident in LDS), 4 conv3x3_fewout_kernel (<= 4 output channels:
  * vector ALUs, weights through the scalar cache) */
-int gad_gemm_kernel_id(const gad_gemm_args* a);   /* ... 5 wino_input_kernel + wino_gemm_kernel (Winograd F(2x2, 3x3)), 6 wino4_input_kernel + batched gemm_kernel + wino4_output_kernel (F(4x4, 3x3)) */
+int gad_gemm_kernel_id(const gad_gemm_args* a);   /* ... 5 wino_input_kernel + wino_gemm_kernel (Winograd F(2x2, 3x3)), 6 wino4_input_kernel + wino4_gemm_kernel / batched gemm_kernel + wino4_output_kernel (F(4x4, 3x3)), 7 the F(4x4, 3x3) weight gradient
+ * (wino4_dy_kernel + wino4_input_kernel + batched gemm_kernel + wino4_dw_kernel) */
 /* bytes of wino_ws the Winograd route of gad_gemm(a) needs; 0 when gad_gemm(a) runs a direct kernel (set B_wino first) */
 int64_t gad_gemm_wino_bytes(const gad_gemm_args* a);
 /* Winograd weight transform U = G w G^T for the 3x3 weights listed in `table`: n_tiles rows of six int64

@@ -267,6 +267,37 @@ def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi, form):
     assert torch.equal(y, ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw))        # deterministic
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ups", [(4, 64, 128, 16, 16, False), (3, 96, 64, 8, 8, True), (2, 32, 68, 16, 12, False),
+                                                 (8, 128, 128, 32, 32, False), (2, 320, 320, 8, 8, False)])
+def test_conv_wgrad_winograd(ops, B, Cin, Cout, H, W, ups):
+    """Weight gradient in Winograd F(4x4, 3x3) form (wino4_dy_kernel + wino4_input_kernel + 36 batched products + wino4_dw_kernel;
+    tile_hint 8 forces it) against fp64 autograd and against the direct kernels, into a fresh tensor and into a caller-owned
+    [Cout, Cin, 3, 3] channels_last slot (the flat gradient buffer's)."""
+    x = rnd(B, Cin, H, W, seed=1).double().requires_grad_(False)
+    w = rnd(Cout, Cin, 3, 3, seed=2, scale=0.05).double().requires_grad_(True)
+    y = conv_ref(x, w, None, 1, (1, 1, 1, 1), ups)
+    dy = rnd(*y.shape, seed=6)
+    y.backward(dy.double())
+    xg, dyg, wg = nhwc(x.float()), nhwc(dy), cl_weight(w.detach().float())
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        dw = ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups, tile_hint=8)
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    assert [k[0] for k in prof.summary()] == ["conv_wgrad_wino4"], list(prof.summary())
+    dw = ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups, tile_hint=8)
+    He = H * (2 if ups else 1)
+    close(dw, w.grad, atol=3e-5 * math.sqrt(B * He * He / 16))
+    with ops.kernel_flags(no_wino=True):
+        dw0 = ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups)
+    assert not torch.equal(dw, dw0)
+    close(dw, dw0, rtol=1e-4, atol=1e-4)
+    slot = torch.full((Cout, Cin, 3, 3), 7.0, device=dev).contiguous(memory_format=torch.channels_last)
+    ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups, tile_hint=8, out=slot)
+    assert torch.equal(slot, dw)
+
+
 def test_winograd_planner_takes_the_large_launches(ops):
     """The planner's modelled times against the direct plan's: maps that are multiples of 4 go to F(4x4) down to small
     launches, other even maps to F(2x2) when the launch is large, tiny launches stay direct."""
