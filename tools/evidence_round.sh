@@ -4,6 +4,7 @@
 #   <tag>_pmc_{FETCH,WRITE}_SIZE_w{32,16}.json  separate --pmc passes over the cifar20 launch mix
 #   <tag>_train_step_kernel_stats.csv        rocprofv3 of tools/prof_train.py
 #   <tag>_bench_bf16_<workload>.json         bf16-operand mode lines (not the headline)
+#   <tag>_ab_winograd{,_wgrad}.txt           tools/ab_winograd.py, tools/ab_winograd_wgrad.py
 #   <tag>_attention.txt                      tools/bench_attention.py
 #   <tag>_full_coalition.txt                 two real end-to-end coalitions
 set -e
@@ -24,6 +25,8 @@ for wl in cifar20 sd256 sd512; do
   timeout -k 10 200 python3 bench.py --workload $wl --precision bf16 --steps $st --warmup 2 --no-cpu-baseline > $O/${TAG}_bench_bf16_${wl}.json 2> $O/${TAG}_bench_bf16_${wl}.err
   echo "done bf16 $wl"
 done
+timeout -k 10 300 python3 tools/ab_winograd.py > $O/${TAG}_ab_winograd.txt 2>&1
+timeout -k 10 300 python3 tools/ab_winograd_wgrad.py > $O/${TAG}_ab_winograd_wgrad.txt 2>&1
 timeout -k 10 600 python3 tools/bench_attention.py 5 > $O/${TAG}_attention.txt 2>&1
 echo "done attention"
 timeout -k 10 900 python3 bench.py --full-coalition --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/${TAG}_full_coalition.txt 2>&1
