@@ -457,6 +457,8 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
 
     dist_on = dist.is_available() and dist.is_initialized()
     rank, world = (dist.get_rank(), dist.get_world_size()) if dist_on else (0, 1)
+    if db_path and os.path.dirname(db_path):
+        os.makedirs(os.path.dirname(db_path), exist_ok=True)     # a fresh --db under a directory that does not exist yet
     done = finished_seeds(db_path)
     mine = shard_seeds([s for s in seeds if s not in done], rank, world)
     shard = _rank_shard(db_path, rank) if db_path else None

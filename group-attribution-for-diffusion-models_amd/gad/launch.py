@@ -175,6 +175,8 @@ def main(argv=None) -> int:
     env = {"PYTHONPATH": pkg_root + os.pathsep + os.environ.get("PYTHONPATH", "")}
     codes = [0]
     for entry in range(a.requeue + 1):
+        if os.path.dirname(a.db):
+            os.makedirs(os.path.dirname(a.db), exist_ok=True)    # shards and tombstones live next to the db
         missing = sorted(seeds - finished_seeds(a.db))
         if not missing:
             break

@@ -103,6 +103,15 @@ def test_failed_coalition_is_recorded_and_retried(tmp_path):
     assert not launch.os.path.exists(db + ".rank0")                                    # shard consolidated away
 
 
+def test_db_under_a_directory_that_does_not_exist_yet(tmp_path):
+    """`--db out/run7/db.jsonl` on a fresh machine: the scheduler creates the directory for the db, its shards and tombstones
+    instead of failing after the first coalition has been computed."""
+    db = str(tmp_path / "fresh" / "nested" / "db.jsonl")
+    rc = subprocess.run([sys.executable, WORKER, db, "4", ""]).returncode
+    assert rc == 0
+    assert sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 2, 3]
+
+
 @pytest.mark.timeout(120)
 def test_persistently_failing_coalition_does_not_lose_the_others(tmp_path):
     db = str(tmp_path / "db.jsonl")
