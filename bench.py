@@ -39,6 +39,7 @@ GD_STEPS, N_SAMPLES, DDIM_STEPS, TRAIN_B, SAMPLE_B, FUSE = 1000, 10240, 100, 128
 UNET_GFLOP_PER_IMG = 12.44          # forward, SURVEY §8d (6.222 GMAC)
 BF16_MFMA_PEAK_TF = 2500.0          # dense bf16 MFMA (v_mfma_f32_32x32x16_bf16)
 F32_MFMA_PEAK_TF = 157.3            # MI355X_MICROARCH.md: v_mfma_f32_32x32x2_f32, 64 FLOP/clk/SIMD
+HBM_PEAK_GBPS = 8000.0              # MI355X_MICROARCH.md: HBM3E spec peak (6.29 TB/s measured with a float4 copy)
 
 
 PRUNED_WIDTHS = (96, 192, 192, 192)      # magnitude pruning at ratio 0.3 keeps 32-channel GroupNorm groups whole
@@ -356,7 +357,9 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     """roofline of the dominant kernel family + per-family table, from the live HIP-event brackets."""
     summ = prof.summary()
     kern = {f"{k[0]}_t{k[1]}_sk{k[2]}_v{k[3]}": dict(launches=v["launches"], avg_us=v["ms"] / v["launches"] * 1e3,
-                                                   tflops=v["flops"] / v["ms"] / 1e9) for k, v in summ.items()}
+                                                   tflops=v["executed"] / v["ms"] / 1e9, frac=v["executed"] / v["ms"] / 1e9 / peak_tf,
+                                                   **({"tflops_algorithmic": v["flops"] / v["ms"] / 1e9} if v["executed"] != v["flops"] else {}))
+            for k, v in summ.items()}
     dom_key = max(summ, key=lambda k: summ[k]["ms"])
     d = summ[dom_key]
     nm = dom_key[0]
@@ -374,10 +377,13 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
         else:
             tiles_ = "128- then 96-channel tiles, two launches" if dom_key[1] == 224 else f"{dom_key[1]}-channel tiles"
             kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {'128 | 96' if dom_key[1] == 224 else dom_key[1]}> ({nm}, {tiles_})"
-    elif "_wino4" in nm:      # Winograd F(4x4,3x3): input transform + 36 batched products + output transform, bracketed together
-        kname = (f"wino4_input_kernel + wino4_gemm_kernel<64, 128> / <128, 64> (six-position products; small launches: 36 batched products on "
-                 f"gemm_kernel<20, 22, tile, tile, 4, 1>) + wino4_output_kernel ({nm}: "
-                 "the three launches are one convolution; time = all of them)")
+    elif "_wino4" in nm:      # Winograd F(4x4,3x3): the launches of one convolution, bracketed together
+        if dom_key[1] in (32, 64):
+            kname = (f"wino4_input_kernel + wino4_fused{'2' if dom_key[1] == 32 else ''}_kernel ({nm}, {dom_key[1]} tiles x 64 channels per workgroup: all 36 "
+                     "products and the whole output transform in one launch; time = both launches)")
+        else:
+            kname = (f"wino4_input_kernel + wino4_gemm_kernel<64, 128> / <128, 64> (six-position products; small launches: 36 batched products on "
+                     f"gemm_kernel<20, 22, tile, tile, 4, 1>) + wino4_output_kernel ({nm}: the three launches are one convolution; time = all of them)")
     elif "_wino" in nm:       # Winograd F(2x2,3x3): input transform + the 16-position MFMA loop, bracketed together
         kname = (f"wino_input_kernel + wino_gemm_kernel<{'64, 128' if dom_key[1] == 128 else '128, 64'}> ({nm}: the pair is one "
                  "convolution; time = both launches)")
@@ -387,31 +393,49 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json" if workload == "cifar20" else f"pmc_summary_{workload}.json")
     if precision == "f32" and os.path.exists(pmc):
         j = json.load(open(pmc))
-        traffic = j.get("dominant_kernel_hbm_bytes_per_launch")
-        traffic_src = (f"STORED counter pass, not measured in this run: profiles/{os.path.basename(pmc)} "
-                       f"({j.get('bench_workload', {}).get('source', j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE'))})")
-    roof = {"bound": "mfma", "kernel": kname, "achieved": d["flops"] / d["ms"] / 1e9, "peak": peak_tf, "unit": "TFLOP/s",
-            "frac": d["flops"] / d["ms"] / 1e9 / peak_tf, "traffic": traffic, "traffic_source": traffic_src,
+        if j.get("dominant_key") in (None, "_".join(str(x) for x in dom_key)):      # a stored pass of another kernel says nothing here
+            traffic = j.get("dominant_kernel_hbm_bytes_per_launch")
+            traffic_src = (f"STORED counter pass, not measured in this run: profiles/{os.path.basename(pmc)} "
+                           f"({j.get('bench_workload', {}).get('source', j.get('source', 'rocprofv3 --pmc FETCH_SIZE / WRITE_SIZE'))})")
+    # `achieved` / `frac`: the MFMA work actually ISSUED over the family's time (for a Winograd route: all of its launches,
+    # the HBM-bound input transform included) - a fraction of a roof, <= 1.  The direct-convolution count 2 M N K that every
+    # other line of this file uses is kept beside it (`algorithmic_*`): Winograd F(4x4) issues 36/144 of it, F(2x2) 16/36.
+    ex_tf, alg_tf = d["executed"] / d["ms"] / 1e9, d["flops"] / d["ms"] / 1e9
+    alg_bytes = d["bytes"] / d["launches"]
+    roof = {"bound": "mfma", "kernel": kname, "achieved": ex_tf, "peak": peak_tf, "unit": "TFLOP/s",
+            "frac": ex_tf / peak_tf, "traffic": traffic, "traffic_ratio": (traffic / alg_bytes if traffic else None),
+            "traffic_source": traffic_src,
             "launches": d["launches"], "avg_launch_us": d["ms"] / d["launches"] * 1e3,
+            "executed_gflop_per_launch": d["executed"] / d["launches"] / 1e9,
             "algorithmic_gflop_per_launch": d["flops"] / d["launches"] / 1e9,
-            "algorithmic_bytes_per_launch": d["bytes"] / d["launches"], "share_of_step_time": d["ms"] / (dt * 1e3)}
-    if "_wino" in nm:
-        # `achieved` stays the ALGORITHMIC rate (2 x 9 Cin Cout per output pixel, the direct-convolution count every other
-        # line uses) and may exceed the MFMA peak: the Winograd forms execute 16/36 (F(2x2)) or 36/144 (F(4x4)) of those multiplies.
-        ex = 36.0 / 144.0 if "_wino4" in nm else 16.0 / 36.0
-        roof["mfma_executed"] = {"gflop_per_launch": roof["algorithmic_gflop_per_launch"] * ex,
-                                 "tflops": roof["achieved"] * ex, "frac_of_peak": roof["frac"] * ex,
-                                 "note": ("Winograd F(4x4,3x3) executes 36 multiplies per 4x4 output tile and channel pair instead of 144"
-                                          if "_wino4" in nm else
-                                          "Winograd F(2x2,3x3) executes 16 multiplies per 2x2 output tile and channel pair instead of 36")
-                                         + "; frac = algorithmic FLOPs / time / peak (> 1 is possible), frac_of_peak here = the MFMA "
-                                           "work actually issued / the same time (transform launches included) / peak"}
-        if traffic is not None and ("wino4" in nm) != ("wino4" in json.dumps(j.get("dominant_kernel", ""))):
-            roof["traffic"], roof["traffic_source"] = None, None          # the stored counter pass is of another kernel
+            "algorithmic_tflops": alg_tf, "algorithmic_speedup_vs_direct_peak": alg_tf / peak_tf,
+            "algorithmic_bytes_per_launch": alg_bytes, "share_of_step_time": d["ms"] / (dt * 1e3)}
+    if "ms_input" in d:
+        # the two stages of the route, each against the roof that bounds it (an event between the two launches)
+        t_in, t_rest = d["ms_input"], d["ms"] - d["ms_input"]
+        roof.update({
+            "stage_input_kernel": "wino4_input_kernel" if "_wino4" in nm else "wino_input_kernel",
+            "stage_input_bound": "hbm", "stage_input_us": t_in / d["launches"] * 1e3,
+            "stage_input_gbps": d["bytes_input"] / t_in / 1e6, "stage_input_frac_of_hbm_peak": d["bytes_input"] / t_in / 1e6 / HBM_PEAK_GBPS,
+            "stage_products_kernel": kname.split(" + ", 1)[1].split(" (")[0],
+            "stage_products_bound": "mfma", "stage_products_us": t_rest / d["launches"] * 1e3,
+            "stage_products_tflops_executed": d["executed"] / t_rest / 1e9,
+            "stage_products_frac_of_mfma_peak": d["executed"] / t_rest / 1e9 / peak_tf,
+            "stage_products_algorithmic_gbps": d["bytes_rest"] / t_rest / 1e6,
+            "stage_products_frac_of_hbm_peak": d["bytes_rest"] / t_rest / 1e6 / HBM_PEAK_GBPS,
+            "stage_note": ("input transform: x in, V out (2.25x the input for F(4x4)), a pure HBM stream; products: V and U in, y out "
+                           "(+ residual in) - MFMA-bound by design, its algorithmic stream rate is listed against the HBM roof too")})
+    # every forward launch of the route's family, whatever form the planner gave it (one-launch / three-launch)
+    fam = [v for k, v in summ.items() if k[0] == nm]
+    if len(fam) > 1:
+        f_ms, f_ex, f_fl = sum(v["ms"] for v in fam), sum(v["executed"] for v in fam), sum(v["flops"] for v in fam)
+        roof.update({"family_launches": sum(v["launches"] for v in fam), "family_share_of_step_time": f_ms / (dt * 1e3),
+                     "family_frac": f_ex / f_ms / 1e9 / peak_tf, "family_algorithmic_tflops": f_fl / f_ms / 1e9})
     all_ms = sum(v["ms"] for v in summ.values())
     all_fl = sum(v["flops"] for v in summ.values())
-    table = {"tflops": all_fl / all_ms / 1e9, "share_of_step_time": all_ms / (dt * 1e3), "by_instance": kern}
-    return roof, table, all_fl
+    all_ex = sum(v["executed"] for v in summ.values())
+    table = {"tflops": all_ex / all_ms / 1e9, "tflops_algorithmic": all_fl / all_ms / 1e9, "share_of_step_time": all_ms / (dt * 1e3), "by_instance": kern}
+    return roof, table, all_fl, all_ex
 
 
 class LDMRunner:
@@ -595,13 +619,15 @@ def measure(a, name, steps, warmup, env, headline):
         out["vs_baseline"] = None
     if prof is not None:
         torch.cuda.synchronize(dev)
-        out["roofline"], out["contraction_kernels"], all_fl = kernel_report(prof, dt, peak_tf, a.precision, name)
-        out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs of every contraction / attention launch
-        out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf      # whole path, not one kernel
+        out["roofline"], out["contraction_kernels"], all_fl, all_ex = kernel_report(prof, dt, peak_tf, a.precision, name)
+        out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs (direct-form count) of every contraction / attention launch
+        out["unet_tflops_executed_per_gpu"] = all_ex / dt / 1e12   # the MFMA work issued (Winograd launches: 36/144 or 16/36 of the direct count)
+        out["path_mfma_frac"] = out["unet_tflops_executed_per_gpu"] / peak_tf        # whole path, executed work / step time / peak: <= 1
+        out["path_mfma_frac_algorithmic"] = out["unet_tflops_per_gpu"] / peak_tf    # the same on the direct-form count (> executed where Winograd runs)
     elif name == "cifar20" and not a.full_coalition:
         fl = (3 * UNET_GFLOP_PER_IMG * TRAIN_B + UNET_GFLOP_PER_IMG * N_SAMPLES * DDIM_STEPS / GD_STEPS) * 1e9
         out["unet_tflops_per_gpu"] = fl * steps / dt / 1e12
-        out["path_mfma_frac"] = out["unet_tflops_per_gpu"] / peak_tf
+        out["path_mfma_frac_algorithmic"] = out["unet_tflops_per_gpu"] / peak_tf     # (--no-kernel-timing: no executed count is taken)
     if n_tr:
         out["unet_train_steps_per_s"] = {"value": n_tr * world / dt_train, "batch_per_gpu": TRAIN_B, "n_gpus": world,
                                          "ms_per_step": dt_train / n_tr * 1e3, "reference": 3.81,   # 3.81 steps/s, 1 GPU

@@ -32,124 +32,15 @@
 //   conv3x3_patch_bf16_kernel   the patch convolution with bf16 operands (optionally a bf16 weight copy by LDS-DMA)
 //   splitk_reduce_kernel        deterministic reduction + fused epilogue of any split launch
 #include "gad_common.h"
+#include "gemm_dev.h"
+
+using namespace gadk;
+
+namespace gadk {
+void launch_wino4_fused(const DevArgs& w, int bm, hipStream_t st);   // wino4_fused.hip: all 36 products + the output transform, one launch
+}
 
 namespace {
-
-constexpr int BK = 32;
-constexpr int NTHREADS = 256;
-
-// 64 bytes of zeros in device memory: the DMA source of padding / out-of-range tile slots
-__device__ __attribute__((aligned(64))) float g_zero_block[16];
-
-// physical float offset of logical 16-B chunk q (0..7) of KC-tile row r
-__device__ __forceinline__ int kc_off(int r, int q) { return r * BK + ((q ^ ((r >> 1) & 7)) << 2); }
-
-// LDS-DMA: 64 lanes x 16 B -> LDS [dst, dst + 1 KiB), lane-linear; src is per lane
-__device__ __forceinline__ void glds16(const float* src, float* dst_wave_uniform) {
-  __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                   (__attribute__((address_space(3))) void*)dst_wave_uniform, 16, 0, 0);
-}
-
-// A barrier that publishes LDS-DMA'd tiles: the DMA is a VMEM operation (vmcnt), and the compiler's own waitcnt placement
-// at __syncthreads() only covers it when it happens to track the LDS side effect - so wait for it explicitly.
-// s_waitcnt immediate (gfx9): vmcnt = 0 (bits 3:0 and 15:14), expcnt = 7 (no wait), lgkmcnt = 15 (no wait).
-__device__ __forceinline__ void barrier_after_dma() {
-  __builtin_amdgcn_s_waitcnt(0x0F70);
-  __syncthreads();
-}
-
-// division by a launch-invariant divisor: q = (mulhi(n, mul) + n) >> shift, exact for 0 <= n < 2^31
-struct FastDiv {
-  unsigned mul, shift;
-  __device__ __forceinline__ int div(int n) const { return (int)((__umulhi((unsigned)n, mul) + (unsigned)n) >> shift); }
-};
-
-struct DevArgs {
-  FastDiv fdC, fdKW, fdHoWo, fdWo, fdRpg, fdTaps;
-  int kperm, taps;   // kperm: K steps visit (channel chunk, tap) instead of (tap, channel chunk)
-  const float* A;
-  const float* B;
-  float* C;
-  const unsigned short* Bh;   // bf16 copy of B ([N][ldb], k contiguous): bf16 patch conv streams it by LDS-DMA
-  const float* A2;   // two-source conv gather (virtual channel concat): channels >= a_split come from A2
-  int a_split, ldx2;
-  // K-concatenated dense operands (fused LoRA side path): for k >= k_split the products read Ak2 / Bk2 at k - k_split
-  const float* Ak2;
-  const float* Bk2;
-  int lda2, ldb2, k_split;
-  int M, N, K;
-  int lda, ldb, ldc;
-  int batch_inner;
-  long sA0, sA1, sB0, sB1, sC0, sC1;
-  gad_conv_geom g;
-  float alpha;
-  const float* bias;
-  const float* rowadd;
-  int rows_per_group, ld_rowadd;
-  const float* residual;
-  int ldr;
-  float* ws;
-  int tiles_m, tiles_n, splitk, ktiles_per_split;
-  int epi_vec;       // the output (and bias / rowadd / residual / workspace) can be written / read as aligned float4
-};
-
-__device__ __forceinline__ f32x4 ldg4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
-__device__ __forceinline__ f32x4 zero4() { return f32x4{0.f, 0.f, 0.f, 0.f}; }
-__device__ __forceinline__ f32x4 keep_if(f32x4 v, bool ok) { return ok ? v : zero4(); }
-
-// ------------------------------------------------------------------------------------
-// Tile loaders.  Each thread owns NS float4 slots of the tile.
-//   load(k0, v, mask): issue the global loads of the K step starting at k0.  Loads are
-//     UNCONDITIONAL (an invalid slot reads the tensor's base address) so that all of a
-//     thread's loads are in flight together behind the MFMAs of the current step;
-//     `mask` bit i says whether slot i is real data.
-//   store(lds, v, mask): zero the invalid slots and write the tile into LDS.
-// KC-type: slot i = (row (tid>>3)+32 i, float4 column tid&7)
-// MC-type: slot i = (k row tid/F4 + (256/F4) i, float4 column tid%F4),  F4 = ROWS/4
-// ------------------------------------------------------------------------------------
-// the wave's index as a SCALAR: LDS-DMA destinations (M0) derived from it need no per-launch v_readfirstlane in the K loop
-__device__ __forceinline__ int wave_id() { return __builtin_amdgcn_readfirstlane((int)(threadIdx.x >> 6)); }
-
-template <int ROWS>
-struct KCSlots {
-  static constexpr int NS = ROWS / 32;
-  __device__ static int row(int i) { return (threadIdx.x >> 3) + 32 * i; }
-  // logical float4 column (k chunk) this lane supplies for its row: the lane's LDS position is fixed by
-  // the DMA (physical chunk = lane & 7), so the swizzle is applied to what it loads
-  // (row(i) >> 1) & 7 == (tid >> 4) & 7 for every slot i, so the column is slot independent
-  __device__ static int kq4() { return ((threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7)) * 4; }
-  __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * 8 + 32 * i) * BK; }
-  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-      *reinterpret_cast<f32x4*>(lds + row(i) * BK + (threadIdx.x & 7) * 4) = keep_if(v[i], (mask >> i) & 1u);
-  }
-};
-template <int ROWS>
-struct MCSlots {
-  static constexpr int NS = ROWS / 32;
-  static constexpr int F4 = ROWS / 4;
-  static constexpr int KSTEP = NTHREADS / F4;
-  __device__ static int krow(int i) { return threadIdx.x / F4 + KSTEP * i; }
-  __device__ static int rq4() { return (threadIdx.x % F4) * 4; }
-  __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * (KSTEP / 4) + KSTEP * i) * ROWS; }
-  __device__ static void store(float* lds, const f32x4* v, unsigned mask) {   // register path (VEC == 1)
-#pragma unroll
-    for (int i = 0; i < NS; ++i)
-      *reinterpret_cast<f32x4*>(lds + krow(i) * ROWS + rq4()) = keep_if(v[i], (mask >> i) & 1u);
-  }
-};
-
-// Loader protocol: prep(k0) once per K step (shared decode), then per slot i either
-//   src(i)            -> per-lane source address of the float4 (or the zero block)   [VEC == 4, LDS-DMA]
-//   slot(i, v, mask)  -> register-staged scalar gather of the 4 floats               [VEC == 1]
-// both called from between MFMA groups so the address arithmetic sits in the MFMA shadow.
-// branch-free source select: offsets are always computed (possibly from out-of-range coordinates), masked
-// to 0 when invalid and added to either the tensor base or the zero block
-__device__ __forceinline__ const float* sel_src(const float* base, long off, bool ok) {
-  const float* b = ok ? base : (const float*)g_zero_block;
-  return b + (off & -(long)ok);
-}
 
 // dense [row][k]
 template <int ROWS, int VEC>
@@ -740,14 +631,6 @@ struct BLoader<GAD_B_CONV, ROWS, VEC> : LoadConvCols<ROWS, VEC> {
   __device__ void setup(const DevArgs& p, const float* b, int col0, int kend) { this->init(b, p, col0, p.N, kend); }
 };
 
-// Workgroup id -> work item, XCD-aware and bijective: hardware deals consecutive workgroup ids round-robin to the 8 XCDs
-// (each with its own L2); this hands every XCD a CONTIGUOUS range of work items, so tiles that share an operand panel
-// (neighbouring tile_n of one tile_m, the halo rows of neighbouring row tiles) meet in one L2.
-__device__ __forceinline__ int xcd_remap(int bid, int nwg) {
-  int xcd = bid & 7, q = nwg >> 3, rr = nwg & 7;
-  return (xcd < rr ? xcd * (q + 1) : rr * (q + 1) + (xcd - rr) * q) + (bid >> 3);
-}
-
 // ------------------------------------------------------------------------------------
 // Epilogue shared by every contraction kernel: the wave block's accumulators (C/D map: col = lane & 31,
 // row = (reg & 3) + 8 (reg >> 2) + 4 (lane >> 5)) go to C with alpha, bias[n], rowadd[m / rows_per_group][n] and
@@ -763,8 +646,6 @@ __device__ __forceinline__ int xcd_remap(int bid, int nwg) {
 // Per element the arithmetic and its order are unchanged (bit-identical to the scalar form, which remains for outputs
 // that cannot take aligned float4: N % 4 != 0, odd leading dimensions).
 // ------------------------------------------------------------------------------------
-constexpr int EPI_LD = 40;                       // scratch row stride in floats
-constexpr int EPI_WAVE = 32 * EPI_LD;            // floats of scratch per wave (5 KB; 20 KB per workgroup)
 
 template <int TM, int TN, int BM, int BN, int WM = 2, int WN = 2>
 __device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc)[TM][TN], int row0, int col0, int wm, int wn,
@@ -827,19 +708,6 @@ __device__ __forceinline__ void store_block(const DevArgs& p, const f32x16 (&acc
   }
 }
 
-// ------------------------------------------------------------------------------------
-// Fragment reads.  K step of 32 = 4 groups of 8; in group g, MFMA step j (0..3) feeds
-// lane half h with k = 8g + 4h + j  (so a KC tile is read as one b128 per group).
-// ------------------------------------------------------------------------------------
-template <bool KC, int ROWS>
-__device__ __forceinline__ f32x4 read_frag(const float* lds, int row, int g, int h) {
-  if (KC) {
-    return *reinterpret_cast<const f32x4*>(lds + kc_off(row, 2 * g + h));
-  } else {
-    const float* p = lds + (8 * g + 4 * h) * ROWS + row;
-    return f32x4{p[0], p[ROWS], p[2 * ROWS], p[3 * ROWS]};
-  }
-}
 
 // TAG only names an instance apart in profiles (1: the 36 batched products of the F(4x4) Winograd route)
 template <int AM, int BMODE, int BM, int BN, int VEC, int TAG = 0>
@@ -1927,24 +1795,6 @@ __global__ __launch_bounds__(256) void wino_weights_kernel(const float* src, flo
   }
 }
 
-// dense [row][k] rows by LDS-DMA with a 64-bit step offset (position x panel stride + k): rows beyond the operand clamp
-// to the last one (they feed outputs the epilogue never stores)
-template <int ROWS>
-struct WinoKC : KCSlots<ROWS> {
-  using S = KCSlots<ROWS>;
-  const float* ptr[S::NS];
-  long off;
-  __device__ void init(const float* b, int ld, int row0, int nrows) {
-#pragma unroll
-    for (int i = 0; i < S::NS; ++i) {
-      int r = row0 + S::row(i);
-      r = r < nrows ? r : nrows - 1;
-      ptr[i] = b + (long)r * ld + S::kq4();
-    }
-    off = 0;
-  }
-  __device__ __forceinline__ const float* src(int i) const { return ptr[i] + off; }
-};
 
 // one output pixel (di, dj) of every 2x2 tile of the block: p.M counts TILES, p.fdHoWo / p.fdWo divide by the tiles per
 // image / per tile row, the pixel row is ((n Ho + 2 ty + di) Wo + 2 tx + dj); same arithmetic order as store_block
@@ -2242,14 +2092,6 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_gemm_kernel(const DevArgs p
 // fp32 throughout; the larger transform coefficients cost about a decimal digit against the direct kernels (measured
 // max error 4e-6 of the output scale vs 4e-7), still an order of magnitude inside the contraction tolerance of the tests.
 // ------------------------------------------------------------------------------------
-__device__ __forceinline__ void wino4_bt(const f32x4 (&d)[6], f32x4 (&t)[6]) {
-  t[0] = 4.f * d[0] - 5.f * d[2] + d[4];
-  t[1] = -4.f * (d[1] + d[2]) + d[3] + d[4];
-  t[2] = 4.f * (d[1] - d[2]) - d[3] + d[4];
-  t[3] = 2.f * (d[3] - d[1]) - d[2] + d[4];
-  t[4] = 2.f * (d[1] - d[3]) - d[2] + d[4];
-  t[5] = 4.f * d[1] - 5.f * d[3] + d[5];
-}
 
 __global__ __launch_bounds__(256) void wino4_input_kernel(const WinoIn p) {   // p.TH / p.TW / p.T count 4x4 tiles
   const int C4 = p.C >> 2;
@@ -2847,7 +2689,9 @@ constexpr int GAD_GEMM_INTERNAL_WINO4 = 1 << 30;
    // set by gad_gemm on its own batched sub-launch (names the kernel instance apart)
 struct WinoPlan {
   int f;                     // 2: F(2x2,3x3) fused kernels; 4: F(4x4,3x3)
-  int fused4;                // f = 4: the six-position product kernel (24 half-transformed panels) instead of 36 batched products
+  int fused4;                // f = 4: 0 = 36 batched products on the generic engine + output kernel, 1 = the six-position product kernel
+                             // (24 half-transformed panels) + output kernel, 2 = wino4_fused_kernel (products and the whole output
+                             // transform in one launch: no product ever reaches memory)
   int bm, bn, tiles_m, tiles_n;
   long T;                    // tiles (2x2 or 4x4 output pixels each)
   int64_t bytes;             // scratch: V (f = 2), V + M (f = 4)
@@ -2857,7 +2701,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   if ((!a->B_wino && !a->B_wino4) || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
   const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 1) || (We & 1)) return false;
-  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7 && a->tile_hint != 8) || a->splitk_hint > 0 || a->batch > 1) return false;
+  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7 && a->tile_hint != 8 && a->tile_hint != 9 && a->tile_hint != 10 && a->tile_hint != 11 && a->tile_hint != 12 && a->tile_hint != 13 && a->tile_hint != 14 && a->tile_hint != 15) || a->splitk_hint > 0 || a->batch > 1) return false;
   if (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_SCALAR_EPILOGUE | GAD_GEMM_TAP_MAJOR_K)) return false;
   if (a->rowadd && a->rows_per_group != g.Ho * g.Wo) return false;
   if (a->M % (g.Ho * g.Wo) != 0) return false;
@@ -2865,7 +2709,8 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
                       (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
                       (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0));
   if (!vec_ok) return false;
-  const bool f2_ok = a->B_wino != nullptr && (long)a->M / 4 < (1L << 30) && a->tile_hint != 8;
+  const bool force4 = a->tile_hint >= 8 && a->tile_hint <= 15;   // 8: planner's F(4x4) form, 9 / 11: the one-launch form on 32- / 64-tile blocks, 10: the three-launch forms
+  const bool f2_ok = a->B_wino != nullptr && (long)a->M / 4 < (1L << 30) && !force4;
   const bool f4_ok = a->B_wino4 != nullptr && (He & 3) == 0 && (We & 3) == 0 && a->tile_hint != 7;
   // Modelled times (calibrated on tools/ab_winograd.py, profiles/r03_ab_winograd.txt).  Transform launches stream their bytes
   // at ~4.9 TB/s.  F(2x2): a CU runs the 16-position product of one block at ~0.43 TF/s whether it holds one block or two,
@@ -2899,15 +2744,33 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm);
     p4.tiles_n = (int)gad_ceil_div(a->N, p4.bn);
     p4.fused4 = ((long)p4.tiles_m * p4.tiles_n * 6 >= 1024 && !(a->flags & GAD_GEMM_GENERAL_LOADERS)) ? 1 : 0;   // >= 4 rounds of one block per CU
-    const double vb = 36.0 * p4.T * g.C * 4.0, mb = (p4.fused4 ? 24.0 : 36.0) * p4.T * a->N * 4.0;
-    p4.bytes = (int64_t)(vb + mb);
+    // one-launch form (wino4_fused.hip): a (32 tiles x 64 channels) block carries all 36 positions, two workgroups per CU at
+    // ~0.2 TF/s executed each (rounds of 512); its epilogue reads the residual under the other workgroup's K loop, which costs
+    // about the residual's bytes at 2.2 TB/s (profiles/r04_ab_winograd.txt, r04_wino4_fused_experiments.txt).  Taken when it
+    // models faster than the three-launch form and its blocks fill most of a round.
+    const long blocks32 = gad_ceil_div(p4.T, 32) * gad_ceil_div(a->N, 64);
+    const double y_once = 4.0 * (double)a->M * a->N;
+    const double t_full = (double)gad_ceil_div(blocks32, 512) * 36.0 * (g.C / BK) * (32.0 * 64.0 * BK * 2.0) / 0.20e12 +
+                          (a->residual ? y_once / 2.2e12 : y_once / 20e12);
+    const double vb = 36.0 * p4.T * g.C * 4.0;
     const long blocks = gad_ceil_div(p4.T, 128) * gad_ceil_div(a->N, 128) * 36;
     const double t_gemm = (double)gad_ceil_div(blocks, 512) * (g.C / BK + 1) * (128.0 * 128.0 * BK * 2.0) / 0.254e12;
-    t4 = (x_bytes + vb) / 4.9e12 + t_gemm + (mb + y_bytes) / 4.9e12 + 18e-6;
+    const double mb3 = (p4.fused4 ? 24.0 : 36.0) * p4.T * a->N * 4.0;
+    const double t3 = t_gemm + (mb3 + y_bytes) / 4.9e12 + 12e-6;
+    const bool full_ok = !(a->flags & GAD_GEMM_GENERAL_LOADERS) && a->tile_hint != 10;
+    if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (a->tile_hint >= 12 && a->tile_hint <= 15) || (t_full < t3 && blocks32 >= 320))) {
+      p4.fused4 = 2;
+      p4.bm = a->tile_hint == 11 ? 64 : 32; p4.bn = 64;
+      p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm);
+      p4.tiles_n = (int)gad_ceil_div(a->N, 64);
+    }
+    const double mb = p4.fused4 == 2 ? 0.0 : mb3;
+    p4.bytes = (int64_t)(vb + mb);
+    t4 = (x_bytes + vb) / 4.9e12 + (p4.fused4 == 2 ? t_full : t3) + 6e-6;
   }
-  if (a->tile_hint == 7 || a->tile_hint == 8) {  // A/B tools force a route
+  if (a->tile_hint == 7 || force4) {             // A/B tools force a route
     if (a->tile_hint == 7 && f2_ok) { *wp = p2; return true; }
-    if (a->tile_hint == 8 && f4_ok) { *wp = p4; return true; }
+    if (force4 && f4_ok) { *wp = p4; return true; }
     return false;
   }
   double t_direct;
@@ -2998,7 +2861,7 @@ extern "C" int gad_gemm_plan(const gad_gemm_args* a, int32_t* tile, int32_t* spl
     *tile = 128;
     *splitk = 1;
   } else if (WinoPlan wp; use_wino(a, &wp)) {    // Winograd: bm tiles of 2x2 pixels x bn channels (reported: bn); F(4x4): 128
-    *tile = wp.f == 2 ? wp.bn : 128;
+    *tile = wp.f == 2 ? wp.bn : (wp.fused4 == 2 ? wp.bm : 128);
     *splitk = 1;
   } else if (use_fewout_conv(a)) {               // vector-ALU kernel: 256 pixels x all (<= 4) output channels
     *tile = 256;
@@ -3051,7 +2914,7 @@ extern "C" int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a) {
     return gad_gemm_workspace_bytes(&sub);
   }
   if (WinoPlan wp; use_wino(a, &wp)) {
-    if (wp.f == 2 || wp.fused4) return 0;
+    if (wp.f == 2 || wp.fused4) return 0;         // (the product kernels of both fused forms never split K)
     gad_gemm_args sub = *a;                      // the 36 batched products may split K on small launches
     sub.B_wino = nullptr; sub.B_wino4 = nullptr;
     sub.a_mode = GAD_A_KC; sub.b_mode = GAD_B_KC;
@@ -3085,6 +2948,9 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
   WinoPlan wino_first;
   if (int n1 = 0; !use_wino(a, &wino_first) && patch_split_n(a, &n1)) {          // 224 / 448 output channels: 128-wide tiles, then 96-wide tiles
     gad_gemm_args lo = *a, hi = *a;
+    lo.B_wino = lo.B_wino4 = hi.B_wino = hi.B_wino4 = nullptr;    // the halves are direct launches: the transformed weights' position stride is the FULL Cout
+    lo.wino_ws = hi.wino_ws = nullptr;
+    lo.wino_ws_bytes = hi.wino_ws_bytes = 0;
     lo.N = n1;
     hi.N = a->N - n1;
     hi.B = a->B + (long)n1 * a->ldb;
@@ -3244,16 +3110,36 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     wi.TH = g.Ho / wp.f; wi.TW = g.Wo / wp.f; wi.T = wp.T;
     const long items = wp.T * (g.C / 4);
     GAD_CHECK(gad_ceil_div(items, 256) < (1L << 31), "gad_gemm: Winograd input transform grid too large");
+    const bool only_input = (a->flags & GAD_GEMM_WINO_ONLY_INPUT) != 0, skip_input = (a->flags & GAD_GEMM_WINO_SKIP_INPUT) != 0;
+    GAD_CHECK(!(only_input && skip_input), "gad_gemm: GAD_GEMM_WINO_ONLY_INPUT and GAD_GEMM_WINO_SKIP_INPUT exclude each other");
     if (wp.f == 4) {
-      hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
-      GAD_LAUNCH_CHECK("gad_gemm(winograd F4 input transform)");
+      if (!skip_input) {
+        hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
+        GAD_LAUNCH_CHECK("gad_gemm(winograd F4 input transform)");
+      }
+      if (only_input) return 0;
+      if (wp.fused4 == 2) {                        // products + the whole output transform in one launch
+        DevArgs w = d;
+        w.A = wi.V; w.B = a->B_wino4;
+        w.M = (int)wp.T; w.N = a->N; w.K = g.C;
+        w.lda = g.C; w.ldb = g.C;
+        w.sA0 = wp.T * (long)g.C; w.sB0 = (long)a->N * g.C;
+        w.fdHoWo = make_fastdiv((unsigned)(wi.TH * wi.TW));
+        w.fdWo = make_fastdiv((unsigned)wi.TW);
+        w.tiles_m = wp.tiles_m; w.tiles_n = wp.tiles_n;
+        w.splitk = a->tile_hint == 12 ? 1 : a->tile_hint == 13 ? 2 : a->tile_hint == 14 ? 4 : a->tile_hint == 15 ? 3 : 0;      // timing experiments (wrong results): see wino4_fused.hip
+        GAD_CHECK((long)wp.tiles_m * wp.tiles_n < (1L << 31), "gad_gemm: Winograd grid too large");
+        gadk::launch_wino4_fused(w, wp.bm, st);
+        GAD_LAUNCH_CHECK("gad_gemm(winograd F4 fused products + output transform)");
+        return 0;
+      }
       float* Mb = wi.V + 36 * wp.T * (long)g.C;
       WinoOut wo;
       wo.Mb = Mb; wo.y = a->C; wo.bias = a->bias; wo.rowadd = a->rowadd; wo.residual = a->residual;
       wo.N = a->N; wo.ldc = a->ldc; wo.ldr = a->ldr; wo.ld_rowadd = a->ld_rowadd;
       wo.Ho = g.Ho; wo.Wo = g.Wo; wo.TH = wi.TH; wo.TW = wi.TW; wo.T = wp.T; wo.alpha = a->alpha;
       const long oitems = wp.T * (a->N / 4);
-      if (wp.fused4) {
+      if (wp.fused4 == 1) {
         DevArgs w = d;
         w.A = wi.V; w.B = a->B_wino4; w.C = Mb;
         w.M = (int)wp.T; w.N = a->N; w.K = g.C;
@@ -3288,8 +3174,11 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
       GAD_LAUNCH_CHECK("gad_gemm(winograd F4 output transform)");
       return 0;
     }
-    hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
-    GAD_LAUNCH_CHECK("gad_gemm(winograd input transform)");
+    if (!skip_input) {
+      hipLaunchKernelGGL(wino_input_kernel, dim3((unsigned)gad_ceil_div(items, 256)), dim3(256), 0, st, wi);
+      GAD_LAUNCH_CHECK("gad_gemm(winograd input transform)");
+    }
+    if (only_input) return 0;
     DevArgs w = d;
     w.A = wi.V; w.B = a->B_wino;
     w.M = (int)wp.T; w.N = a->N; w.K = g.C;

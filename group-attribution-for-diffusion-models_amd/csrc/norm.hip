@@ -11,6 +11,7 @@
 // in one workgroup's registers; the two-pass plan remains for the other shapes.
 #include "gad_common.h"
 #include "gad_reduce.h"
+#include "gemm_dev.h"
 
 namespace {
 
@@ -359,6 +360,159 @@ static int make_slab(const gad_groupnorm_args* a, SlabGeo* out, const int nth = 
   return best_nv <= 4 ? 4 : best_nv <= 8 ? 8 : best_nv <= 16 ? 16 : 32;
 }
 
+// ------------------------------------------- forward, one pass, Winograd output ----
+// GroupNorm + SiLU whose consumer is a 3x3 / stride-1 convolution on the Winograd F(4x4, 3x3) route (ResnetBlock2D:
+// norm -> silu -> conv, reference diffusers ResnetBlock2D.forward): instead of y the kernel writes the route's
+// transformed input V [36][tiles][C] = B^T y_patch B directly, so y never exists in HBM and the route's own input-transform
+// launch (one read of y, one write of V) disappears.  Same slab plan and the same statistics arithmetic as gn_slab_kernel
+// (mean / rstd bit-identical); the normalised slab then goes to LDS ([pixel][SC channels], up to 128 KB: a 32 x 32 map of 32
+// channels) and every thread transforms 6 x 6 patches of one channel quad from there - the halo re-reads (2.25x) stay on
+// chip.  LDS image: pixel column x is stored at x ^ ((x >> 2) & 1), which puts the same patch position of two neighbouring
+// tiles on opposite bank halves, so a 16-lane ds_read_b128 group (8 quads x 2 tiles at SC = 32) is conflict-free.
+// V rows are whole 128-B lines (SC % 32 == 0).
+struct GnWino {
+  float* V;
+  int W, TH, TW;
+  long pos_stride;           // floats between two Winograd positions: B * TH * TW * C
+};
+
+template <int NV>
+__global__ __launch_bounds__(512) void gn_wino4_kernel(const float* __restrict__ x, const float* __restrict__ x2, int C1,
+                                                      const float* __restrict__ gamma, const float* __restrict__ beta,
+                                                      float* __restrict__ mean_out, float* __restrict__ rstd_out,
+                                                      SlabGeo s, float eps, int silu, GnWino w) {
+  constexpr int NTH = 512;
+  extern __shared__ __attribute__((aligned(16))) float gn_img[];       // [HW][SC]
+  __shared__ float red[NTH];
+  __shared__ float s_mean[64], s_rstd[64];
+  int b, sl;
+  slab_of_block(s, b, sl);
+  const int tid = threadIdx.x;
+  const int pl = tid / s.qpr, q = tid - pl * s.qpr;
+  const bool act = pl < s.PL;
+  const int c0 = sl * s.SC + q * 4;
+  const bool second = c0 >= C1;
+  const int ldin = second ? s.C - C1 : C1;
+  const float* xin = (second ? x2 + (c0 - C1) : x + c0) + ((long)b * s.HW) * ldin;
+  f32x4 v[NV];
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = pl + i * s.PL;
+    v[i] = (act && p < s.HW) ? *reinterpret_cast<const f32x4*>(xin + (long)p * ldin) : f32x4{0.f, 0.f, 0.f, 0.f};
+  }
+  f32x4 acc = {0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) acc += v[i];
+  const float inv_n = 1.f / (float)((long)s.HW * s.cpg);
+  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  if (tid < s.gps) {
+    float S = 0.f;
+    for (int j = 0; j < s.qpg; ++j) S += red[tid * s.qpg + j];
+    s_mean[tid] = S * inv_n;
+  }
+  __syncthreads();
+  const float m1 = act ? s_mean[q / s.qpg] : 0.f;
+  const f32x4 mu = f32x4{m1, m1, m1, m1};
+  acc = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+  for (int i = 0; i < NV; ++i) {
+    int p = pl + i * s.PL;
+    f32x4 d = v[i] - mu;
+    if (act && p < s.HW) acc += d * d;
+  }
+  slab_reduce(red, (acc[0] + acc[1]) + (acc[2] + acc[3]), s, pl, act);
+  if (tid < s.gps) {
+    float SS = 0.f;
+    for (int j = 0; j < s.qpg; ++j) SS += red[tid * s.qpg + j];
+    float rs = rsqrtf(SS * inv_n + eps);
+    s_rstd[tid] = rs;
+    mean_out[b * s.G + sl * s.gps + tid] = s_mean[tid];
+    rstd_out[b * s.G + sl * s.gps + tid] = rs;
+  }
+  __syncthreads();
+  f32x4* img4 = reinterpret_cast<f32x4*>(gn_img);
+  if (act) {
+    const float r1 = s_rstd[q / s.qpg];
+    const f32x4 rs = f32x4{r1, r1, r1, r1};
+    const f32x4 ga = *reinterpret_cast<const f32x4*>(gamma + c0), be = *reinterpret_cast<const f32x4*>(beta + c0);
+    const f32x4 scale = ga * rs, shift = be - scale * mu;
+#pragma unroll
+    for (int i = 0; i < NV; ++i) {
+      int p = pl + i * s.PL;
+      if (p < s.HW) {
+        f32x4 z = v[i] * scale + shift;
+        if (silu) {
+#pragma unroll
+          for (int e = 0; e < 4; ++e) z[e] = silu_f(z[e]);
+        }
+        const int yy = p / w.W, xx = p - yy * w.W;
+        img4[(yy * w.W + (xx ^ ((xx >> 2) & 1))) * s.qpr + q] = z;
+      }
+    }
+  }
+  __syncthreads();
+  // ---- 6 x 6 patches of one channel quad -> V (the arithmetic of wino4_input_kernel, gemm_f32.hip) ----
+  const int H = s.HW / w.W;
+  const int items = w.TH * w.TW * s.qpr;
+  for (int it = tid; it < items; it += NTH) {
+    const int tile = it / s.qpr, qq = it - tile * s.qpr;
+    const int ty = tile / w.TW, tx = tile - ty * w.TW;
+    f32x4 t[6][6];
+#pragma unroll
+    for (int dx = 0; dx < 6; ++dx) {
+      const int xx = 4 * tx - 1 + dx;
+      const bool xok = xx >= 0 && xx < w.W;
+      const int xs = xx ^ ((xx >> 2) & 1);
+      f32x4 d[6], col[6];
+#pragma unroll
+      for (int dy = 0; dy < 6; ++dy) {
+        const int yy = 4 * ty - 1 + dy;
+        const bool ok = xok && yy >= 0 && yy < H;
+        d[dy] = ok ? img4[(yy * w.W + xs) * s.qpr + qq] : f32x4{0.f, 0.f, 0.f, 0.f};
+      }
+      gadk::wino4_bt(d, col);
+#pragma unroll
+      for (int i = 0; i < 6; ++i) t[i][dx] = col[i];
+    }
+    float* out = w.V + ((long)b * (w.TH * w.TW) + tile) * s.C + sl * s.SC + qq * 4;
+#pragma unroll
+    for (int i = 0; i < 6; ++i) {
+      f32x4 vv[6];
+      gadk::wino4_bt(t[i], vv);
+#pragma unroll
+      for (int j = 0; j < 6; ++j) *reinterpret_cast<f32x4*>(out + (long)(6 * i + j) * w.pos_stride) = vv[j];
+    }
+  }
+}
+
+// slab plan of gn_wino4_kernel: whole groups, whole 128-B lines, the normalised slab within 128 KB of LDS, <= 16 slots per
+// thread at 512 threads; among those enough workgroups for the chip first, then the widest slab.  Returns NV (0: no plan)
+static int make_slab_wino(const gad_groupnorm_args* a, SlabGeo* out) {
+  const int cpg = a->C / a->G, nth = 512;
+  if (cpg % 4 != 0) return 0;
+  int best_nv = 0;
+  long best_score = -1;
+  for (int k = 1; k * cpg <= a->C && k <= 64; ++k) {
+    const int SC = k * cpg;
+    if (a->C % SC != 0 || SC % 32 != 0) continue;
+    if ((long)a->HW * SC * 4 > 128 * 1024) break;
+    const int qpr = SC / 4;
+    if (qpr > nth) break;
+    const int PL = nth / qpr, nv = (a->HW + PL - 1) / PL;
+    if (nv > 16) continue;
+    const long blocks = (long)a->B * (a->C / SC);
+    const long score = (blocks >= 512 ? (1L << 40) : blocks << 16) + SC;
+    if (score > best_score) {
+      best_score = score;
+      best_nv = nv;
+      int P2 = 1;
+      while (P2 < PL) P2 <<= 1;
+      *out = SlabGeo{a->HW, a->C, a->G, cpg, SC, qpr, PL, P2, a->C / SC, k, cpg / 4, 0};
+    }
+  }
+  return !best_nv ? 0 : best_nv <= 4 ? 4 : best_nv <= 8 ? 8 : 16;
+}
+
 // --------------------------------------------------------------- backward ----
 // g_e = dy * silu'(z) (or dy);  per channel partials  A_c = sum g_e,  Bx_c = sum g_e * xhat_e
 __device__ __forceinline__ float act_grad(float dy, float z, int silu) {
@@ -637,6 +791,51 @@ extern "C" int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream)
   hipLaunchKernelGGL(gn_apply_kernel, grid, block, 0, st, a->x, a->y, a->gamma, a->beta, (const float*)a->ws, a->mean, a->rstd, g, a->eps, a->silu,
                      a->x2, a->C1);
   GAD_LAUNCH_CHECK("gn_apply");
+  return 0;
+}
+
+
+// GroupNorm (+SiLU) forward writing the F(4x4, 3x3) Winograd input transform of its result (see gn_wino4_kernel)
+static bool gn_wino_shapes_ok(const gad_groupnorm_args* a, int32_t W) {
+  if (!a || a->B <= 0 || a->HW <= 0 || a->C <= 0 || a->G <= 0 || a->C % a->G != 0 || a->C % 32 != 0 || a->G > 256) return false;
+  if (W <= 0 || a->HW % W != 0 || (W & 3) || ((a->HW / W) & 3)) return false;
+  if (a->x2 && !(a->C1 > 0 && a->C1 < a->C && a->C1 % 4 == 0 && (a->C - a->C1) % 4 == 0)) return false;
+  return true;
+}
+extern "C" int gad_groupnorm_wino4_ok(const gad_groupnorm_args* a, int32_t W) {
+  SlabGeo sg;
+  return gn_wino_shapes_ok(a, W) && make_slab_wino(a, &sg) ? 1 : 0;
+}
+extern "C" int gad_groupnorm_silu_wino4(const gad_groupnorm_args* a, float* V, int32_t W, void* stream) {
+  GAD_CHECK(a && a->x && a->gamma && a->beta && a->mean && a->rstd && V, "gad_groupnorm_silu_wino4: null pointer");
+  GAD_CHECK(gn_wino_shapes_ok(a, W), "gad_groupnorm_silu_wino4: shapes outside the plan (C %% 32, W and H multiples of 4; C=%d G=%d HW=%d W=%d)", a->C, a->G, a->HW, W);
+  GAD_CHECK(gad_aligned16(a->x) && gad_aligned16(V) && gad_aligned16(a->gamma) && gad_aligned16(a->beta) && (!a->x2 || gad_aligned16(a->x2)),
+            "gad_groupnorm_silu_wino4: pointers must be 16-byte aligned");
+  SlabGeo sg;
+  const int nv = make_slab_wino(a, &sg);
+  GAD_CHECK(nv, "gad_groupnorm_silu_wino4: no slab plan (gad_groupnorm_wino4_ok tells)");
+  GnWino w;
+  w.V = V; w.W = W; w.TH = (a->HW / W) / 4; w.TW = W / 4;
+  w.pos_stride = (long)a->B * w.TH * w.TW * a->C;
+  const int c1 = a->x2 ? a->C1 : a->C;
+  const int bytes = a->HW * sg.SC * (int)sizeof(float);
+  hipStream_t st = (hipStream_t)stream;
+  dim3 grid(a->B * sg.nslab), block(512);
+#define GAD_GNW(NV_)                                                                                                        \
+  do {                                                                                                                      \
+    static int lds_set = 0;                                                                                                 \
+    if (bytes > lds_set) {                                                                                                  \
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(gn_wino4_kernel<NV_>), hipFuncAttributeMaxDynamicSharedMemorySize, bytes); \
+      GAD_CHECK(e == hipSuccess, "gad_groupnorm_silu_wino4: cannot reserve %d bytes of LDS: %s", bytes, hipGetErrorString(e)); \
+      lds_set = bytes;                                                                                                      \
+    }                                                                                                                       \
+    hipLaunchKernelGGL((gn_wino4_kernel<NV_>), grid, block, bytes, st, a->x, a->x2, c1, a->gamma, a->beta, a->mean, a->rstd, sg, a->eps, a->silu, w); \
+  } while (0)
+  if (nv == 4) GAD_GNW(4);
+  else if (nv == 8) GAD_GNW(8);
+  else GAD_GNW(16);
+#undef GAD_GNW
+  GAD_LAUNCH_CHECK("gn_wino4");
   return 0;
 }
 

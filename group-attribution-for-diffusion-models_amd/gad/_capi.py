@@ -74,6 +74,7 @@ class AdamArgs(C.Structure):
 GEMM_NO_PATCH, GEMM_TAP_MAJOR_K, GEMM_SCALAR_EPILOGUE, GEMM_GENERAL_LOADERS, GN_TWO_PASS = 1, 2, 4, 8, 1
 GEMM_NO_WINO = 16
 GEMM_WINO_WGRAD = 32
+GEMM_WINO_ONLY_INPUT, GEMM_WINO_SKIP_INPUT = 64, 128
 A_KC, A_MC, A_CONV, A_CONVT = 0, 1, 2, 3
 B_KC, B_MC, B_WDGRAD, B_CONV = 0, 1, 2, 3
 
@@ -95,6 +96,8 @@ SIGNATURES = {
     "gad_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
     "gad_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_groupnorm_wino4_ok": (C.c_int, [C.POINTER(GroupNormArgs), C.c_int32]),
+    "gad_groupnorm_silu_wino4": (C.c_int, [C.POINTER(GroupNormArgs), _vp, C.c_int32, _vp]),
     "gad_attention_supported": (C.c_int, [_i32]),
     "gad_attention_uses_bf16": (C.c_int, [C.POINTER(AttentionArgs), _i32]),
     "gad_attention_bwd_workspace_bytes": (_i64, [C.POINTER(AttentionArgs)]),

@@ -396,10 +396,13 @@ def _rendezvous(db_path: Optional[str], tag: str, timeout_s: float):
     """Rendezvous ahead of the final collective that cannot hang on a dead rank and cannot split the ranks: every rank
     posts an arrival key in the process group's store; RANK 0 ALONE decides - it waits for every arrival, not waiting
     for a rank the launcher has declared dead (tombstone `<db>.rank<r>.dead`, written by gad.launch when a child exits
-    non-zero) nor past `timeout_s` - and publishes the decision under `gad/<tag>/go` ("gather" or "skip:<missing ranks>");
-    every other rank polls that one key.  The store is polled with the non-blocking `check` (False = not there yet; an
-    exception = the store is gone, i.e. rank 0, which hosts it, died: skip the collective) and a sleep between polls.
-    Returns (gather: bool, missing ranks)."""
+    non-zero) nor past `timeout_s` from its own arrival - and publishes the decision under `gad/<tag>/go` ("gather" or
+    "skip:<missing ranks>"); every other rank polls that one key and has NO deadline of its own: it leaves only when rank
+    0 is known to be dead (tombstone) or the store it hosts is gone, and then says so first (`gad/<tag>/<r>/left`), which
+    rank 0 - should it be alive after all - reads before it decides, counting that rank as missing.  (A deadline of their
+    own let a late rank 0 publish "gather" to peers that had already given up, and then sit alone in the collective.)
+    The store is polled with the non-blocking `check` (False = not there yet; an exception = the store is gone, i.e. rank
+    0, which hosts it, died: skip the collective) and a sleep between polls.  Returns (gather: bool, missing ranks)."""
     import torch.distributed as dist
 
     rank, world = dist.get_rank(), dist.get_world_size()
@@ -419,10 +422,12 @@ def _rendezvous(db_path: Optional[str], tag: str, timeout_s: float):
                         missing.append(r)
                         break
                     time.sleep(0.2)
-            store.set(f"gad/{tag}/go", "gather" if not missing else "skip:" + ",".join(map(str, missing)))
-            return not missing, missing
+            missing += [r for r in range(1, world) if r not in missing and store.check([f"gad/{tag}/{r}/left"])]
+            store.set(f"gad/{tag}/go", "gather" if not missing else "skip:" + ",".join(map(str, sorted(missing))))
+            return not missing, sorted(missing)
         while not store.check([f"gad/{tag}/go"]):
-            if dead(0) or time.time() - t0 > 2 * timeout_s:         # rank 0 decides within timeout_s if it is alive
+            if dead(0):
+                store.set(f"gad/{tag}/{rank}/left", "1")
                 return False, [0]
             time.sleep(0.2)
         go = store.get(f"gad/{tag}/go").decode()

@@ -185,9 +185,16 @@ def main(argv=None) -> int:
         if any(codes):
             print(f"[gad.launch] exit codes {codes}", flush=True)
     clear_tombstones(a.db, a.gpus)
-    missing = sorted(seeds - finished_seeds(a.db))
+    # Rows may still sit only in rank shards - rank 0 died after the work was done, or the ranks skipped the collective and
+    # rank 0 never merged: consolidate them here, on the host (no GPU, no process group), so that what lds.py reads is the db.
+    from gad.coalition import _read_rows, _shard_paths, merge_shards
+    if _shard_paths(a.db):
+        moved = merge_shards(a.db)
+        print(f"[gad.launch] merged {len(moved)} row(s) left in rank shards into {a.db}", flush=True)
+    in_db = {int(r["removal_seed"]) for r in _read_rows(a.db)} if os.path.exists(a.db) else set()
+    missing = sorted(seeds - in_db)
     if missing:
-        print(f"[gad.launch] still missing after {a.requeue} requeues: {missing}", flush=True)
+        print(f"[gad.launch] still missing from {a.db} after {a.requeue} requeues: {missing}", flush=True)
         return 1
     return 0
 

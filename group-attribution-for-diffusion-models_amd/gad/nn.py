@@ -123,6 +123,15 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb_act, x2=None):
         """x2: the block input is cat([x, x2], channels) (up blocks); norm1 and conv_shortcut read both in place."""
+        if not torch.is_grad_enabled():
+            # sampling: each norm -> silu -> conv half is one fused op - where the convolution takes the Winograd F(4x4) route the
+            # norm writes the route's transformed input directly (ops.gn_silu_conv3x3_raw), else the two ordinary launches run
+            n1, n2 = self.norm1, self.norm2
+            h = ops.gn_silu_conv3x3_raw(x, x2, n1.weight, n1.bias, n1.num_groups, n1.eps, self.conv1.weight, self.conv1.bias,
+                                        rowadd=self.time_emb_proj(temb_act))
+            sc = self.conv_shortcut(x, x2=x2) if self.conv_shortcut is not None else x
+            return ops.gn_silu_conv3x3_raw(h, None, n2.weight, n2.bias, n2.num_groups, n2.eps, self.conv2.weight, self.conv2.bias,
+                                           residual=sc)
         if x2 is None:
             h, x = self.norm1.with_bypass(x, silu=True)              # x: this node's alias, for the shortcut below
         else:

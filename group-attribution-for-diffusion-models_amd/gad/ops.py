@@ -140,7 +140,8 @@ def set_operand_precision(name):
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
 # structs (gad_gemm_args.flags / gad_groupnorm_args.flags); the library itself reads no environment variable.
-KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False, "narrow_attn_fwd": False, "no_wino4": False}
+KERNEL_FLAGS = {"gemm": 0, "gn": 0, "native_dgrad": False, "two_kernel_attn_bwd": False, "narrow_attn_fwd": False, "no_wino4": False,
+                "no_gn_wino": False}
 
 
 class kernel_flags:
@@ -149,8 +150,9 @@ class kernel_flags:
     rotated weights, see `dgrad_as_forward`)"""
 
     def __init__(self, no_patch=False, tap_major_k=False, gn_two_pass=False, scalar_epilogue=False, general_loaders=False,
-                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False, no_wino=False, no_wino4=False):
+                 native_dgrad=False, two_kernel_attn_bwd=False, narrow_attn_fwd=False, no_wino=False, no_wino4=False, no_gn_wino=False):
         self.native_dgrad, self.two_kernel_attn_bwd, self.narrow_attn_fwd, self.no_wino4 = native_dgrad, two_kernel_attn_bwd, narrow_attn_fwd, no_wino4
+        self.no_gn_wino = no_gn_wino
         self.gemm = ((_capi.GEMM_NO_PATCH if no_patch else 0) | (_capi.GEMM_TAP_MAJOR_K if tap_major_k else 0)
                      | (_capi.GEMM_NO_WINO if no_wino else 0)
                      | (_capi.GEMM_SCALAR_EPILOGUE if scalar_epilogue else 0)
@@ -162,6 +164,7 @@ class kernel_flags:
         KERNEL_FLAGS["gemm"], KERNEL_FLAGS["gn"], KERNEL_FLAGS["native_dgrad"] = self.gemm, self.gn, self.native_dgrad
         KERNEL_FLAGS["two_kernel_attn_bwd"], KERNEL_FLAGS["narrow_attn_fwd"] = self.two_kernel_attn_bwd, self.narrow_attn_fwd
         KERNEL_FLAGS["no_wino4"] = self.no_wino4
+        KERNEL_FLAGS["no_gn_wino"] = self.no_gn_wino
         return self
 
     def __exit__(self, *exc):
@@ -169,10 +172,33 @@ class kernel_flags:
         return False
 
 
+# Allocation hooks for the out-of-bounds canaries (tests/test_gpu_guards.py; never set in production): SCRATCH_ALLOC(kind,
+# nbytes, device) -> uint8 tensor provides every caller-owned scratch region at EXACTLY the size the C ABI's *_bytes query
+# returns (kind: "ws" split-K / reduction workspace, "wino" Winograd scratch, "attn_ws" dQ slabs); OUT_ALLOC(shape, device)
+# provides output tensors.  The tests hand out views between poisoned guard bands and check the bands afterwards.
+SCRATCH_ALLOC = None
+OUT_ALLOC = None
+
+
+def _scratch(kind, nbytes, device):
+    if SCRATCH_ALLOC is not None:
+        return SCRATCH_ALLOC(kind, nbytes, device)
+    return torch.empty(nbytes, dtype=torch.uint8, device=device)
+
+
+def _out(shape, device):
+    if OUT_ALLOC is not None:
+        return OUT_ALLOC(tuple(shape), device)
+    return torch.empty(tuple(shape), device=device, dtype=torch.float32)
+
+
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False):
+             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False, wino_input=None):
+    """`wino_input(V)`: the caller supplies the F(4x4) Winograd input transform itself (GroupNorm writing V directly,
+    `gn_silu_conv3x3_raw`): if the planner puts this launch on an F(4x4) route the callback is run on the route's scratch and
+    the convolution starts behind its input stage (-> True); on any other route nothing is launched (-> False)."""
     lib = _capi.load()
     ws = workspace(A.device)
     a = GemmArgs()
@@ -206,7 +232,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
         a.B_wino, a.B_wino4 = _ptr(B_wino), _ptr(B_wino4)
         need = lib.gad_gemm_wino_bytes(C.byref(a))
         if need:
-            V = torch.empty(need, dtype=torch.uint8, device=A.device)      # stream-ordered: safe to drop after the launch
+            V = _scratch("wino", need, A.device)      # stream-ordered: safe to drop after the launch
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
         else:
             a.B_wino = a.B_wino4 = None
@@ -214,14 +240,24 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
         a.flags |= _capi.GEMM_WINO_WGRAD
         need = lib.gad_gemm_wino_bytes(C.byref(a))
         if need:
-            V = torch.empty(need, dtype=torch.uint8, device=A.device)
+            V = _scratch("wino", need, A.device)
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
         else:
             a.flags &= ~_capi.GEMM_WINO_WGRAD
+    if wino_input is not None:
+        if lib.gad_gemm_kernel_id(C.byref(a)) != 6 or not a.wino_ws:
+            return False
+        wino_input(V)
+        a.flags |= _capi.GEMM_WINO_SKIP_INPUT
+    if SCRATCH_ALLOC is not None:    # canary runs: the workspace at exactly the size the planner asks for this launch
+        need = lib.gad_gemm_workspace_bytes(C.byref(a))
+        ws = _scratch("ws", need, A.device) if need else None
+        a.ws, a.ws_bytes = (ws.data_ptr() if need else None), need
     if PROFILER is not None:
         PROFILER.gemm(lib, a, batch)
-        return
+        return True
     check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+    return True
 
 
 class GemmProfiler:
@@ -236,11 +272,23 @@ class GemmProfiler:
     def gemm(self, lib, a, batch):
         tile, sk, vec = C.c_int32(), C.c_int32(), C.c_int32()
         check(lib.gad_gemm_plan(C.byref(a), C.byref(tile), C.byref(sk), C.byref(vec)), "gad_gemm_plan")
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
-        s.record()
-        check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
-        e.record()
         kid = lib.gad_gemm_kernel_id(C.byref(a))
+        s, e, mid = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True), None
+        s.record()
+        if kid in (5, 6) and not (a.flags & _capi.GEMM_WINO_SKIP_INPUT):
+            # a Winograd forward launch as its two stages with an event between them - the same kernels in the same order as
+            # the plain call (GAD_GEMM_WINO_ONLY_INPUT / _SKIP_INPUT): input transform (an HBM stream) | products + output transform
+            flags = a.flags
+            mid = torch.cuda.Event(enable_timing=True)
+            a.flags = flags | _capi.GEMM_WINO_ONLY_INPUT
+            check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+            mid.record()
+            a.flags = flags | _capi.GEMM_WINO_SKIP_INPUT
+            check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+            a.flags = flags
+        else:
+            check(lib.gad_gemm(C.byref(a), _stream()), "gad_gemm")
+        e.record()
         name = self.NAMES.get((a.a_mode, a.b_mode), "gemm") + ("", "_bf16", f"_patch_w{a.g.Wo}", f"_patch_bf16_w{a.g.Wo}", f"_fewout_valu_w{a.g.Wo}", "_wino", "_wino4", "_wino4")[kid]   # (the Winograd kernels are one instance for every map width)
         if kid == 3:                         # bf16 patch kernel: fixed 128 x 128 tiles
             tile.value, sk.value = 128, 1
@@ -254,7 +302,16 @@ class GemmProfiler:
         b_elems = (a.K // max(1, g.Ho * g.Wo)) * g.H * g.W * g.C if a.b_mode == B_CONV else a.N * a.K
         extra = a.M * a.N if a.residual else 0
         nbytes = 4.0 * max(1, batch) * (a_elems + b_elems + a.M * a.N + extra)
-        self.records.append((key, 2.0 * a.M * a.N * a.K * max(1, batch), nbytes, s, e))
+        flops = 2.0 * a.M * a.N * a.K * max(1, batch)
+        # the MFMA work actually issued: Winograd F(4x4) multiplies 36 positions per 4x4 tile where the direct form multiplies
+        # 16 x 9 (36/144), F(2x2) 16 per 2x2 tile instead of 36; the weight gradient's F(4x4) form likewise
+        executed = flops * ({5: 16.0 / 36.0, 6: 0.25, 7: 0.25}.get(kid, 1.0))
+        stage = None
+        if mid is not None:
+            npos, tpx = (16, 4) if kid == 5 else (36, 16)
+            v_bytes = 4.0 * npos * (a.M // tpx) * g.C
+            stage = (mid, 4.0 * a_elems + v_bytes, v_bytes + 4.0 * (b_elems * npos / 9.0 + a.M * a.N + extra))     # input stage: x in, V out | rest: V, U in, y out (+ residual in; + the product panels out and back in the three-launch forms: not algorithmic)
+        self.records.append((key, flops, nbytes, s, e, executed, stage))
 
     def attention(self, fn, a, what):
         """Bracket a fused attention launch.  Algorithmic FLOPs: forward 4 B h Tq Tk d (Q K^T and P V), backward
@@ -268,17 +325,24 @@ class GemmProfiler:
         unit = float(a.B) * a.heads * a.Tq * a.Tk * d_alg
         qb, kb = 4.0 * a.B * a.Tq * a.heads * d_alg, 4.0 * a.B * a.Tk * a.heads * d_alg
         flops, nbytes = (4.0 * unit, 2 * qb + 2 * kb) if what == "fwd" else (10.0 * unit, 4 * qb + 4 * kb)
-        self.records.append(((f"attn_{what}_d{d_alg}", a.Tq, a.Tk, 4), flops, nbytes, s, e))
+        self.records.append(((f"attn_{what}_d{d_alg}", a.Tq, a.Tk, 4), flops, nbytes, s, e, flops, None))
 
     def summary(self):
-        """{key: dict(launches, ms, flops)} - call after a device synchronize."""
+        """{key: dict(launches, ms, flops, bytes, executed[, ms_input, bytes_input, bytes_rest])} - call after a device
+        synchronize.  flops = algorithmic (2 M N K of the direct form), executed = the MFMA work issued; Winograd forward
+        launches also carry the duration and the stream bytes of their input-transform stage."""
         out = {}
-        for key, fl, nb, s, e in self.records:
-            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0))
+        for key, fl, nb, s, e, ex, stage in self.records:
+            d = out.setdefault(key, dict(launches=0, ms=0.0, flops=0.0, bytes=0.0, executed=0.0))
             d["launches"] += 1
             d["ms"] += s.elapsed_time(e)
             d["flops"] += fl
             d["bytes"] += nb
+            d["executed"] += ex
+            if stage is not None:
+                d["ms_input"] = d.get("ms_input", 0.0) + s.elapsed_time(stage[0])
+                d["bytes_input"] = d.get("bytes_input", 0.0) + stage[1]
+                d["bytes_rest"] = d.get("bytes_rest", 0.0) + stage[2]
         return out
 
 
@@ -290,7 +354,7 @@ def _conv_out_size(h, k, stride, pad_lo, pad_hi):
 
 
 def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowadd=None, residual=None,
-                   tile_hint=0, splitk_hint=0, x2=None):
+                   tile_hint=0, splitk_hint=0, x2=None, wino_input=None):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; pad = (top, bottom, left, right).
     x2 [B,H,W,C2]: the conv input is cat([x, x2], channels) without materialising it (UpBlock2D's skip concat)."""
     _req(x, "conv x")
@@ -308,23 +372,74 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     He, We = (2 * H, 2 * W) if upsample else (H, W)
     Ho = _conv_out_size(He, KH, stride, pad[0], pad[1])
     Wo = _conv_out_size(We, KW, stride, pad[2], pad[3])
-    y = torch.empty((Bn, Ho, Wo, Cout), device=x.device, dtype=torch.float32)
+    y = _out((Bn, Ho, Wo, Cout), x.device)
     g = ConvGeom(H, W, Cin, C1, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     if residual is not None:
         _req(residual, "conv residual")
     # Winograd forms of the weight: F(4x4) wherever the output map is a multiple of 4 (it measured faster than F(2x2) at every
     # shape of tools/ab_winograd.py), F(2x2) for the other even maps; the library's planner still decides per launch
-    wino_ok = (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7, 8) and splitk_hint == 0
+    wino_ok = (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7, 8, 9, 10, 11, 12, 13, 14, 15) and splitk_hint == 0
                and tuple(pad) == (1, 1, 1, 1))
     f4_maps = Ho % 4 == 0 and Wo % 4 == 0 and not KERNEL_FLAGS.get("no_wino4")
-    gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
+    launched = gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
-             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1,
+             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1, wino_input=wino_input,
              B_wino=wino_weight(w, 2) if (wino_ok and (tile_hint == 7 or (tile_hint == 0 and not f4_maps))) else None,
              B_wino4=wino_weight(w, 4) if (wino_ok and tile_hint != 7 and f4_maps) else None,
              B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
                                        and not torch.cuda.is_current_stream_capturing()) else None)
-    return y
+    return y if launched is not False else None
+
+
+def gn_silu_conv3x3_raw(x, x2, gamma, beta, G, eps, w, bias, rowadd=None, residual=None, tile_hint=0):
+    """conv3x3(SiLU(GroupNorm(cat([x, x2])))) + bias + rowadd + residual, forward only (the sampler's ResnetBlock2D halves:
+    reference diffusers ResnetBlock2D.forward, norm1 -> silu -> conv1 (+ temb) and norm2 -> silu -> conv2 (+ shortcut)).
+    Where the convolution takes an F(4x4) Winograd route and the norm has a plan for it (`gad_groupnorm_wino4_ok`), GroupNorm
+    writes the route's transformed input V directly - the normalised activation never exists in HBM and the route's input
+    transform launch disappears; otherwise the two ordinary launches run.  Same results either way (V is bit-identical)."""
+    _req(x, "groupnorm x")
+    Bn, H, W, C1 = x.shape
+    Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
+    lib = _capi.load()
+
+    def plain():
+        h = group_norm_cat_raw(x, x2, gamma, beta, G, eps, True) if x2 is not None else group_norm(x, gamma, beta, G, eps, True)
+        return conv2d_fwd_raw(h, w, bias, 1, (1, 1, 1, 1), False, rowadd=rowadd, residual=residual, tile_hint=tile_hint)
+    if (torch.is_grad_enabled() or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != Cin or OPERAND_PRECISION[0] != 0 or KERNEL_FLAGS["gn"]
+            or KERNEL_FLAGS.get("no_gn_wino") or H % 4 or W % 4):
+        return plain()
+    mean = torch.empty((Bn, G), device=x.device, dtype=torch.float32)
+    rstd = torch.empty_like(mean)
+    a = GroupNormArgs()
+    a.x, a.gamma, a.beta, a.mean, a.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    a.B, a.HW, a.C, a.G, a.eps, a.silu = Bn, H * W, Cin, G, eps, 1
+    if x2 is not None:
+        _req(x2, "groupnorm x2")
+        a.x2, a.C1 = x2.data_ptr(), C1
+    if not lib.gad_groupnorm_wino4_ok(C.byref(a), W):
+        return plain()
+
+    def fill(V):
+        check(lib.gad_groupnorm_silu_wino4(C.byref(a), V.data_ptr(), W, _stream()), "gad_groupnorm_silu_wino4")
+    # the convolution's "input" is only a shape here: its first stage is replaced by `fill`
+    y = conv2d_fwd_raw(_ShapeOnly(x, (Bn, H, W, Cin)), w, bias, 1, (1, 1, 1, 1), False, rowadd=rowadd, residual=residual,
+                       tile_hint=tile_hint, wino_input=fill)
+    return y if y is not None else plain()
+
+
+class _ShapeOnly:
+    """Stands in for the input tensor of a convolution whose input stage another kernel has taken over: shape, device and a
+    valid aligned pointer (never dereferenced)."""
+
+    def __init__(self, t, shape):
+        self._t, self.shape, self.device, self.dtype = t, tuple(shape), t.device, t.dtype
+        self.is_cuda = t.is_cuda
+
+    def data_ptr(self):
+        return self._t.data_ptr()
+
+    def is_contiguous(self):
+        return True
 
 
 def bf16_weight(w):
@@ -521,7 +636,7 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False,
     Cout, KH, KW, _ = wk.shape
     _, Ho, Wo, _ = dy.shape
     He, We = (2 * H, 2 * W) if upsample else (H, W)
-    dxe = torch.empty((Bn, He, We, Cin), device=dy.device, dtype=torch.float32)
+    dxe = _out((Bn, He, We, Cin), dy.device)
     if (KH == 1 and KW == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not upsample and Cin % 4 == 0 and Cout % 4 == 0
             and not KERNEL_FLAGS["gemm"] & _capi.GEMM_GENERAL_LOADERS):
         # a 1x1 / stride-1 convolution (ResNet shortcuts, proj_in / proj_out of the SD transformer blocks) is a dense
@@ -546,7 +661,7 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
     Bn, H, W, Cin = x.shape
     Cout, _, KH, KW = w_like.shape
     _, Ho, Wo, _ = dy.shape
-    dwk = torch.empty((Cout, KH, KW, Cin), device=dy.device, dtype=torch.float32) if out is None else weight_krsc(out)
+    dwk = _out((Cout, KH, KW, Cin), dy.device) if out is None else weight_krsc(out)
     if (KH == 1 and KW == 1 and stride == 1 and tuple(pad) == (0, 0, 0, 0) and not upsample and Cin % 4 == 0 and Cout % 4 == 0
             and not KERNEL_FLAGS["gemm"] & _capi.GEMM_GENERAL_LOADERS):
         gemm_raw(dy, x, dwk, A_MC, B_MC, Cout, Cin, Bn * H * W, Cout, Cin, Cin, tile_hint=tile_hint, splitk_hint=splitk_hint)   # dW = dy^T x
@@ -576,7 +691,7 @@ def colsum_raw(dy2d: torch.Tensor, segments=1, out=None):
 def linear_fwd_raw(x2d, w, bias=None, residual=None, alpha=1.0):
     M, K = x2d.shape
     N = w.shape[0]
-    y = torch.empty((M, N), device=x2d.device, dtype=torch.float32)
+    y = _out((M, N), x2d.device)
     gemm_raw(x2d, w, y, A_KC, B_KC, M, N, K, K, K, N, bias=bias, residual=residual, ldr=N, alpha=alpha)
     return y
 
@@ -584,7 +699,7 @@ def linear_fwd_raw(x2d, w, bias=None, residual=None, alpha=1.0):
 def linear_dgrad_raw(dy2d, w):
     M, N = dy2d.shape
     K = w.shape[1]
-    dx = torch.empty((M, K), device=dy2d.device, dtype=torch.float32)
+    dx = _out((M, K), dy2d.device)
     gemm_raw(dy2d, w, dx, A_KC, B_MC, M, K, N, N, K, K)
     return dx
 
@@ -592,7 +707,7 @@ def linear_dgrad_raw(dy2d, w):
 def linear_wgrad_raw(dy2d, x2d, out=None):
     M, N = dy2d.shape
     K = x2d.shape[1]
-    dw = torch.empty((N, K), device=dy2d.device, dtype=torch.float32) if out is None else out
+    dw = _out((N, K), dy2d.device) if out is None else out
     gemm_raw(dy2d, x2d, dw, A_MC, B_MC, N, K, M, N, K, K)
     return dw
 
@@ -976,8 +1091,8 @@ def _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, sq, sk
 def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=True, scale=None):
     """Fused attention forward on [Bn, T, *] views (q, k, v may be column blocks of one projection output: their
     data_ptr is the column offset, ld* the row stride).  -> (o [Bn, Tq, heads*d], lse [Bn, heads, Tq] or None)"""
-    o = torch.empty((Bn, Tq, heads * d), device=q.device, dtype=torch.float32)
-    lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32) if need_lse else None
+    o = _out((Bn, Tq, heads * d), q.device)
+    lse = _out((Bn, heads, Tq), q.device) if need_lse else None
     a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv, scale)
     a.operand_precision = OPERAND_PRECISION[0]         # bf16 mode: bf16-operand instance of the fused kernel
     a.flags = _capi.ATTN_NARROW_FWD if KERNEL_FLAGS.get("narrow_attn_fwd") else 0
@@ -1014,8 +1129,8 @@ class AttentionCoreFn(torch.autograd.Function):
         Bn, Tq, Cq = q.shape
         Tk = k.shape[1]
         d = Cq // heads
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse)
+        dq, dk, dv = _out(q.shape, q.device), _out(k.shape, k.device), _out(v.shape, v.device)
+        delta = _out(lse.shape, lse.device)
         a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, Tq * Cq, Tk * Cq, Tk * Cq, ctx.scale)
         a.d_o, a.delta, a.dq, a.dk, a.dv = do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
         a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq
@@ -1025,7 +1140,7 @@ class AttentionCoreFn(torch.autograd.Function):
         a.flags = _capi.ATTN_TWO_KERNEL_BWD if KERNEL_FLAGS.get("two_kernel_attn_bwd") else 0
         need = _capi.load().gad_attention_bwd_workspace_bytes(C.byref(a))
         if need:                                         # dQ partial slabs of the single-pass kernel (one per key block)
-            slabs = torch.empty(need // 4, device=q.device, dtype=torch.float32)
+            slabs = _scratch("attn_ws", need, q.device)
             a.ws, a.ws_bytes = slabs.data_ptr(), need
         if PROFILER is not None:
             PROFILER.attention(_capi.load().gad_attention_bwd, a, "bwd")

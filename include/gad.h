@@ -129,7 +129,9 @@ typedef struct gad_gemm_args {
    * gad_wino4_weights.  With both forms given the planner takes whichever models fastest (or neither); wino_ws then holds the
    * transformed input AND the 36 product panels (gad_gemm_wino_bytes covers both), ws may be needed for a split of the batched
    * products (gad_gemm_workspace_bytes as usual).  4x fewer multiplies than the direct form; about one decimal digit less
-   * accurate than the direct fp32 kernels (still ~4e-6 of the output scale). */
+   * accurate than the direct fp32 kernels (still ~4e-6 of the output scale).  Large launches run the one-launch form
+   * (csrc/wino4_fused.hip: all 36 products and the output transform in one kernel, wino_ws holds V only); the planner decides,
+   * tile_hint 9 / 10 force the one-launch / three-launch forms (tests, A/B tools). */
   const float* B_wino4;
 } gad_gemm_args;
 enum gad_gemm_flags {
@@ -140,7 +142,13 @@ enum gad_gemm_flags {
   GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
   GAD_GEMM_TAP_MAJOR_K = 2,   /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
   GAD_GEMM_SCALAR_EPILOGUE = 4, /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */
-  GAD_GEMM_GENERAL_LOADERS = 8  /* dense operands with K % 32 == 0: the masking loaders instead of the lean (row-clamping) ones */
+  GAD_GEMM_GENERAL_LOADERS = 8, /* dense operands with K % 32 == 0: the masking loaders instead of the lean (row-clamping) ones */
+  /* Stages of a Winograd forward launch, so that a caller can put an event between them (bench.py's per-stage roofline) or
+   * supply the transformed input itself: ONLY_INPUT runs the input transform x -> V into wino_ws and returns; SKIP_INPUT
+   * takes wino_ws as already holding V (written by an ONLY_INPUT call with the same arguments) and runs the rest.  The two
+   * calls back to back are the same kernels in the same order as one plain call: bit-identical. */
+  GAD_GEMM_WINO_ONLY_INPUT = 64,
+  GAD_GEMM_WINO_SKIP_INPUT = 128
 };
 
 int64_t gad_gemm_workspace_bytes(const gad_gemm_args* a);
@@ -207,6 +215,15 @@ int64_t gad_groupnorm_workspace_bytes(const gad_groupnorm_args* a);
 int gad_groupnorm_one_pass(const gad_groupnorm_args* a);
 int gad_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream);
 int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
+/* Forward whose consumer is a 3x3 / stride-1 convolution on the Winograd F(4x4, 3x3) route of gad_gemm (ResnetBlock2D's
+ * norm -> silu -> conv, reference diffusers ResnetBlock2D.forward): writes V[36][B * (H/4) * (W/4)][C] = B^T y_patch B - what
+ * the route's own input transform would make of y - instead of y (a->y is ignored and may be NULL), plus mean / rstd.  The
+ * convolution then runs with GAD_GEMM_WINO_SKIP_INPUT and wino_ws = V.  W = the map's width (HW = H * W, both multiples of 4),
+ * C % 32 == 0, channels per group a multiple of 4; gad_groupnorm_wino4_ok tells whether a plan exists (the normalised
+ * (image, channel slab) must fit 128 KB of LDS: up to 32 x 32 maps).  Same statistics, same normalisation arithmetic and the
+ * same transform arithmetic as the two separate launches: V is bit-identical to theirs. */
+int gad_groupnorm_wino4_ok(const gad_groupnorm_args* a, int32_t W);
+int gad_groupnorm_silu_wino4(const gad_groupnorm_args* a, float* V, int32_t W, void* stream);
 
 /* ------------------------------------------------------------------------------
  * Fused attention core: o = softmax(scale * q k^T) v per (batch, head), the score matrix never leaves the CU

@@ -1,5 +1,5 @@
 """Child process of tests/test_sharding_gloo.py: one gloo rank of run_sharded over a stub engine.
-argv: db_path n_seeds mode      mode: ok | raise_once:<seed> | raise_always:<seed> | die:<seed>"""
+argv: db_path n_seeds mode [rendezvous timeout s]      mode: ok | raise_once:<seed> | raise_always:<seed> | die:<seed> | slow:<seed>:<seconds>"""
 import os
 import sys
 
@@ -17,12 +17,16 @@ class StubEngine:
 
     def __init__(self, mode):
         self.kind, _, seed = mode.partition(":")
+        seed, _, self.secs = seed.partition(":")
         self.bad = int(seed) if seed else -1
         self.calls = {}
 
     def run_coalition(self, seed, verbose=False):
         self.calls[seed] = self.calls.get(seed, 0) + 1
         if seed == self.bad:
+            if self.kind == "slow":
+                import time
+                time.sleep(float(self.secs))                   # a straggler: alive, late
             if self.kind == "die":
                 os._exit(17)                                   # a GPU fault / OOM kill: no exception, no cleanup
             if self.kind == "raise_always" or (self.kind == "raise_once" and self.calls[seed] == 1):
@@ -38,6 +42,7 @@ if __name__ == "__main__":
     world = int(os.environ.get("WORLD_SIZE", "1"))
     if world > 1:
         dist.init_process_group("gloo")
-    run_sharded(StubEngine(mode), list(range(n)), db_path=db, retries=1, rendezvous_timeout_s=60)
+    tmo = float(sys.argv[4]) if len(sys.argv) > 4 else 60
+    run_sharded(StubEngine(mode), list(range(n)), db_path=db, retries=1, rendezvous_timeout_s=tmo)
     if world > 1:
         dist.destroy_process_group()

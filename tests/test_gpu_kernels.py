@@ -233,15 +233,18 @@ WINO_CASES = [
 ]
 
 
-@pytest.mark.parametrize("form", [2, 4])
+@pytest.mark.parametrize("form", [2, 4, 9, 10, 11])
 @pytest.mark.parametrize("B,Cin,Cout,H,W,ups,epi", WINO_CASES)
 def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi, form):
     """Winograd routes against fp64 - with bias, the time-embedding row and the residual in the epilogue - and against the
     direct kernels on the same inputs.  F(2x2, 3x3): wino_input_kernel + wino_gemm_kernel on gad_wino_weights' U (tile_hint 7
-    forces it); F(4x4, 3x3): wino4_input_kernel + 36 batched products on the generic engine + wino4_output_kernel on
-    gad_wino4_weights' U (tile_hint 8).  Same tolerance as every fp32 contraction (F(4x4) measures ~4e-6 of the output scale,
-    a decimal digit more than the direct kernels), not bit-identical, deterministic."""
-    if form == 4 and ((H * (2 if ups else 1)) % 4 or (W * (2 if ups else 1)) % 4):
+    forces it); F(4x4, 3x3) on gad_wino4_weights' U: the planner's form (tile_hint 8), wino4_input_kernel + wino4_fused_kernel -
+    all 36 products and the whole output transform in one launch, on 32-tile blocks / two workgroups per CU (tile_hint 9) or 64-tile
+    blocks / one per CU (tile_hint 11) -, or the three-launch forms wino4_input_kernel +
+    products (36 batched on the generic engine, or the six-position kernel) + wino4_output_kernel (tile_hint 10).  Same tolerance
+    as every fp32 contraction (F(4x4) measures ~4e-6 of the output scale, a decimal digit more than the direct kernels), not
+    bit-identical, deterministic."""
+    if form != 2 and ((H * (2 if ups else 1)) % 4 or (W * (2 if ups else 1)) % 4):
         pytest.skip("F(4x4) needs output maps that are multiples of 4")
     x, w, b = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=1 / math.sqrt(Cin * 9)), rnd(Cout, seed=3)
     want = conv_ref(x, w, b if epi else None, 1, (1, 1, 1, 1), ups)
@@ -250,7 +253,7 @@ def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi, form):
         want = want + temb.double()[:, :, None, None] + res.double()
     kw = dict(rowadd=temb.to(dev), residual=nhwc(res)) if epi else {}
     xg, wg, bg = nhwc(x), cl_weight(w), b.to(dev) if epi else None
-    hint = 7 if form == 2 else 8
+    hint = {2: 7, 4: 8, 9: 9, 10: 10, 11: 11}[form]
     ops.PROFILER = prof = ops.GemmProfiler()
     try:
         y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw)
@@ -258,6 +261,8 @@ def test_conv_fwd_winograd(ops, B, Cin, Cout, H, W, ups, epi, form):
     finally:
         ops.PROFILER = None
     assert [k[0] for k in prof.summary()] == ["conv_fwd_wino" if form == 2 else "conv_fwd_wino4"], list(prof.summary())
+    if form in (9, 10, 11):
+        assert [k[1] for k in prof.summary()] == [{9: 32, 10: 128, 11: 64}[form]], list(prof.summary())       # tile 32 / 64 name the one-launch forms
     y = ops.conv2d_fwd_raw(xg, wg, bg, 1, (1, 1, 1, 1), ups, tile_hint=hint, **kw)
     close(y.permute(0, 3, 1, 2), want, atol=3e-5)
     with ops.kernel_flags(no_wino=True):
@@ -1282,3 +1287,88 @@ def test_lean_dense_loaders_are_bit_identical_to_the_masking_ones(ops, prec):
         xin = x if x2 is None else torch.cat([x, x2], -1)
         want = xin.double().reshape(-1, C1 + C2) @ w.double().reshape(Cout, -1).t() + b.double()
         close(got.reshape(-1, Cout), want, rtol=3e-4, atol=3e-4)
+
+
+GN_WINO_CASES = [  # B, H, W, C (C1 of it from the first source, 0 = single source), groups
+    (4, 32, 32, 128, 0, 32), (2, 16, 16, 256, 0, 32), (3, 8, 8, 512, 256, 32), (2, 16, 16, 384, 256, 32), (2, 4, 4, 256, 0, 32),
+    (2, 32, 32, 256, 128, 32), (1, 16, 12, 96, 0, 8), (8, 32, 32, 96, 0, 32),
+]
+
+
+@pytest.mark.parametrize("B,H,W,C,C1,G", GN_WINO_CASES)
+def test_groupnorm_writes_the_winograd_input_transform(ops, B, H, W, C, C1, G):
+    """gad_groupnorm_silu_wino4 (norm -> silu -> F(4x4) input transform in one kernel, the normalised activation only in LDS)
+    against the two launches it replaces - gad_groupnorm_silu_fwd, then the route's own input stage
+    (GAD_GEMM_WINO_ONLY_INPUT) - on the same inputs: V bit-identical, mean / rstd bit-identical; two-source inputs
+    (UpBlock2D's cat read in place); a shape without a plan (3 channels per group) says so."""
+    from gad import _capi
+    lib = _capi.load()
+    xs = rnd(B, H, W, C, seed=1).to(dev)
+    x, x2 = (xs, None) if not C1 else (xs[..., :C1].contiguous(), xs[..., C1:].contiguous())
+    gamma, beta = (1 + 0.1 * rnd(C, seed=2)).to(dev), (0.1 * rnd(C, seed=3)).to(dev)
+    a = _capi.GroupNormArgs()
+    mean, rstd = torch.empty(B, G, device=dev), torch.empty(B, G, device=dev)
+    a.x, a.gamma, a.beta, a.mean, a.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+    a.B, a.HW, a.C, a.G, a.eps, a.silu = B, H * W, C, G, 1e-5, 1
+    if x2 is not None:
+        a.x2, a.C1 = x2.data_ptr(), C1
+    ok = lib.gad_groupnorm_wino4_ok(_capi.C.byref(a), W)
+    assert ok == (1 if (C // G) % 4 == 0 else 0)
+    T = B * (H // 4) * (W // 4)
+    V = torch.full((36 * T * C + 64,), 7.0, device=dev)
+    if not ok:
+        with pytest.raises(_capi.GadError, match="no slab plan|outside the plan"):
+            _capi.check(lib.gad_groupnorm_silu_wino4(_capi.C.byref(a), V.data_ptr(), W, ops._stream()), "gad_groupnorm_silu_wino4")
+        return
+    _capi.check(lib.gad_groupnorm_silu_wino4(_capi.C.byref(a), V.data_ptr(), W, ops._stream()), "gad_groupnorm_silu_wino4")
+    assert bool((V[36 * T * C:] == 7.0).all())                                     # nothing past the 36 panels
+    # the two launches it replaces
+    y = ops.group_norm_cat_raw(x, x2, gamma, beta, G, 1e-5, True) if x2 is not None else ops.group_norm(xs, gamma, beta, G, 1e-5, True)
+    w = cl_weight(rnd(64, C, 3, 3, seed=4, scale=0.05))
+    grabbed = []
+
+    def grab(kind, n, device):
+        t = torch.empty(n, dtype=torch.uint8, device=device)
+        if kind == "wino":
+            grabbed.append(t)
+        return t
+    ops.SCRATCH_ALLOC = grab
+    try:
+        with ops.kernel_flags():
+            ops.KERNEL_FLAGS["gemm"] |= _capi.GEMM_WINO_ONLY_INPUT
+            ops.conv2d_fwd_raw(y, w, None, tile_hint=10)
+    finally:
+        ops.SCRATCH_ALLOC = None
+    Vref = grabbed[0].view(torch.float32)[:36 * T * C]
+    assert torch.equal(V[:36 * T * C], Vref)
+    m2, r2 = torch.empty(B, G, device=dev), torch.empty(B, G, device=dev)
+    a.y, a.mean, a.rstd = torch.empty_like(y).data_ptr(), m2.data_ptr(), r2.data_ptr()
+    ws = ops.workspace(dev)
+    a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    _capi.check(lib.gad_groupnorm_silu_fwd(_capi.C.byref(a), ops._stream()), "gad_groupnorm_silu_fwd")
+    if lib.gad_groupnorm_one_pass(_capi.C.byref(a)):                              # same arithmetic as the one-pass slab plan
+        assert torch.equal(mean, m2) and torch.equal(rstd, r2)
+    else:
+        close(mean, m2, atol=1e-6, rtol=1e-6)
+        close(rstd, r2, atol=1e-5, rtol=1e-5)
+
+
+@pytest.mark.parametrize("B,H,C,C1,Cout,epi", [(64, 32, 128, 0, 128, "rowadd"), (64, 32, 128, 0, 128, "residual"), (32, 32, 384, 256, 128, "rowadd"),
+                                                (64, 16, 256, 0, 256, "residual"), (256, 8, 512, 256, 256, "rowadd"), (2, 8, 256, 0, 256, "rowadd")])
+def test_fused_norm_silu_conv_matches_the_separate_launches(ops, B, H, C, C1, Cout, epi):
+    """ops.gn_silu_conv3x3_raw (the sampler's ResnetBlock2D halves) = group norm, then convolution: bit-identical, whatever route
+    the planner gives the convolution (the last case is too small for Winograd: the plain launches run)."""
+    xs = rnd(B, H, H, C, seed=1).to(dev)
+    x, x2 = (xs, None) if not C1 else (xs[..., :C1].contiguous(), xs[..., C1:].contiguous())
+    gamma, beta = (1 + 0.1 * rnd(C, seed=2)).to(dev), (0.1 * rnd(C, seed=3)).to(dev)
+    w, b = cl_weight(rnd(Cout, C, 3, 3, seed=4, scale=1 / math.sqrt(9 * C))), rnd(Cout, seed=5).to(dev)
+    kw = dict(rowadd=rnd(B, Cout, seed=6).to(dev)) if epi == "rowadd" else dict(residual=rnd(B, H, H, Cout, seed=7).to(dev))
+    with torch.no_grad():
+        got = ops.gn_silu_conv3x3_raw(x, x2, gamma, beta, 32, 1e-5, w, b, **kw)
+        with ops.kernel_flags(no_gn_wino=True):
+            want = ops.gn_silu_conv3x3_raw(x, x2, gamma, beta, 32, 1e-5, w, b, **kw)
+    assert torch.equal(got, want)
+    ref = conv_ref(torch.nn.functional.silu(torch.nn.functional.group_norm(xs.cpu().double().permute(0, 3, 1, 2), 32, gamma.cpu().double(), beta.cpu().double(), 1e-5)),
+                   w.cpu().double(), b.cpu(), 1, (1, 1, 1, 1), False)
+    ref = ref + (kw["rowadd"].cpu().double()[:, :, None, None] if epi == "rowadd" else kw["residual"].cpu().double().permute(0, 3, 1, 2))
+    close(got.permute(0, 3, 1, 2), ref, atol=5e-5, rtol=5e-5)

@@ -1,0 +1,53 @@
+"""End-to-end statement of what the lower-precision Winograd routes cost in SCORE terms (north_star: per-
+coalition FID within a stated tolerance; reference unlearn.py:807-837 computes the behaviours this compares).
+
+The same coalitions - same removal seeds, same host-drawn batches / noise / timesteps / sampler noise, same base weights -
+run through the coalition engine three times: planner default (Winograd F(4x4) one-launch / three-launch forms, F(2x2) for
+the other even maps), F(4x4) switched off, every Winograd route switched off (direct LDS-patch kernels, the round-2 path).
+Width [64, 128, 128, 128] at 32 x 32, training B = 128, sampler launches of 256 images: every 3x3 / stride-1 convolution of this
+model is Winograd-eligible and the planner takes the route (asserted).  The tolerance asserted here is the one DESIGN.md §3
+states: per-coalition FID within 2e-3 relative of the direct kernels' (measured on this shape: see profiles/r04_winograd_drift.txt;
+at full size the same comparison is recorded by tools/e2e_winograd_drift.py full)."""
+import os
+
+import pytest
+import torch
+
+pytestmark = pytest.mark.gpu
+FID_RTOL = 2e-3
+
+
+def test_per_coalition_scores_agree_across_kernel_families(monkeypatch):
+    monkeypatch.setenv("GAD_SYNTH_SCALE", "0.2")
+    from gad import ops
+    from gad.coalition import CoalitionEngine
+    eng = CoalitionEngine("cifar100", device="cuda:0", gd_steps=40, n_samples=512, num_inference_steps=20, fuse=8,
+                          unet_overrides=dict(block_out_channels=(64, 128, 128, 128)))
+    # the route under test is really taken: profile one sampler forward
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        model, _ = eng.load_base()
+        model.eval()
+        with torch.no_grad():
+            model.forward_nhwc(torch.zeros(256, 32, 32, 3, device="cuda:0"), torch.zeros(256, device="cuda:0", dtype=torch.int64))
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    names = [k[0] for k in prof.summary()]
+    assert any(n == "conv_fwd_wino4" for n in names), names
+    fams = {"default": {}, "no_wino4": dict(no_wino4=True), "direct": dict(no_wino=True)}
+    res = {}
+    for name, flags in fams.items():
+        with ops.kernel_flags(**flags):
+            res[name] = [eng.run_coalition(s, verbose=False) for s in (0, 1)]
+    for name in ("default", "no_wino4"):
+        for a, b in zip(res[name], res["direct"]):
+            assert a.n_remaining == b.n_remaining and a.remaining_classes == b.remaining_classes     # bookkeeping: bit-exact
+            rel = abs(a.fid_value - b.fid_value) / abs(b.fid_value)
+            print(f"{name} seed {a.removal_seed}: fid {a.fid_value:.6f} vs direct {b.fid_value:.6f} (rel {rel:.2e})")
+            assert rel < FID_RTOL, (name, a.removal_seed, a.fid_value, b.fid_value)
+            assert abs(a.inception_score - b.inception_score) < 2e-3 * abs(b.inception_score)
+            assert abs(a.precision - b.precision) <= 0.02 and abs(a.recall - b.recall) <= 0.02
+    # the run itself is reproducible: same flags, same seed -> the same record bit for bit
+    again = eng.run_coalition(0, verbose=False)
+    assert again.fid_value == res["default"][0].fid_value
