@@ -411,20 +411,32 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
             "algorithmic_tflops": alg_tf, "algorithmic_speedup_vs_direct_peak": alg_tf / peak_tf,
             "algorithmic_bytes_per_launch": alg_bytes, "share_of_step_time": d["ms"] / (dt * 1e3)}
     if "ms_input" in d:
-        # the two stages of the route, each against the roof that bounds it (an event between the two launches)
-        t_in, t_rest = d["ms_input"], d["ms"] - d["ms_input"]
+        # the two stages of the route, each against the roof that bounds it (an event between the two launches).  Launches whose
+        # V was written by the producing GroupNorm (gn_wino4_kernel: the sampler's norm -> silu -> conv halves) have no input
+        # stage of their own: `stage_input_launches` of the family's `launches` ran one.
+        t_in, t_rest, n_in = d["ms_input"], d["ms"] - d["ms_input"], d.get("n_input", 0)
+        if n_in:
+            roof.update({
+                "stage_input_kernel": "wino4_input_kernel" if "_wino4" in nm else "wino_input_kernel",
+                "stage_input_bound": "hbm", "stage_input_launches": n_in, "stage_input_us": t_in / n_in * 1e3,
+                "stage_input_gbps": d["bytes_input"] / t_in / 1e6, "stage_input_frac_of_hbm_peak": d["bytes_input"] / t_in / 1e6 / HBM_PEAK_GBPS})
         roof.update({
-            "stage_input_kernel": "wino4_input_kernel" if "_wino4" in nm else "wino_input_kernel",
-            "stage_input_bound": "hbm", "stage_input_us": t_in / d["launches"] * 1e3,
-            "stage_input_gbps": d["bytes_input"] / t_in / 1e6, "stage_input_frac_of_hbm_peak": d["bytes_input"] / t_in / 1e6 / HBM_PEAK_GBPS,
             "stage_products_kernel": kname.split(" + ", 1)[1].split(" (")[0],
             "stage_products_bound": "mfma", "stage_products_us": t_rest / d["launches"] * 1e3,
             "stage_products_tflops_executed": d["executed"] / t_rest / 1e9,
             "stage_products_frac_of_mfma_peak": d["executed"] / t_rest / 1e9 / peak_tf,
+            "stage_products_algorithmic_bytes_per_launch": d["bytes_rest"] / d["launches"],
             "stage_products_algorithmic_gbps": d["bytes_rest"] / t_rest / 1e6,
             "stage_products_frac_of_hbm_peak": d["bytes_rest"] / t_rest / 1e6 / HBM_PEAK_GBPS,
-            "stage_note": ("input transform: x in, V out (2.25x the input for F(4x4)), a pure HBM stream; products: V and U in, y out "
-                           "(+ residual in) - MFMA-bound by design, its algorithmic stream rate is listed against the HBM roof too")})
+            "stage_note": ("input transform: x in, V out (2.25x the input for F(4x4)), a pure HBM stream - run by the route only where the "
+                           "producing GroupNorm did not write V itself; products: V and U in, y out (+ residual in) - MFMA-bound by design, "
+                           "its algorithmic stream rate is listed against the HBM roof too")})
+        if traffic and j.get("traffic_is") == "products_stage":
+            # the stored counters are of the products kernel alone: against the convolution's algorithmic bytes (x + w + y: `traffic_ratio`)
+            # and against what that stage must move given that V is its input (`traffic_ratio_vs_stage_bytes`)
+            roof["traffic_ratio_vs_stage_bytes"] = traffic / (d["bytes_rest"] / d["launches"])
+            roof["traffic_note"] = ("HBM bytes per launch of the products kernel (the whole route where GroupNorm wrote V); launches that ran "
+                                    "wino4_input_kernel add its x-in / V-out stream: profiles/pmc_summary.json lists it per launch")
     # every forward launch of the route's family, whatever form the planner gave it (one-launch / three-launch)
     fam = [v for k, v in summ.items() if k[0] == nm]
     if len(fam) > 1:

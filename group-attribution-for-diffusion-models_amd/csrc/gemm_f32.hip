@@ -2701,7 +2701,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
   if ((!a->B_wino && !a->B_wino4) || a->operand_precision != 0 || a->a_mode != GAD_A_CONV || a->b_mode != GAD_B_KC || a->A2 || a->A_k2) return false;
   const int He = g.upsample ? 2 * g.H : g.H, We = g.upsample ? 2 * g.W : g.W;
   if (g.KH != 3 || g.KW != 3 || g.stride != 1 || g.pad_t != 1 || g.pad_l != 1 || g.Ho != He || g.Wo != We || (He & 1) || (We & 1)) return false;
-  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7 && a->tile_hint != 8 && a->tile_hint != 9 && a->tile_hint != 10 && a->tile_hint != 11 && a->tile_hint != 12 && a->tile_hint != 13 && a->tile_hint != 14 && a->tile_hint != 15) || a->splitk_hint > 0 || a->batch > 1) return false;
+  if (g.C % BK != 0 || g.ldx % 4 != 0 || a->N % 4 != 0 || a->N < 64 || (a->tile_hint != 0 && a->tile_hint != 7 && a->tile_hint != 8 && a->tile_hint != 9 && a->tile_hint != 10 && a->tile_hint != 11) || a->splitk_hint > 0 || a->batch > 1) return false;
   if (a->flags & (GAD_GEMM_NO_WINO | GAD_GEMM_NO_PATCH | GAD_GEMM_SCALAR_EPILOGUE | GAD_GEMM_TAP_MAJOR_K)) return false;
   if (a->rowadd && a->rows_per_group != g.Ho * g.Wo) return false;
   if (a->M % (g.Ho * g.Wo) != 0) return false;
@@ -2709,7 +2709,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
                       (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
                       (!a->residual || (gad_aligned16(a->residual) && a->ldr % 4 == 0));
   if (!vec_ok) return false;
-  const bool force4 = a->tile_hint >= 8 && a->tile_hint <= 15;   // 8: planner's F(4x4) form, 9 / 11: the one-launch form on 32- / 64-tile blocks, 10: the three-launch forms
+  const bool force4 = a->tile_hint >= 8 && a->tile_hint <= 11;   // 8: planner's F(4x4) form, 9 / 11: the one-launch form on 32- / 64-tile blocks, 10: the three-launch forms
   const bool f2_ok = a->B_wino != nullptr && (long)a->M / 4 < (1L << 30) && !force4;
   const bool f4_ok = a->B_wino4 != nullptr && (He & 3) == 0 && (We & 3) == 0 && a->tile_hint != 7;
   // Modelled times (calibrated on tools/ab_winograd.py, profiles/r03_ab_winograd.txt).  Transform launches stream their bytes
@@ -2758,7 +2758,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     const double mb3 = (p4.fused4 ? 24.0 : 36.0) * p4.T * a->N * 4.0;
     const double t3 = t_gemm + (mb3 + y_bytes) / 4.9e12 + 12e-6;
     const bool full_ok = !(a->flags & GAD_GEMM_GENERAL_LOADERS) && a->tile_hint != 10;
-    if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (a->tile_hint >= 12 && a->tile_hint <= 15) || (t_full < t3 && blocks32 >= 320))) {
+    if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (t_full < t3 && blocks32 >= 320))) {
       p4.fused4 = 2;
       p4.bm = a->tile_hint == 11 ? 64 : 32; p4.bn = 64;
       p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm);
@@ -3127,7 +3127,6 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
         w.fdHoWo = make_fastdiv((unsigned)(wi.TH * wi.TW));
         w.fdWo = make_fastdiv((unsigned)wi.TW);
         w.tiles_m = wp.tiles_m; w.tiles_n = wp.tiles_n;
-        w.splitk = a->tile_hint == 12 ? 1 : a->tile_hint == 13 ? 2 : a->tile_hint == 14 ? 4 : a->tile_hint == 15 ? 3 : 0;      // timing experiments (wrong results): see wino4_fused.hip
         GAD_CHECK((long)wp.tiles_m * wp.tiles_n < (1L << 31), "gad_gemm: Winograd grid too large");
         gadk::launch_wino4_fused(w, wp.bm, st);
         GAD_LAUNCH_CHECK("gad_gemm(winograd F4 fused products + output transform)");

@@ -266,14 +266,37 @@ __device__ __forceinline__ f32x4 mfma16(float a, float b, f32x4 c) { return __bu
 constexpr int EPI2_LD = 36;                      // scratch row stride (floats): rows e and e + 4 of a ds_write_b32 half land 16 banks apart
 constexpr int EPI2_WAVE = 16 * EPI2_LD;
 
-template <int SUB, int NST>
-__global__ __launch_bounds__(NTHREADS, 2) void wino4_fused2_kernel(const DevArgs p) {
-  constexpr int BM = 32, BN = 64, D = NST - 1;
+// k-contiguous operand rows by LDS-DMA for a workgroup of NTH threads (WinoKC's layout: slot i of a thread = row (tid >> 3) + (NTH / 8) i,
+// 16-byte chunk (tid & 7) swizzled by the row; rows beyond the operand clamp to the last one)
+template <int ROWS, int NTH>
+struct RowsKC {
+  static constexpr int RPS = NTH / 8, NS = ROWS / RPS;
+  static_assert(ROWS % RPS == 0, "whole slots");
+  const float* ptr[NS];
+  long off;
+  __device__ void init(const float* b, int ld, int row0, int nrows) {
+#pragma unroll
+    for (int i = 0; i < NS; ++i) {
+      int r = row0 + (int)(threadIdx.x >> 3) + RPS * i;
+      r = r < nrows ? r : nrows - 1;
+      ptr[i] = b + (long)r * ld + ((threadIdx.x & 7) ^ ((threadIdx.x >> 4) & 7)) * 4;
+    }
+    off = 0;
+  }
+  __device__ __forceinline__ const float* src(int i) const { return ptr[i] + off; }
+  __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * 8 + RPS * i) * BK; }
+};
+
+// WM = waves along the tiles: 2 (32 tiles, 256 threads, two workgroups per CU) or 4 (64 tiles, 512 threads, one workgroup per CU
+// whose eight waves share ONE U tile: two thirds of the LDS-DMA traffic per FLOP)
+template <int WM, int SUB, int NST>
+__global__ __launch_bounds__(128 * WM, 2) void wino4_fused2_kernel(const DevArgs p) {
+  constexpr int NTH = 128 * WM, BM = 16 * WM, BN = 64, D = NST - 1;
   constexpr int A_TILE = BK * BM, SUBT = BK * (BM + BN), STAGE = SUB * SUBT;
-  constexpr int NDMA = 3 * SUB;
-  static_assert(NST * STAGE >= 4 * EPI2_WAVE, "the epilogue scratch lives in the ring");
-  using AL = WinoKC<BM>;
-  using BL = WinoKC<BN>;
+  using AL = RowsKC<BM, NTH>;
+  using BL = RowsKC<BN, NTH>;
+  constexpr int NDA = AL::NS, NDB = BL::NS, NDS = NDA + NDB, NDMA = NDS * SUB;      // LDS-DMA wave-instructions per thread: per 32-deep sub-tile, per stage-step
+  static_assert(NST * STAGE >= 2 * WM * EPI2_WAVE, "the epilogue scratch lives in the ring");
   __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
   const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -307,21 +330,20 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_fused2_kernel(const DevArgs
     }
   }
 
-  const int dbg = p.splitk;                     // TIMING EXPERIMENTS ONLY (tools/ab_winograd.py): 1 = no epilogue stores, 2 = no DMA in the loop, 4 = DMA re-reads step 0
   int pp = 0, pk = 0;
   const long wrapA = p.sA0 - (long)kcs * (BK * SUB), wrapB = p.sB0 - (long)kcs * (BK * SUB);
   auto advance = [&]() {
-    const bool last = (pp == 35 && pk == kcs - 1) || (dbg & 4), wrap = pk + 1 == kcs;
+    const bool last = pp == 35 && pk == kcs - 1, wrap = pk + 1 == kcs;
     al.off += last ? 0L : (wrap ? wrapA + BK * SUB : (long)(BK * SUB));
     bl.off += last ? 0L : (wrap ? wrapB + BK * SUB : (long)(BK * SUB));
     pk = last ? pk : (wrap ? 0 : pk + 1);
     pp = (wrap && !last) ? pp + 1 : pp;
   };
-  auto issue = [&](int d, float* stage) {        // d-th DMA of a stage-step: sub-tile d / 3, slot d % 3 = A0, B0, B1
-    const int sub = d / 3, slot = d - 3 * sub;
+  auto issue = [&](int d, float* stage) {        // d-th DMA of a stage-step: sub-tile d / NDS, slot d % NDS = A slots, then B slots
+    const int sub = d / NDS, slot = d - NDS * sub;
     float* base = stage + sub * SUBT;
-    if (slot == 0) glds16(al.src(0) + sub * BK, AL::dma_dst(base, 0));
-    else glds16(bl.src(slot - 1) + sub * BK, BL::dma_dst(base + A_TILE, slot - 1));
+    if (slot < NDA) glds16(al.src(slot) + sub * BK, AL::dma_dst(base, slot));
+    else glds16(bl.src(slot - NDA) + sub * BK, BL::dma_dst(base + A_TILE, slot - NDA));
   };
 #pragma unroll
   for (int s = 0; s < D; ++s) {
@@ -358,7 +380,7 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_fused2_kernel(const DevArgs
           const int pc = (sub * 2 + g) * 4 + j;                 // piece = two MFMAs (the two channel tiles)
           cur[0] = mfma16(fa[fi][j], fb[fi][0][j], cur[0]);
           cur[1] = mfma16(fa[fi][j], fb[fi][1][j], cur[1]);
-          if (pc < NDMA && !(dbg & 2)) issue(pc, pf);
+          if (pc < NDMA) issue(pc, pf);
           if (j == 1 && !(sub == SUB - 1 && g == 1)) {         // the next half-step's fragments
             const int ng = g ^ 1, nsub = g == 1 ? sub + 1 : sub;
             const float* nb = st + nsub * SUBT;
@@ -478,12 +500,12 @@ __global__ __launch_bounds__(NTHREADS, 2) void wino4_fused2_kernel(const DevArgs
 #pragma unroll
       for (int q = 0; q < 2; ++q) {
         f32x4 v = *reinterpret_cast<const f32x4*>(scratch + (rr + 8 * q) * EPI2_LD + c4);
-        if (!m_ok[q] || ((dbg & 1) && v[0] != 12345.f)) continue;
+        if (!m_ok[q]) continue;
         const long pix = pix0[q] + (long)i * p.g.Wo + j;
         v = f32x4{__builtin_fmaf(v[0], p.alpha, ra[q][0]), __builtin_fmaf(v[1], p.alpha, ra[q][1]),
                   __builtin_fmaf(v[2], p.alpha, ra[q][2]), __builtin_fmaf(v[3], p.alpha, ra[q][3])};
         v += rs[j][q];
-        *reinterpret_cast<f32x4*>(p.C + pix * p.ldc + n) = v;
+        *reinterpret_cast<f32x4*>(p.C + pix * p.ldc + n) = v;      // (plain accesses: non-temporal ones measured 5-15 % slower, profiles/r04_wino4_fused_experiments.txt)
       }
     }
   }
@@ -500,9 +522,9 @@ void launch_wino4_fused(const DevArgs& w, int bm, hipStream_t st) {
   if (bm == 64) {
     if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused_kernel<2, 3>), grid, block, 0, st, w);
     else hipLaunchKernelGGL((wino4_fused_kernel<1, 4>), grid, block, 0, st, w);
-  } else {
-    if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused2_kernel<2, 3>), grid, block, 0, st, w);
-    else hipLaunchKernelGGL((wino4_fused2_kernel<1, 4>), grid, block, 0, st, w);
+  } else {                                       // (WM = 4 - 64 tiles on eight waves - measured no faster: profiles/r04_wino4_fused_experiments.txt)
+    if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused2_kernel<2, 2, 3>), grid, block, 0, st, w);
+    else hipLaunchKernelGGL((wino4_fused2_kernel<2, 1, 4>), grid, block, 0, st, w);
   }
 }
 

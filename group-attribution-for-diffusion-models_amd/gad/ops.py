@@ -215,7 +215,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.alpha = alpha
     a.bias, a.rowadd, a.residual = _ptr(bias), _ptr(rowadd), _ptr(residual)
     a.rows_per_group = rows_per_group
-    a.ld_rowadd = rowadd.shape[-1] if rowadd is not None else 0
+    a.ld_rowadd = (rowadd.stride(0) if rowadd.ndim == 2 else rowadd.shape[-1]) if rowadd is not None else 0      # (a column block of a wider matrix: nn.UNet2DModel._temb_rows)
     a.ldr = ldr
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
@@ -307,10 +307,12 @@ class GemmProfiler:
         # 16 x 9 (36/144), F(2x2) 16 per 2x2 tile instead of 36; the weight gradient's F(4x4) form likewise
         executed = flops * ({5: 16.0 / 36.0, 6: 0.25, 7: 0.25}.get(kid, 1.0))
         stage = None
-        if mid is not None:
+        if kid in (5, 6):
             npos, tpx = (16, 4) if kid == 5 else (36, 16)
             v_bytes = 4.0 * npos * (a.M // tpx) * g.C
-            stage = (mid, 4.0 * a_elems + v_bytes, v_bytes + 4.0 * (b_elems * npos / 9.0 + a.M * a.N + extra))     # input stage: x in, V out | rest: V, U in, y out (+ residual in; + the product panels out and back in the three-launch forms: not algorithmic)
+            # input stage: x in, V out (None: another kernel - GroupNorm - wrote V) | rest: V, U in, y out (+ residual in; the product
+            # panels of the three-launch forms go out and back in on top of that: not algorithmic)
+            stage = (mid, 4.0 * a_elems + v_bytes if mid is not None else 0.0, v_bytes + 4.0 * (b_elems * npos / 9.0 + a.M * a.N + extra))
         self.records.append((key, flops, nbytes, s, e, executed, stage))
 
     def attention(self, fn, a, what):
@@ -340,9 +342,14 @@ class GemmProfiler:
             d["bytes"] += nb
             d["executed"] += ex
             if stage is not None:
-                d["ms_input"] = d.get("ms_input", 0.0) + s.elapsed_time(stage[0])
-                d["bytes_input"] = d.get("bytes_input", 0.0) + stage[1]
                 d["bytes_rest"] = d.get("bytes_rest", 0.0) + stage[2]
+                d.setdefault("ms_input", 0.0)
+                d.setdefault("bytes_input", 0.0)
+                d.setdefault("n_input", 0)
+                if stage[0] is not None:                 # this launch ran its own input transform
+                    d["ms_input"] += s.elapsed_time(stage[0])
+                    d["bytes_input"] += stage[1]
+                    d["n_input"] += 1
         return out
 
 
@@ -378,7 +385,7 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
         _req(residual, "conv residual")
     # Winograd forms of the weight: F(4x4) wherever the output map is a multiple of 4 (it measured faster than F(2x2) at every
     # shape of tools/ab_winograd.py), F(2x2) for the other even maps; the library's planner still decides per launch
-    wino_ok = (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7, 8, 9, 10, 11, 12, 13, 14, 15) and splitk_hint == 0
+    wino_ok = (KH == 3 and KW == 3 and stride == 1 and x2 is None and tile_hint in (0, 7, 8, 9, 10, 11) and splitk_hint == 0
                and tuple(pad) == (1, 1, 1, 1))
     f4_maps = Ho % 4 == 0 and Wo % 4 == 0 and not KERNEL_FLAGS.get("no_wino4")
     launched = gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
@@ -396,7 +403,7 @@ def gn_silu_conv3x3_raw(x, x2, gamma, beta, G, eps, w, bias, rowadd=None, residu
     reference diffusers ResnetBlock2D.forward, norm1 -> silu -> conv1 (+ temb) and norm2 -> silu -> conv2 (+ shortcut)).
     Where the convolution takes an F(4x4) Winograd route and the norm has a plan for it (`gad_groupnorm_wino4_ok`), GroupNorm
     writes the route's transformed input V directly - the normalised activation never exists in HBM and the route's input
-    transform launch disappears; otherwise the two ordinary launches run.  Same results either way (V is bit-identical)."""
+    transform launch disappears; otherwise the two ordinary launches run.  Same results to fp32 rounding either way."""
     _req(x, "groupnorm x")
     Bn, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)

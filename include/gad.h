@@ -220,8 +220,9 @@ int gad_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
  * the route's own input transform would make of y - instead of y (a->y is ignored and may be NULL), plus mean / rstd.  The
  * convolution then runs with GAD_GEMM_WINO_SKIP_INPUT and wino_ws = V.  W = the map's width (HW = H * W, both multiples of 4),
  * C % 32 == 0, channels per group a multiple of 4; gad_groupnorm_wino4_ok tells whether a plan exists (the normalised
- * (image, channel slab) must fit 128 KB of LDS: up to 32 x 32 maps).  Same statistics, same normalisation arithmetic and the
- * same transform arithmetic as the two separate launches: V is bit-identical to theirs. */
+ * (image, channel slab) must fit 128 KB of LDS: up to 32 x 32 maps).  Same normalisation and transform arithmetic as the two
+ * separate launches; the moments are reduced in the order of this kernel's channel slabs, so V equals theirs to fp32 rounding
+ * (bit for bit where both cut the same slabs). */
 int gad_groupnorm_wino4_ok(const gad_groupnorm_args* a, int32_t W);
 int gad_groupnorm_silu_wino4(const gad_groupnorm_args* a, float* V, int32_t W, void* stream);
 

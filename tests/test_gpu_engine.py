@@ -271,3 +271,32 @@ def test_graph_replay_reads_the_current_winograd_weights():
     want = call(eager)
     assert not torch.equal(a, b)
     assert torch.equal(b, want)
+
+
+def test_batched_time_embedding_projection_matches_per_block():
+    """Sampling computes the 22 `time_emb_proj` Linears of the U-Net as ONE GEMM on concatenated weights (UNet2DModel._temb_rows)
+    and every ResnetBlock2D adds its column block in its first convolution's epilogue: same output as the per-block launches (the
+    tile / split-K plan of the wide GEMM sums in another order: fp32 rounding), rebuilt when a weight changes, not used with grad."""
+    import gad
+    from gad.nn import ResnetBlock2D
+    from src.ddpm_config import DDPMConfig
+    torch.manual_seed(0)
+    net = gad.UNet2DModel(**DDPMConfig.cifar100_config["unet_config"]).to(dev).eval()
+    x = torch.randn(8, 32, 32, 3, device=dev)
+    t = torch.randint(0, 1000, (8,), device=dev)
+    with torch.no_grad():
+        y = net.forward_nhwc(x, t)
+        assert net._temb_w.shape == (sum(r.time_emb_proj.weight.shape[0] for r in net.modules() if isinstance(r, ResnetBlock2D)), 512)
+        keep = net._temb_rows
+        net._temb_rows = lambda temb: ()
+        y0 = net.forward_nhwc(x, t)
+        net._temb_rows = keep
+        assert (y - y0).abs().max().item() < 2e-5 * max(1.0, y0.abs().max().item())
+        r0 = next(m for m in net.modules() if isinstance(m, ResnetBlock2D))
+        r0.time_emb_proj.bias.add_(1.0)                                   # torch-side write: the concatenation must follow
+        y1 = net.forward_nhwc(x, t)
+        net._temb_rows = lambda temb: ()
+        y2 = net.forward_nhwc(x, t)
+        net._temb_rows = keep
+        assert (y1 - y2).abs().max().item() < 2e-5 * max(1.0, y2.abs().max().item()) and (y1 - y).abs().max().item() > 1e-3
+    assert all(getattr(m, "_temb_row", None) is None for m in net.modules())          # nothing left behind for a later grad-mode call

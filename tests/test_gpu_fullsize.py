@@ -138,16 +138,19 @@ def test_fused_sampler_at_bench_width_equals_per_batch_launches():
 
 
 def test_whole_model_is_kernel_family_invariant():
-    """Full-width U-Net at the training batch: forward, loss, gradient norm and the updated weights with the production
-    kernels (Winograd F(2x2,3x3) + LDS-patch forward / dgrad, patch wgrad), with the direct LDS-patch kernels only
-    (ops.kernel_flags(no_wino=True)) and on the generic im2col kernels (no_patch=True): only fp32 summation order (and, for
-    Winograd, the rounding of its transforms) may differ."""
+    """Full-width U-Net at the training batch: forward (no-grad: the sampler's fused norm -> V -> one-launch Winograd halves),
+    loss, gradient norm and the updated weights with the production kernels - Winograd F(4x4, 3x3) forward / data gradient (one-
+    launch form wino4_input_kernel + wino4_fused2_kernel where the planner takes it, else the three-launch forms) and Winograd
+    F(4x4) weight gradient -, with F(4x4) switched off (no_wino4: F(2x2) has no plan at these multiples-of-4 maps, so the direct
+    kernels), with every Winograd route off (no_wino: the direct LDS-patch kernels of round 2), without the norm -> V fusion
+    (no_gn_wino) and on the generic im2col kernels (no_patch): only fp32 summation order and, for Winograd, the rounding of
+    its transforms (about one decimal digit: 1e-5 on the updated weights where the direct families agree to 2e-6) may differ."""
     import gad
     from src.ddpm_config import DDPMConfig
     cfg = DDPMConfig.cifar100_config
     outs = []
     from gad import ops as O
-    for flags in (dict(), dict(no_wino=True), dict(no_patch=True)):
+    for flags in (dict(), dict(no_gn_wino=True), dict(no_wino4=True), dict(no_wino=True), dict(no_patch=True)):
         with O.kernel_flags(**flags):
             torch.manual_seed(0)
             net = gad.UNet2DModel(**cfg["unet_config"]).to(dev)
@@ -167,13 +170,13 @@ def test_whole_model_is_kernel_family_invariant():
         assert abs(l0 - l1) < 1e-5 * abs(l1) and abs(g0 - g1) < 1e-4 * g1
         # one Adam step of lr 1e-4: updates are lr g / (|g| + 1e-8) = +-1e-4 except where |g| ~ eps; signs must agree
         assert (w0 - w1).abs().max().item() < 1e-5
-    assert not torch.equal(outs[0][0], outs[1][0])        # the Winograd route really ran in the default configuration
+    assert not torch.equal(outs[0][0], outs[3][0])        # the Winograd route really ran in the default configuration
 
 
 def test_full_width_training_step_matches_cpu_oracle():
-    """The full CIFAR U-Net at the training batch (B=128: the LDS-patch forward / dgrad / wgrad kernels are the ones that
-    run) against the CPU oracle's training step on the same weights, batch, noise and timesteps: loss, gradient norm,
-    updated weights and EMA."""
+    """The full CIFAR U-Net at the training batch (B=128: the Winograd F(4x4) forward / data-gradient / weight-gradient routes
+    are the ones that run for the 3x3 convolutions) against the CPU oracle's training step on the same weights, batch, noise and
+    timesteps: loss, gradient norm, updated weights and EMA."""
     import gad
     from oracle import diffusers_ref as R
     from src.ddpm_config import DDPMConfig

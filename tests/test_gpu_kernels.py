@@ -1299,7 +1299,8 @@ GN_WINO_CASES = [  # B, H, W, C (C1 of it from the first source, 0 = single sour
 def test_groupnorm_writes_the_winograd_input_transform(ops, B, H, W, C, C1, G):
     """gad_groupnorm_silu_wino4 (norm -> silu -> F(4x4) input transform in one kernel, the normalised activation only in LDS)
     against the two launches it replaces - gad_groupnorm_silu_fwd, then the route's own input stage
-    (GAD_GEMM_WINO_ONLY_INPUT) - on the same inputs: V bit-identical, mean / rstd bit-identical; two-source inputs
+    (GAD_GEMM_WINO_ONLY_INPUT) - on the same inputs: V equal to fp32 rounding (bit-identical where both kernels cut the image
+    into the same channel slabs: the moments' reduction order follows the slab), mean / rstd likewise; two-source inputs
     (UpBlock2D's cat read in place); a shape without a plan (3 channels per group) says so."""
     from gad import _capi
     lib = _capi.load()
@@ -1340,24 +1341,22 @@ def test_groupnorm_writes_the_winograd_input_transform(ops, B, H, W, C, C1, G):
     finally:
         ops.SCRATCH_ALLOC = None
     Vref = grabbed[0].view(torch.float32)[:36 * T * C]
-    assert torch.equal(V[:36 * T * C], Vref)
+    # B^T . B multiplies by up to 25 per direction-pair entry; y itself agrees to ~1e-6
+    assert (V[:36 * T * C] - Vref).abs().max().item() <= 2e-6 * Vref.abs().max().item() + 2e-5
     m2, r2 = torch.empty(B, G, device=dev), torch.empty(B, G, device=dev)
     a.y, a.mean, a.rstd = torch.empty_like(y).data_ptr(), m2.data_ptr(), r2.data_ptr()
     ws = ops.workspace(dev)
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     _capi.check(lib.gad_groupnorm_silu_fwd(_capi.C.byref(a), ops._stream()), "gad_groupnorm_silu_fwd")
-    if lib.gad_groupnorm_one_pass(_capi.C.byref(a)):                              # same arithmetic as the one-pass slab plan
-        assert torch.equal(mean, m2) and torch.equal(rstd, r2)
-    else:
-        close(mean, m2, atol=1e-6, rtol=1e-6)
-        close(rstd, r2, atol=1e-5, rtol=1e-5)
+    close(mean, m2, atol=1e-6, rtol=1e-6)
+    close(rstd, r2, atol=1e-5, rtol=1e-5)
 
 
 @pytest.mark.parametrize("B,H,C,C1,Cout,epi", [(64, 32, 128, 0, 128, "rowadd"), (64, 32, 128, 0, 128, "residual"), (32, 32, 384, 256, 128, "rowadd"),
                                                 (64, 16, 256, 0, 256, "residual"), (256, 8, 512, 256, 256, "rowadd"), (2, 8, 256, 0, 256, "rowadd")])
 def test_fused_norm_silu_conv_matches_the_separate_launches(ops, B, H, C, C1, Cout, epi):
-    """ops.gn_silu_conv3x3_raw (the sampler's ResnetBlock2D halves) = group norm, then convolution: bit-identical, whatever route
-    the planner gives the convolution (the last case is too small for Winograd: the plain launches run)."""
+    """ops.gn_silu_conv3x3_raw (the sampler's ResnetBlock2D halves) = group norm, then convolution, to fp32 rounding, whatever
+    route the planner gives the convolution (the last case is too small for Winograd: the plain launches run, bit-identical)."""
     xs = rnd(B, H, H, C, seed=1).to(dev)
     x, x2 = (xs, None) if not C1 else (xs[..., :C1].contiguous(), xs[..., C1:].contiguous())
     gamma, beta = (1 + 0.1 * rnd(C, seed=2)).to(dev), (0.1 * rnd(C, seed=3)).to(dev)
@@ -1367,7 +1366,9 @@ def test_fused_norm_silu_conv_matches_the_separate_launches(ops, B, H, C, C1, Co
         got = ops.gn_silu_conv3x3_raw(x, x2, gamma, beta, 32, 1e-5, w, b, **kw)
         with ops.kernel_flags(no_gn_wino=True):
             want = ops.gn_silu_conv3x3_raw(x, x2, gamma, beta, 32, 1e-5, w, b, **kw)
-    assert torch.equal(got, want)
+    close(got, want, atol=3e-5, rtol=3e-5)
+    if B == 2:
+        assert torch.equal(got, want)
     ref = conv_ref(torch.nn.functional.silu(torch.nn.functional.group_norm(xs.cpu().double().permute(0, 3, 1, 2), 32, gamma.cpu().double(), beta.cpu().double(), 1e-5)),
                    w.cpu().double(), b.cpu(), 1, (1, 1, 1, 1), False)
     ref = ref + (kw["rowadd"].cpu().double()[:, :, None, None] if epi == "rowadd" else kw["residual"].cpu().double().permute(0, 3, 1, 2))

@@ -6,8 +6,8 @@ run through the coalition engine three times: planner default (Winograd F(4x4) o
 the other even maps), F(4x4) switched off, every Winograd route switched off (direct LDS-patch kernels, the round-2 path).
 Width [64, 128, 128, 128] at 32 x 32, training B = 128, sampler launches of 256 images: every 3x3 / stride-1 convolution of this
 model is Winograd-eligible and the planner takes the route (asserted).  The tolerance asserted here is the one DESIGN.md §3
-states: per-coalition FID within 2e-3 relative of the direct kernels' (measured on this shape: see profiles/r04_winograd_drift.txt;
-at full size the same comparison is recorded by tools/e2e_winograd_drift.py full)."""
+states for this reduced shape: per-coalition FID within 2e-3 relative of the direct kernels' (measured on this shape: see profiles/r04_winograd_drift.txt;
+at full size - 1000 steps, 100 DDIM steps: more amplification - the same comparison gives 1.7e-3 .. 8.4e-3, profiles/r04_winograd_drift.txt)."""
 import os
 
 import pytest

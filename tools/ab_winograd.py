@@ -1,4 +1,5 @@
-"""Winograd F(2x2,3x3) route (wino_input_kernel + wino_gemm_kernel) against the direct LDS-patch kernels on the 3x3 convolutions
+"""Winograd routes - F(2x2,3x3) (wino_input_kernel + wino_gemm_kernel), F(4x4,3x3) in its three-launch and one-launch forms
+(wino4_input_kernel + wino4_gemm / batched products + wino4_output_kernel; wino4_input_kernel + wino4_fused[2]_kernel) - against the direct LDS-patch kernels on the 3x3 convolutions
 of the reference's models (HIP events, median).  TF/s are ALGORITHMIC (2 x 9 Cin Cout per output pixel) for both.
 usage: python tools/ab_winograd.py [launches]"""
 import os, sys
@@ -43,10 +44,8 @@ for B, H, Cin, Cout in SHAPES:
     t4 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=10)) if H % 4 == 0 else float("nan")      # three launches (products -> HBM -> output transform)
     t9 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=9)) if H % 4 == 0 else float("nan")       # input transform + wino4_fused_kernel
     t11 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=11)) if H % 4 == 0 else float("nan")     # the same on 64-tile blocks, one workgroup per CU
-    t12 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=12)) if H % 4 == 0 else float("nan")     # 32-tile blocks without the phase stagger
-    t13 = ev(lambda: ops.conv2d_fwd_raw(x, w, b, tile_hint=13)) if H % 4 == 0 else float("nan")     # staggered by workgroup id
     ex = fl / 4.0 / t9 / 1e9 if t9 == t9 else float("nan")
-    forced = (f" | forced F(2x2) {t2:7.3f} ms (x{t0 / t2:.2f}) F(4x4) three-launch {t4:7.3f} ms (x{t0 / t4:.2f}) one-launch/64 {t11:7.3f} ms one-launch/32 no stagger {t12:7.3f} by-id {t13:7.3f} by-slot {t9:7.3f} ms (x{t0 / t9:.2f}, "
+    forced = (f" | forced F(2x2) {t2:7.3f} ms (x{t0 / t2:.2f}) F(4x4) three-launch {t4:7.3f} ms (x{t0 / t4:.2f}) one-launch/64 {t11:7.3f} ms one-launch/32 {t9:7.3f} ms (x{t0 / t9:.2f}, "
               f"{ex:5.1f} TF/s executed incl. the input transform = {ex / 157.3:.2f})")
     print(f"B{B:5d} {H:2d}x{H:<2d} {Cin:4d}->{Cout:<4d}: planner {took} {t1:7.3f} ms ({fl / t1 / 1e9:6.1f} TF/s) | direct kernels {t0:7.3f} ms "
           f"({fl / t0 / 1e9:6.1f} TF/s) | x{t0 / t1:.2f}" + forced, flush=True)

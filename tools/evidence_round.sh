@@ -7,15 +7,20 @@
 #   <tag>_ab_winograd{,_wgrad}.txt           tools/ab_winograd.py, tools/ab_winograd_wgrad.py
 #   <tag>_attention.txt                      tools/bench_attention.py
 #   <tag>_full_coalition.txt                 two real end-to-end coalitions
+# Two halves (a gpurun call is limited to 20 minutes):  bash tools/evidence_round.sh r04 a   then   ... r04 b
 set -e
-TAG=${1:-r03}
+TAG=${1:-r04}
+HALF=${2:-ab}
 R=$GRAFT_REPO_ROOT
 O=$R/gpurun_out
 export TMPDIR=/tmp
 cd $R
+if [[ $HALF == *a* ]]; then
 python3 bench.py > $O/${TAG}_bench_default.json 2> $O/${TAG}_bench_default.err
 echo "done default bench"
 bash tools/prof_round.sh $TAG "cifar20 cifar20-pruned sd256 sd512 celeba celeba-pruned" pmc
+fi
+if [[ $HALF != *b* ]]; then exit 0; fi
 rm -rf $O/prof_train
 rocprofv3 --kernel-trace --stats --output-format csv -d $O/prof_train -- python3 tools/prof_train.py 20 > $O/${TAG}_train_step.txt 2>&1
 python3 tools/summarize_rocprof.py $(find $O/prof_train -name "*kernel_stats.csv" | head -1) $O/${TAG}_train_step_kernel_stats.csv

@@ -19,6 +19,8 @@ if [ "$3" = pmc ]; then
   for c in FETCH_SIZE WRITE_SIZE; do
     rm -rf $O/pmc_$c
     (cd $R && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmc_$c -- python3 bench.py --workload cifar20 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-train-rate > /dev/null 2> $O/${TAG}_pmc_$c.err)
+    python3 $R/tools/pmc_summarize.py $O/pmc_$c "wino4_fused2_kernel" $c > $O/${TAG}_pmc_${c}_wino4_fused2.json
+    python3 $R/tools/pmc_summarize.py $O/pmc_$c "gn_wino4_kernel" $c > $O/${TAG}_pmc_${c}_gn_wino4.json
     python3 $R/tools/pmc_summarize.py $O/pmc_$c "wino4_gemm_kernel|, 4, 1>(" $c > $O/${TAG}_pmc_${c}_wino_gemm.json
     python3 $R/tools/pmc_summarize.py $O/pmc_$c "wino4_input_kernel" $c > $O/${TAG}_pmc_${c}_wino_input.json
     python3 $R/tools/pmc_summarize.py $O/pmc_$c "wino4_output_kernel" $c > $O/${TAG}_pmc_${c}_wino_output.json
