@@ -1011,17 +1011,21 @@ def test_unet_sampling_forward_without_concat_equals_grad_mode_forward(ops):
     with torch.no_grad():
         a = net(x, t).sample
     b = net(x, t).sample.detach()
-    # the concat-free gathers are bit-identical to the materialised torch.cat; since round 2 the two modes differ in ONE
-    # other place - training at one 256-wide head keeps the three-launch attention, sampling runs the fused kernel -
-    # which is fp32 summation order only
+    # the concat-free gathers are bit-identical to the materialised torch.cat; the two modes differ in three other places, all
+    # fp32 summation order only: training at one 256-wide head keeps the three-launch attention while sampling runs the fused
+    # kernel (round 2); sampling lets GroupNorm write the Winograd input transform (its moments are reduced per channel slab of
+    # that kernel) and computes all time-embedding projections as one GEMM (round 4)
     assert (a - b).abs().max().item() < 2e-5 * max(1.0, b.abs().max().item())
-    monkey = ops.attention_core
-    ops.attention_core = ops.attention_core_fused            # same attention route in both modes -> bit-identical again
+    monkey, keep = ops.attention_core, net._temb_rows
+    ops.attention_core = ops.attention_core_fused            # same attention route, norm and projections in both modes -> bit-identical again
+    net._temb_rows = lambda temb: ()
     try:
         b2 = net(x, t).sample.detach()
+        with torch.no_grad(), ops.kernel_flags(no_gn_wino=True):
+            a2 = net(x, t).sample
     finally:
-        ops.attention_core = monkey
-    assert torch.equal(a, b2)
+        ops.attention_core, net._temb_rows = monkey, keep
+    assert torch.equal(a2, b2)
 
 
 @pytest.mark.parametrize("prec", ["f32", "bf16"])
