@@ -75,11 +75,16 @@ def parse():
                          "(ddpm_config.py:395-450), unpruned / head-grouped-pruned (prune.py:337-342).  Default: cifar20 + the "
                          "others as `secondary` lines")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
+                    help="CIFAR workloads: coalitions in flight per GPU - 2 (default, what gad.launch / run_sharded run): one coalition's "
+                         "training phase beside another's sampling phase on two HIP streams; 1: strictly sequential on one stream")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--widths", choices=["full", "pruned"], default=None, help="alias: --widths pruned = --workload cifar20-pruned")
     ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
+    ap.add_argument("--no-one-stream-pass", action="store_true",
+                    help="--in-flight 2: skip the second, one-stream pass of the same K steps that gives the roofline's one_stream_* keys")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's default precision and the headline number; bf16 = bf16-operand "
                          "contractions (fp32 storage/accumulation), the analogue of --mixed_precision: a separate, "
@@ -119,7 +124,7 @@ def launch_ranks(a) -> int:
 class SliceRunner:
     """Holds one coalition in flight on this rank and advances it one slice at a time."""
 
-    def __init__(self, engine, removal_seed):
+    def __init__(self, engine, removal_seed, in_flight=1):
         import gad
         from gad import ops
         from gad.coalition import DeviceLoader, FusedSampler, antithetic_timesteps, seed_everything
@@ -144,6 +149,10 @@ class SliceRunner:
         self.t = torch.empty(self.x.shape[0], device=self.dev, dtype=torch.int64)
         self.images_done = 0
         self.n_t = engine.train_scheduler.config.num_train_timesteps
+        self.streams = None
+        if in_flight == 2:                                      # CoalitionEngine.run_pipelined's two streams
+            torch.cuda.synchronize(self.dev)
+            self.streams = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
 
     def train_step(self):
         try:
@@ -176,6 +185,15 @@ class SliceRunner:
             self.ti = 0
 
     def slice(self):
+        if self.streams is not None:
+            # two coalitions in flight: the training phase of one beside the sampling phase of another, each on its own HIP
+            # stream (independent work: the small launches of the B = 128 training step fill the tails of the sampler's large ones)
+            with torch.cuda.stream(self.streams[0]):
+                loss = self.train_step()
+            with torch.cuda.stream(self.streams[1]):
+                for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):
+                    self.sampler_step()
+            return loss
         loss = self.train_step()
         for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):      # 1
             self.sampler_step()
@@ -522,16 +540,20 @@ def measure(a, name, steps, warmup, env, headline):
         barrier()
         t0 = time.time()
         recs = []
-        for i in range(steps):                                           # (stdout carries the JSON line only)
-            recs.append(engine.run_coalition(rank + world * i, verbose=False))
-            r = recs[-1]
+        def show(r):
             log(f"coalition {r.removal_seed}: |S|={r.n_remaining} train {r.total_steps_time:.1f}s sample+score {r.total_sampling_time:.1f}s fid {r.fid_value:.4f}")
+        if a.in_flight == 2:
+            recs = engine.run_pipelined([rank + world * i for i in range(steps)], on_record=show)
+        else:
+            for i in range(steps):                                       # (stdout carries the JSON line only)
+                recs.append(engine.run_coalition(rank + world * i, verbose=False))
+                show(recs[-1])
         barrier()
         dt = time.time() - t0
         units = steps * world                                           # coalitions
     else:
         if wl["kind"] == "cifar":
-            run = SliceRunner(engine, removal_seed=rank)
+            run = SliceRunner(engine, removal_seed=rank, in_flight=a.in_flight)
         elif wl["kind"] == "sd":
             run = SDRunner(dev, wl["latent"], wl["batch"], seed=rank)
         else:
@@ -554,11 +576,29 @@ def measure(a, name, steps, warmup, env, headline):
         if wl["kind"] == "cifar":
             units = steps * world / float(GD_STEPS)
             # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
+            one_stream = None
+            if prof is not None and run.streams is not None and not a.no_one_stream_pass:
+                # the same K steps once more on ONE stream: per-kernel durations without the other stream's share of the chip
+                # (in the timed region a kernel's event bracket spans time in which the other coalition's kernels ran too)
+                keep, run.streams = run.streams, None
+                run.slice()
+                barrier()
+                ops.PROFILER = one_stream = ops.GemmProfiler()
+                t1 = time.time()
+                for _ in range(steps):
+                    run.slice()
+                barrier()
+                dt_one = time.time() - t1
+                ops.PROFILER = None
+                run.streams = keep
             n_tr = 0 if a.no_train_rate else 10
+            import contextlib
+            on_train_stream = torch.cuda.stream(run.streams[0]) if run.streams is not None else contextlib.nullcontext()
             barrier()
             t1 = time.time()
-            for _ in range(n_tr):
-                run.train_step()
+            with on_train_stream:                                       # (the stream whose allocator pool holds the trainer's blocks)
+                for _ in range(n_tr):
+                    run.train_step()
             barrier()
             dt_train = time.time() - t1
             n_rem = len(run.loader.x)
@@ -588,6 +628,11 @@ def measure(a, name, steps, warmup, env, headline):
     f32 = a.precision == "f32"
     dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
     par = {"coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
+    if wl["kind"] == "cifar" and a.in_flight == 2:
+        par = {"coalitions_in_flight": 2 * world,
+               "parallelism": (f"coalition-per-gpu x{world}, two coalitions in flight per GPU: the training phase of one beside the sampling "
+                               "phase of the previous one on two HIP streams (gad.coalition.CoalitionEngine.run_pipelined; --in-flight 1 = "
+                               "strictly sequential)")}
     if wl["kind"] == "cifar":
         widths = list(wl["widths"]) if wl["widths"] else [128, 256, 256, 256]
         nparam = sum(p.numel() for p in run.model.parameters()) if not a.full_coalition else None
@@ -595,7 +640,9 @@ def measure(a, name, steps, warmup, env, headline):
         workload = (f"CIFAR-20 DDPM sFT coalition (BASELINE configs[1]{'' if not wl['widths'] else ', PRUNED widths - the shape unlearn.py:363-367 fine-tunes'}): "
                     f"gd_steps=1000 @B=128 + 10240 samples x 100 DDIM steps @B=32 (32 batches fused/launch), UNet2DModel widths {widths}"
                     + (f" {nparam / 1e6:.2f}M params" if nparam else "") + " fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; "
-                    + ("step = one complete coalition" if a.full_coalition else "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"))
+                    + ("step = one complete coalition" if a.full_coalition else
+                       "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"
+                       + (", enqueued on two HIP streams (the train step belongs to the next coalition: independent work)" if a.in_flight == 2 else "")))
         config = {"workload": workload, "score_tail": SCORE_TAIL, **par}
     elif wl["kind"] == "sd":
         out = {"metric": "sd_lora_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
@@ -636,6 +683,19 @@ def measure(a, name, steps, warmup, env, headline):
         out["unet_tflops_executed_per_gpu"] = all_ex / dt / 1e12   # the MFMA work issued (Winograd launches: 36/144 or 16/36 of the direct count)
         out["path_mfma_frac"] = out["unet_tflops_executed_per_gpu"] / peak_tf        # whole path, executed work / step time / peak: <= 1
         out["path_mfma_frac_algorithmic"] = out["unet_tflops_per_gpu"] / peak_tf    # the same on the direct-form count (> executed where Winograd runs)
+        if wl["kind"] == "cifar" and one_stream is not None:
+            r1, _, _, ex1 = kernel_report(one_stream, dt_one, peak_tf, a.precision, name)
+            roof = out["roofline"]
+            roof["measured"] = ("timed region, two coalitions in flight: a kernel's event bracket there includes the time the other stream's "
+                                "kernels held part of the chip, so `frac` is the kernel's rate WHILE SHARING; the one_stream_* keys are the "
+                                "same K steps run again on one stream right after the timed region (kernel quality without sharing)")
+            for k in ("frac", "achieved", "avg_launch_us", "share_of_step_time", "stage_input_us", "stage_input_gbps", "stage_input_frac_of_hbm_peak",
+                      "stage_products_us", "stage_products_tflops_executed", "stage_products_frac_of_mfma_peak", "family_frac"):
+                if k in r1:
+                    roof["one_stream_" + k] = r1[k]
+            roof["one_stream_kernel"] = r1["kernel"][:60]
+            out["one_stream"] = {"ms_per_step": dt_one / steps * 1e3, "value": units / dt_one * 3600.0,
+                                 "path_mfma_frac": ex1 / dt_one / 1e12 / peak_tf}
     elif name == "cifar20" and not a.full_coalition:
         fl = (3 * UNET_GFLOP_PER_IMG * TRAIN_B + UNET_GFLOP_PER_IMG * N_SAMPLES * DDIM_STEPS / GD_STEPS) * 1e9
         out["unet_tflops_per_gpu"] = fl * steps / dt / 1e12

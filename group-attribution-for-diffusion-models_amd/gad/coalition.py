@@ -87,33 +87,53 @@ class FusedSampler:
                              dtype=torch.float32) for c, n in zip(counters, sizes)]
         return ops.nchw_to_nhwc_raw(torch.cat(parts, 0).to(self.device))
 
-    @torch.no_grad()
-    def denoise(self, x: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
-        """x NHWC noise -> NHWC images in [0,1] after the full DDIM trajectory."""
+    def denoise_steps(self, x: torch.Tensor, num_inference_steps: int):
+        """Generator form of `denoise`: yields after every enqueued DDIM step (the pipelined scheduler interleaves another
+        coalition's training steps there), returns the NHWC images in [0,1]."""
         sch = self.sch
         sch.set_timesteps(num_inference_steps)
         clip = float(sch.config.clip_sample_range) if sch.config.clip_sample else 0.0
         t = torch.empty(x.shape[0], device=x.device, dtype=torch.int64)
         for ts in sch.timesteps.tolist():
-            t.fill_(ts)
-            eps = self.unet.forward_nhwc(x, t)
-            a_t, a_p = sch.step_coefficients(ts)
-            ops.ddim_step_raw(x, eps, a_t, a_p, clip, out=x)
-        return ops.to_image01_raw(x)
+            with torch.no_grad():
+                t.fill_(ts)
+                eps = self.unet.forward_nhwc(x, t)
+                a_t, a_p = sch.step_coefficients(ts)
+                ops.ddim_step_raw(x, eps, a_t, a_p, clip, out=x)
+            yield
+        with torch.no_grad():
+            return ops.to_image01_raw(x)
 
-    @torch.no_grad()
-    def generate(self, n_samples: int, num_inference_steps: int) -> torch.Tensor:
-        """-> float tensor [n,3,H,W] holding k/255 values (uint8 round trip of :344-355), on device."""
+    def denoise(self, x: torch.Tensor, num_inference_steps: int) -> torch.Tensor:
+        """x NHWC noise -> NHWC images in [0,1] after the full DDIM trajectory."""
+        return _drain(self.denoise_steps(x, num_inference_steps))
+
+    def generate_steps(self, n_samples: int, num_inference_steps: int):
+        """Generator form of `generate` (yields once per DDIM step of every fused launch group)."""
         sizes = [self.bs] * (n_samples // self.bs)
         if n_samples % self.bs:
             sizes.append(n_samples % self.bs)
         out = []
         for g0 in range(0, len(sizes), self.fuse):
             cs = list(range(g0, min(g0 + self.fuse, len(sizes))))
-            img = self.denoise(self.initial_noise(cs, [sizes[c] for c in cs]), num_inference_steps)
-            q = img.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)       # .mul(255).add_(0.5).clamp_(0,255) -> uint8
-            out.append(q.permute(0, 3, 1, 2).float().div_(255))             # ToTensor(): /255
+            img = yield from self.denoise_steps(self.initial_noise(cs, [sizes[c] for c in cs]), num_inference_steps)
+            with torch.no_grad():
+                q = img.mul(255).add_(0.5).clamp_(0, 255).to(torch.uint8)       # .mul(255).add_(0.5).clamp_(0,255) -> uint8
+                out.append(q.permute(0, 3, 1, 2).float().div_(255))             # ToTensor(): /255
         return torch.cat(out, 0)
+
+    def generate(self, n_samples: int, num_inference_steps: int) -> torch.Tensor:
+        """-> float tensor [n,3,H,W] holding k/255 values (uint8 round trip of :344-355), on device."""
+        return _drain(self.generate_steps(n_samples, num_inference_steps))
+
+
+def _drain(gen):
+    """Run a step generator to its end and hand back its return value."""
+    while True:
+        try:
+            next(gen)
+        except StopIteration as e:
+            return e.value
 
 
 @dataclass
@@ -182,6 +202,9 @@ class CoalitionEngine:
             self.unet_cfg.update(unet_overrides)
         self.gd_steps = gd_steps if gd_steps is not None else self.config["training_steps"]["gd"]
         self.n_samples, self.sample_batch, self.fuse = n_samples, sample_batch, fuse
+        # coalitions in flight on this GPU: 2 = the training phase of one beside the sampling phase of the previous one on two
+        # HIP streams (run_pipelined; what run_sharded / gad.launch use), 1 = strictly one after the other
+        self.in_flight = int(os.environ.get("GAD_IN_FLIGHT", "2"))
         self.num_inference_steps, self.opt_seed, self.by_class, self.preview = num_inference_steps, opt_seed, by_class, preview
         self.dataset = create_dataset(dataset_name, train=True)
         self.n_groups = len(set(self.dataset.targets))
@@ -225,14 +248,17 @@ class CoalitionEngine:
         return global_scores_against_dataset(images01, self.dataset, self.device, 512, self.feature_net.dims)
 
     # -- the cycle -------------------------------------------------------------------------------
-    def run_coalition(self, removal_seed: int, verbose=False) -> CoalitionRecord:
+    def train_phase(self, removal_seed: int):
+        """Generator: the sparsified fine-tuning of one coalition (unlearn.py:548-644) on the CURRENT stream, yielding after every
+        enqueued optimizer step; returns the hand-over state for `sample_phase`.  No host synchronisation inside."""
         remaining_idx, removed_idx = self.coalition(removal_seed)
         seed_everything(self.opt_seed)                                    # unlearn.py:359
         model, ema = self.load_base()
         trainer = self.make_trainer(model, ema)
         loader = DeviceLoader(self.dataset, remaining_idx, self.config["batch_size"], self.device)
         n_t = self.train_scheduler.config.num_train_timesteps
-        t0 = time.time()
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         steps = 0
         loss = torch.zeros(1, device=self.device)
         while steps < self.gd_steps:                                      # unlearn.py:558-642
@@ -241,33 +267,120 @@ class CoalitionEngine:
                 ts = antithetic_timesteps(n_t, image.shape[0], self.device)
                 loss = trainer.step(image, noise, ts)
                 steps += 1
+                yield
                 if steps == self.gd_steps:
                     break
-        torch.cuda.synchronize(self.device)
-        total_steps_time = time.time() - t0
         # EMA weights are used for inference (unlearn.py:751-753); the fine-tuned ones are not kept
         model.flat[0].copy_(trainer.ema_flat)
         ops.WEIGHT_EPOCH[0] += 1                                         # flat copy: no per-parameter version bump
         model.eval()
-        t1 = time.time()
+        ev1.record()
+        return dict(removal_seed=removal_seed, remaining_idx=remaining_idx, removed_idx=removed_idx, model=model, loss=loss,
+                    steps=steps, train_events=(ev0, ev1))
+
+    def sample_phase(self, st: dict, preview_generator=None):
+        """Generator: sampling + scoring of a fine-tuned coalition (unlearn.py:751-837) on the CURRENT stream, yielding after
+        every enqueued DDIM step; returns the CoalitionRecord (its score tail synchronises with the host)."""
+        model = st["model"]
+        ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        ev0.record()
         if self.preview:                                                  # unlearn.py:761-765 (global RNG)
             pipe = DDPMPipeline(model, self.sample_scheduler)
             pipe.use_graph = False                                        # one-off call: not worth a capture
             pipe(batch_size=self.config["n_samples"], num_inference_steps=self.num_inference_steps,
-                 output_type="tensor")
+                 output_type="tensor", generator=preview_generator)
+            yield
         sampler = FusedSampler(model, self.sample_scheduler, self.sample_batch, self.fuse)
-        images = sampler.generate(self.n_samples, self.num_inference_steps)
+        images = yield from sampler.generate_steps(self.n_samples, self.num_inference_steps)
         sc = self.score(images)
-        fid = sc["fid_value"]
-        torch.cuda.synchronize(self.device)
-        rec = CoalitionRecord(removal_seed, len(remaining_idx), len(removed_idx), fid, float(loss.item()),
-                              total_steps_time, time.time() - t1, steps,
-                              sorted(set(int(self.dataset.targets[i]) for i in remaining_idx)),
-                              sc["is"], sc["precision"], sc["recall"])
+        ev1.record()
+        ev1.synchronize()
+        remaining_idx, removed_idx = st["remaining_idx"], st["removed_idx"]
+        return CoalitionRecord(st["removal_seed"], len(remaining_idx), len(removed_idx), sc["fid_value"], float(st["loss"].item()),
+                               st["train_events"][0].elapsed_time(st["train_events"][1]) / 1e3, ev0.elapsed_time(ev1) / 1e3,
+                               st["steps"], sorted(set(int(self.dataset.targets[i]) for i in remaining_idx)),
+                               sc["is"], sc["precision"], sc["recall"])
+
+    def run_coalition(self, removal_seed: int, verbose=False) -> CoalitionRecord:
+        """One coalition, its two phases back to back on the current stream."""
+        rec = _drain(self.sample_phase(_drain(self.train_phase(removal_seed))))
         if verbose:
-            print(f"[coalition {removal_seed}] |S|={rec.n_remaining} train {total_steps_time:.1f}s "
-                  f"sample+score {rec.total_sampling_time:.1f}s fid {fid:.4f}", flush=True)
+            print(f"[coalition {removal_seed}] |S|={rec.n_remaining} train {rec.total_steps_time:.1f}s "
+                  f"sample+score {rec.total_sampling_time:.1f}s fid {rec.fid_value:.4f}", flush=True)
         return rec
+
+    def run_pipelined(self, seeds: Sequence[int], on_record=None, on_error=None, verbose=False) -> List[CoalitionRecord]:
+        """TWO coalitions in flight on this GPU: while coalition i samples (10 240 images x 100 DDIM steps in launches of 1024
+        images: long kernels that fill the chip) coalition i + 1 fine-tunes (B = 128: short launches that leave CUs idle), each on
+        its own HIP stream - the training step's small launches fill the tails of the sampler's large ones
+        (profiles/r04_two_streams.txt: 91.6 -> 81.7 ms per 1/1000 coalition).  One host thread enqueues both, one optimizer step
+        and one DDIM step per turn (a coalition has 1000 of each), and never runs more than `ahead` turns ahead of the GPU.
+        Every coalition computes exactly what `run_coalition` computes - same kernels, same order on its stream, its own
+        workspace (ops.workspace is per stream), the training phase's device RNG seeded as before; the preview draw of the
+        sampling phase (unlearn.py:761-765: its images are discarded) takes a generator of its own so that it cannot interleave
+        with the next coalition's training draws - records are bit-identical to the sequential run's
+        (tests/test_gpu_engine.py::test_pipelined_coalitions_equal_sequential).
+        `on_record(rec)` is called as each coalition finishes (durable append); a coalition whose phase raises is reported
+        through `on_error(seed, exc)` and dropped, the others carry on."""
+        dev = self.device
+        torch.cuda.synchronize(dev)
+        s_train, s_samp = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        todo = list(seeds)
+        recs, ahead, marks = [], 8, []
+        train = samp = ready = None           # running train phase, running sample phase, trained state waiting for the sampler
+        train_seed = samp_seed = None
+
+        def fail(seed, exc):
+            if on_error is None:
+                raise exc
+            on_error(seed, exc)
+        while todo or train is not None or samp is not None or ready is not None:
+            if samp is None and ready is not None:
+                s_samp.wait_stream(s_train)                               # the EMA weights were written on the training stream
+                st, ready = ready, None
+                samp_seed = st["removal_seed"]
+                g = torch.Generator(device=dev).manual_seed(1_000_003 * self.opt_seed + samp_seed)
+                with torch.cuda.stream(s_samp):
+                    samp = self.sample_phase(st, preview_generator=g)
+            if train is None and ready is None and todo:
+                train_seed = todo.pop(0)
+                with torch.cuda.stream(s_train):
+                    train = self.train_phase(train_seed)
+            if train is not None:
+                try:
+                    with torch.cuda.stream(s_train):
+                        next(train)
+                except StopIteration as e:
+                    train, ready = None, e.value
+                except Exception as e:                                    # this coalition only
+                    train = None
+                    fail(train_seed, e)
+            if samp is not None:
+                try:
+                    with torch.cuda.stream(s_samp):
+                        next(samp)
+                except StopIteration as e:
+                    samp = None
+                    recs.append(e.value)
+                    if verbose:
+                        r = e.value
+                        print(f"[coalition {r.removal_seed}] |S|={r.n_remaining} train {r.total_steps_time:.1f}s (beside a sampling phase) "
+                              f"sample+score {r.total_sampling_time:.1f}s (beside a training phase) fid {r.fid_value:.4f}", flush=True)
+                    if on_record is not None:
+                        on_record(e.value)
+                except Exception as e:
+                    samp = None
+                    fail(samp_seed, e)
+            # bounded run-ahead: wait for the turn `ahead` turns back on both streams
+            ev = (torch.cuda.Event(), torch.cuda.Event())
+            ev[0].record(s_train)
+            ev[1].record(s_samp)
+            marks.append(ev)
+            if len(marks) > ahead:
+                for e_ in marks.pop(0):
+                    e_.synchronize()
+        torch.cuda.synchronize(dev)
+        return recs
 
     def jsonl_row(self, rec: CoalitionRecord, extra: Optional[dict] = None) -> dict:
         """Keys lds.py reads (lds.py:203-257): dataset, removal_dist, method, exp_name, removal_seed,
@@ -469,17 +582,34 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
     shard = _rank_shard(db_path, rank) if db_path else None
     recs, failed = [], []
     todo, attempt = list(mine), 0
+
+    def note_failure(s, e, tb):
+        if db_path:
+            _append_row(db_path + ".failed", dict(removal_seed=s, rank=rank, attempt=attempt, error=repr(e), traceback=tb))
+        if verbose:
+            print(f"[rank {rank}] coalition {s} failed (attempt {attempt}): {e!r}", flush=True)
+    if todo and getattr(engine, "in_flight", 1) > 1 and hasattr(engine, "run_pipelined"):
+        # two coalitions in flight per GPU (CoalitionEngine.run_pipelined): rows are appended as coalitions finish; one that
+        # raises is recorded and goes to the sequential retry loop below
+        again = []
+
+        def on_record(rec):
+            recs.append(rec)
+            if shard:
+                _append_row(shard, engine.jsonl_row(rec))
+
+        def on_error(s, e):
+            note_failure(s, e, "".join(traceback.format_exception(type(e), e, e.__traceback__)))
+            again.append(s)
+        engine.run_pipelined(todo, on_record=on_record, on_error=on_error, verbose=verbose)
+        attempt, todo, failed = 1, (again if retries >= 1 else []), again
     while todo:
         again = []
         for s in todo:
             try:
                 rec = engine.run_coalition(s, verbose=verbose)
             except Exception as e:                               # this coalition only; the rank carries on
-                if db_path:
-                    _append_row(db_path + ".failed", dict(removal_seed=s, rank=rank, attempt=attempt, error=repr(e),
-                                                          traceback=traceback.format_exc()))
-                if verbose:
-                    print(f"[rank {rank}] coalition {s} failed (attempt {attempt}): {e!r}", flush=True)
+                note_failure(s, e, traceback.format_exc())
                 again.append(s)
                 continue
             recs.append(rec)

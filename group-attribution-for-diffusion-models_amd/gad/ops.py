@@ -30,9 +30,10 @@ def _stream():
 
 
 def workspace(device) -> torch.Tensor:
-    """One caller-owned scratch buffer per device (split-K partials, reduction partials).
-    Allocated once so that hipGraph replays see a fixed address."""
-    key = (device.type, device.index)
+    """One caller-owned scratch buffer per device AND stream (split-K partials, reduction partials): launches on one stream are
+    ordered, so they can share it; two coalitions in flight on two streams (a training phase beside a sampling phase,
+    coalition.run_pipelined) must not.  Allocated once per stream so that hipGraph replays see a fixed address."""
+    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)

@@ -300,3 +300,29 @@ def test_batched_time_embedding_projection_matches_per_block():
         net._temb_rows = keep
         assert (y1 - y2).abs().max().item() < 2e-5 * max(1.0, y2.abs().max().item()) and (y1 - y).abs().max().item() > 1e-4
     assert all(getattr(m, "_temb_row", None) is None for m in net.modules())          # nothing left behind for a later grad-mode call
+
+
+def test_pipelined_coalitions_equal_sequential(monkeypatch):
+    """CoalitionEngine.run_pipelined (two coalitions in flight: the training phase of one beside the sampling phase of the previous
+    one, on two HIP streams, one host thread) gives the records `run_coalition` gives one after the other - bit for bit:
+    same kernels in the same order per stream, a workspace per stream, the training RNG seeded per coalition as before."""
+    monkeypatch.setenv("GAD_SYNTH_SCALE", "0.1")
+    from gad.coalition import CoalitionEngine
+    eng = CoalitionEngine("cifar100", device="cuda:0", gd_steps=6, n_samples=64, num_inference_steps=4, fuse=1, sample_batch=32,
+                          unet_overrides=dict(block_out_channels=(32, 64, 64, 64), norm_num_groups=8))
+    seq = [eng.run_coalition(s) for s in (0, 1, 2)]
+    seen = []
+    pip = eng.run_pipelined([0, 1, 2], on_record=seen.append)
+    assert [r.removal_seed for r in pip] == [0, 1, 2] and seen == pip
+    for a, b in zip(seq, pip):
+        assert (a.removal_seed, a.n_remaining, a.remaining_classes, a.trained_steps) == (b.removal_seed, b.n_remaining, b.remaining_classes, b.trained_steps)
+        assert a.fid_value == b.fid_value and a.loss_last == b.loss_last
+        assert a.inception_score == b.inception_score and a.precision == b.precision and a.recall == b.recall
+    # a coalition that raises is reported and dropped, the others finish
+    real = eng.coalition
+    eng.coalition = lambda seed: (_ for _ in ()).throw(RuntimeError("synthetic")) if seed == 1 else real(seed)
+    errs = []
+    got = eng.run_pipelined([0, 1, 2], on_error=lambda s, e: errs.append((s, str(e))))
+    eng.coalition = real
+    assert [r.removal_seed for r in got] == [0, 2] and errs == [(1, "synthetic")]
+    assert got[0].fid_value == seq[0].fid_value and got[1].fid_value == seq[2].fid_value

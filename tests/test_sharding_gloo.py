@@ -201,6 +201,39 @@ def test_straggler_shard_survives_and_the_launcher_consolidates_it(tmp_path, wor
     assert not [f for f in os.listdir(tmp_path) if ".rank" in f]
 
 
+def test_run_sharded_uses_the_pipelined_engine_and_retries_its_failures(tmp_path):
+    """An engine with `in_flight == 2` is driven through `run_pipelined` (rows appended as coalitions finish); a coalition it
+    reports as failed lands in <db>.failed and is retried through `run_coalition`."""
+    from gad.coalition import run_sharded
+
+    class Eng(_StubEngine):
+        in_flight = 2
+        calls = []
+
+        def run_pipelined(self, seeds, on_record=None, on_error=None, verbose=False):
+            out = []
+            for s_ in seeds:
+                self.calls.append(("pipe", s_))
+                if s_ == 3:
+                    on_error(s_, RuntimeError("synthetic failure in flight"))
+                    continue
+                out.append(_StubEngine.run_coalition(self, s_))
+                on_record(out[-1])
+            return out
+
+        def run_coalition(self, seed, verbose=False):
+            self.calls.append(("seq", seed))
+            return _StubEngine.run_coalition(self, seed)
+    db = str(tmp_path / "db.jsonl")
+    eng = Eng()
+    recs = run_sharded(eng, list(range(5)), db_path=db)
+    assert sorted(r.removal_seed for r in recs) == [0, 1, 2, 3, 4]
+    assert eng.calls == [("pipe", 0), ("pipe", 1), ("pipe", 2), ("pipe", 3), ("pipe", 4), ("seq", 3)]
+    assert sorted(r["removal_seed"] for r in _rows(db)) == [0, 1, 2, 3, 4]
+    fails = _rows(db + ".failed")
+    assert len(fails) == 1 and fails[0]["removal_seed"] == 3 and "in flight" in fails[0]["error"]
+
+
 def test_merge_keeps_the_shard_of_a_rank_that_may_still_be_alive(tmp_path):
     """A rank that missed the rendezvous by timeout (no tombstone) may still be appending: its rows are copied into the
     db, its shard stays; a consumed shard is renamed before it is read."""

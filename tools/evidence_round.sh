@@ -34,5 +34,9 @@ timeout -k 10 300 python3 tools/ab_winograd.py > $O/${TAG}_ab_winograd.txt 2>&1
 timeout -k 10 300 python3 tools/ab_winograd_wgrad.py > $O/${TAG}_ab_winograd_wgrad.txt 2>&1
 timeout -k 10 600 python3 tools/bench_attention.py 5 > $O/${TAG}_attention.txt 2>&1
 echo "done attention"
-timeout -k 10 900 python3 bench.py --full-coalition --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/${TAG}_full_coalition.txt 2>&1
-echo "done full coalition"
+# complete coalitions end to end: four with two in flight per GPU (train(0) | sample(0) + train(1) | ... | sample(3): the first training and the
+# last sampling phase run alone), then two strictly one after the other
+timeout -k 10 700 python3 bench.py --full-coalition --steps 4 --warmup 0 --no-cpu-baseline --no-kernel-timing > $O/${TAG}_full_coalition.txt 2>&1
+echo "done full coalition (two in flight)"
+timeout -k 10 400 python3 bench.py --full-coalition --steps 2 --warmup 0 --no-cpu-baseline --no-kernel-timing --in-flight 1 > $O/${TAG}_full_coalition_one_stream.txt 2>&1
+echo "done full coalition (one stream)"

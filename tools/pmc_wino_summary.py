@@ -21,7 +21,7 @@ for k in ("wino4_fused2", "wino_input", "gn_wino4", "wino_gemm", "wino_output"):
 out = {
  "source": "rocprofv3 --kernel-trace --pmc FETCH_SIZE / --pmc WRITE_SIZE --output-format csv (two SEPARATE passes, tools/prof_round.sh via "
            "tools/evidence_round.sh) -- python3 bench.py --workload cifar20 --steps 4 --warmup 1 --no-cpu-baseline --no-kernel-timing "
-           "--no-train-rate ; tools/pmc_summarize.py, tools/pmc_wino_summary.py",
+           "--no-train-rate --in-flight 1 ; tools/pmc_summarize.py, tools/pmc_wino_summary.py",
  "dominant_key": "conv_fwd_wino4_32_1_4",
  "dominant_kernel": "wino4_fused2_kernel<2, 3> (all 36 F(4x4) products + the output transform of a 3x3 convolution in one launch): every launch "
                     "of the run - sampler forward at B=1024 (V written by gn_wino4_kernel), training forward at B=128 and the data gradients "
