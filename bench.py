@@ -396,8 +396,8 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
             tiles_ = "128- then 96-channel tiles, two launches" if dom_key[1] == 224 else f"{dom_key[1]}-channel tiles"
             kname = f"conv3x3_patch_f32_kernel<{wo}, {ni}, {'true' if 'dgrad' in nm else 'false'}, {'128 | 96' if dom_key[1] == 224 else dom_key[1]}> ({nm}, {tiles_})"
     elif "_wino4" in nm:      # Winograd F(4x4,3x3): the launches of one convolution, bracketed together
-        if dom_key[1] in (32, 64):
-            kname = (f"wino4_input_kernel + wino4_fused{'2' if dom_key[1] == 32 else ''}_kernel ({nm}, {dom_key[1]} tiles x 64 channels per workgroup: all 36 "
+        if dom_key[1] in (32, 64, 65):
+            kname = (f"wino4_input_kernel + wino4_fused{'' if dom_key[1] == 64 else '2'}_kernel ({nm}, {'64 tiles x 32' if dom_key[1] == 65 else f'{dom_key[1]} tiles x 64'} channels per workgroup: all 36 "
                      "products and the whole output transform in one launch; time = both launches)")
         else:
             kname = (f"wino4_input_kernel + wino4_gemm_kernel<64, 128> / <128, 64> (six-position products; small launches: 36 batched products on "
@@ -760,7 +760,7 @@ def main():
             gc.collect()
             torch.cuda.empty_cache()
             try:
-                sec = measure(a, name, a.secondary_steps, min(a.warmup, 2), env, headline=False)
+                sec = measure(a, name, a.secondary_steps, a.warmup, env, headline=False)
                 sec.pop("contraction_kernels", None)                    # the per-instance table of the headline is enough
                 out["secondary"][name] = sec
             except Exception as e:                                      # a secondary line never costs the headline

@@ -2748,7 +2748,9 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     // ~0.2 TF/s executed each (rounds of 512); its epilogue reads the residual under the other workgroup's K loop, which costs
     // about the residual's bytes at 2.2 TB/s (profiles/r04_ab_winograd.txt, r04_wino4_fused_experiments.txt).  Taken when it
     // models faster than the three-launch form and its blocks fill most of a round.
-    const long blocks32 = gad_ceil_div(p4.T, 32) * gad_ceil_div(a->N, 64);
+    // block shape: 32 tiles x 64 channels, or 64 tiles x 32 channels where that pads the output channels less (N = 96, 160, 224, 288 ...)
+    const bool narrow = gad_ceil_div(a->N, 32) * 32 < gad_ceil_div(a->N, 64) * 64;
+    const long blocks32 = narrow ? gad_ceil_div(p4.T, 64) * gad_ceil_div(a->N, 32) : gad_ceil_div(p4.T, 32) * gad_ceil_div(a->N, 64);
     const double y_once = 4.0 * (double)a->M * a->N;
     const double t_full = (double)gad_ceil_div(blocks32, 512) * 36.0 * (g.C / BK) * (32.0 * 64.0 * BK * 2.0) / 0.20e12 +
                           (a->residual ? y_once / 2.2e12 : y_once / 20e12);
@@ -2760,9 +2762,10 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     const bool full_ok = !(a->flags & GAD_GEMM_GENERAL_LOADERS) && a->tile_hint != 10;
     if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (t_full < t3 && blocks32 >= 320))) {
       p4.fused4 = 2;
-      p4.bm = a->tile_hint == 11 ? 64 : 32; p4.bn = 64;
-      p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm);
-      p4.tiles_n = (int)gad_ceil_div(a->N, 64);
+      p4.bm = a->tile_hint == 11 ? 64 : narrow ? 65 : 32;       // 65 names the 64-tile x 32-channel shape (64: the one-workgroup-per-CU form kept for A/B)
+      p4.bn = p4.bm == 65 ? 32 : 64;
+      p4.tiles_m = (int)gad_ceil_div(p4.T, p4.bm == 32 ? 32 : 64);
+      p4.tiles_n = (int)gad_ceil_div(a->N, p4.bn);
     }
     const double mb = p4.fused4 == 2 ? 0.0 : mb3;
     p4.bytes = (int64_t)(vb + mb);

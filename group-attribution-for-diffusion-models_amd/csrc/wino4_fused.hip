@@ -287,16 +287,17 @@ struct RowsKC {
   __device__ static float* dma_dst(float* tile, int i) { return tile + (wave_id() * 8 + RPS * i) * BK; }
 };
 
-// WM = waves along the tiles: 2 (32 tiles, 256 threads, two workgroups per CU) or 4 (64 tiles, 512 threads, one workgroup per CU
-// whose eight waves share ONE U tile: two thirds of the LDS-DMA traffic per FLOP)
-template <int WM, int SUB, int NST>
-__global__ __launch_bounds__(128 * WM, 2) void wino4_fused2_kernel(const DevArgs p) {
-  constexpr int NTH = 128 * WM, BM = 16 * WM, BN = 64, D = NST - 1;
+// WM x WN waves of 16 tiles x 32 channels: 2 x 2 (32 tiles x 64 channels) or 4 x 1 (64 tiles x 32 channels: output widths that are
+// multiples of 32 but not of 64 - the pruned models' 96 / 160 / 224 / 288 - without a quarter of the MFMA work on padding);
+// 256 threads and two workgroups per CU either way.  (4 x 2 - 512 threads, one U tile for eight waves - measured no faster.)
+template <int WM, int WN, int SUB, int NST>
+__global__ __launch_bounds__(64 * WM * WN, 2) void wino4_fused2_kernel(const DevArgs p) {
+  constexpr int NTH = 64 * WM * WN, BM = 16 * WM, BN = 32 * WN, D = NST - 1;
   constexpr int A_TILE = BK * BM, SUBT = BK * (BM + BN), STAGE = SUB * SUBT;
   using AL = RowsKC<BM, NTH>;
   using BL = RowsKC<BN, NTH>;
   constexpr int NDA = AL::NS, NDB = BL::NS, NDS = NDA + NDB, NDMA = NDS * SUB;      // LDS-DMA wave-instructions per thread: per 32-deep sub-tile, per stage-step
-  static_assert(NST * STAGE >= 2 * WM * EPI2_WAVE, "the epilogue scratch lives in the ring");
+  static_assert(NST * STAGE >= WM * WN * EPI2_WAVE, "the epilogue scratch lives in the ring");
   __shared__ __attribute__((aligned(16))) float lds[NST * STAGE];
 
   const int t = xcd_remap(blockIdx.x, gridDim.x);
@@ -310,7 +311,7 @@ __global__ __launch_bounds__(128 * WM, 2) void wino4_fused2_kernel(const DevArgs
   bl.init(p.B, p.ldb, col0, p.N);
 
   const int tid = threadIdx.x, wave = tid >> 6, lane = tid & 63;
-  const int wm = wave >> 1, wn = wave & 1, r16 = lane & 15, kg = lane >> 4;
+  const int wm = wave / WN, wn = wave - wm * WN, r16 = lane & 15, kg = lane >> 4;
   // per-lane fragment bases (floats): chunk 4 g + kg of row arow / brow; both halves g = 0, 1 are compile-time offsets apart only
   // through the swizzle, so keep both
   const int arow = wm * 16 + r16, brow = wn * 32 + r16;
@@ -522,9 +523,12 @@ void launch_wino4_fused(const DevArgs& w, int bm, hipStream_t st) {
   if (bm == 64) {
     if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused_kernel<2, 3>), grid, block, 0, st, w);
     else hipLaunchKernelGGL((wino4_fused_kernel<1, 4>), grid, block, 0, st, w);
-  } else {                                       // (WM = 4 - 64 tiles on eight waves - measured no faster: profiles/r04_wino4_fused_experiments.txt)
-    if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused2_kernel<2, 2, 3>), grid, block, 0, st, w);
-    else hipLaunchKernelGGL((wino4_fused2_kernel<2, 1, 4>), grid, block, 0, st, w);
+  } else if (bm == 32) {                         // 32 tiles x 64 channels
+    if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused2_kernel<2, 2, 2, 3>), grid, block, 0, st, w);
+    else hipLaunchKernelGGL((wino4_fused2_kernel<2, 2, 1, 4>), grid, block, 0, st, w);
+  } else {                                       // bm == 65: 64 tiles x 32 channels
+    if (w.K % 64 == 0) hipLaunchKernelGGL((wino4_fused2_kernel<4, 1, 2, 3>), grid, block, 0, st, w);
+    else hipLaunchKernelGGL((wino4_fused2_kernel<4, 1, 1, 4>), grid, block, 0, st, w);
   }
 }
 

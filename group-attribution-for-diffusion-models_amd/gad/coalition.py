@@ -324,7 +324,9 @@ class CoalitionEngine:
         through `on_error(seed, exc)` and dropped, the others carry on."""
         dev = self.device
         torch.cuda.synchronize(dev)
-        s_train, s_samp = torch.cuda.Stream(dev), torch.cuda.Stream(dev)
+        if getattr(self, "_streams", None) is None:           # one pair per engine: ops.workspace keeps 1 GiB of scratch per stream
+            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
+        s_train, s_samp = self._streams
         todo = list(seeds)
         recs, ahead, marks = [], 8, []
         train = samp = ready = None           # running train phase, running sample phase, trained state waiting for the sampler

@@ -112,6 +112,9 @@ def _parse(argv=None):
     ap.add_argument("--num_inference_steps", type=int, default=100)
     ap.add_argument("--opt_seed", type=int, default=42)
     ap.add_argument("--mixed_precision", default="no", choices=["no", "fp16", "bf16"])
+    ap.add_argument("--in_flight", type=int, default=2, choices=[1, 2],
+                    help="cifar cycle: coalitions in flight per GPU - 2: the training phase of one beside the sampling phase of the "
+                         "previous one on two HIP streams (CoalitionEngine.run_pipelined); 1: one after the other")
     ap.add_argument("--requeue", type=int, default=1, help="re-entries of the whole launch while seeds are missing")
     ap.add_argument("--retries", type=int, default=1, help="in-process retries of a coalition that raised")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])
@@ -149,6 +152,7 @@ def worker(a) -> int:
     if a.cycle == "cifar":
         engine = CoalitionEngine(a.dataset, device=dev, gd_steps=a.gd_steps, n_samples=a.n_samples,
                                  sample_batch=a.batch_size, num_inference_steps=a.num_inference_steps, opt_seed=a.opt_seed)
+        engine.in_flight = a.in_flight
     else:
         import json
         from gad import cycles

@@ -37,4 +37,16 @@ if [ "$3" = pmc ]; then
   done
   python3 $R/tools/pmc_wino_summary.py $O $TAG > $O/${TAG}_pmc_summary.json
   cat $O/${TAG}_pmc_summary.json
+  # the secondary workloads' dominant families: sd512 (single-pass attention backward at T = 4096, d = 40) and celeba (three-launch F(4x4))
+  for spec in "sd512|attn_bwd1_f32_kernel|attn_delta_kernel|attn_dq_reduce_kernel" "celeba|wino4_output_kernel|wino4_gemm_kernel|, 4, 1>(|wino4_input_kernel"; do
+    wl=${spec%%|*}; rest=${spec#*|}
+    rm -rf $O/pmcw; mkdir -p $O/pmcw
+    for c in FETCH_SIZE WRITE_SIZE; do
+      (cd $R && rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmcw/pmc_$c -- python3 bench.py --workload $wl --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing --no-train-rate > /dev/null 2> $O/${TAG}_pmc_${c}_$wl.err)
+    done
+    IFS='|' read -ra ks <<< "$rest"
+    python3 $R/tools/pmc_route_summary.py $O/pmcw $wl "" "${ks[@]}" > $O/${TAG}_pmc_summary_$wl.json
+    rm -rf $O/pmcw
+    echo "done pmc $wl"
+  done
 fi
