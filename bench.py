@@ -75,16 +75,16 @@ def parse():
                          "(ddpm_config.py:395-450), unpruned / head-grouped-pruned (prune.py:337-342).  Default: cifar20 + the "
                          "others as `secondary` lines")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
-    ap.add_argument("--in-flight", type=int, choices=[1, 2], default=2,
-                    help="CIFAR workloads: coalitions in flight per GPU - 2 (default, what gad.launch / run_sharded run): one coalition's "
-                         "training phase beside another's sampling phase on two HIP streams; 1: strictly sequential on one stream")
+    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
+                    help="CIFAR workloads: coalitions in flight per GPU - k > 1 (default 3, what gad.launch / run_sharded run): one coalition's "
+                         "sampling phase beside the training phases of the next k - 1, each on its own HIP stream; 1: strictly sequential")
     ap.add_argument("--secondary-steps", type=int, default=10)
     ap.add_argument("--widths", choices=["full", "pruned"], default=None, help="alias: --widths pruned = --workload cifar20-pruned")
     ap.add_argument("--full-coalition", action="store_true", help="time K complete coalitions instead of slices")
     ap.add_argument("--no-cpu-baseline", action="store_true")
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
     ap.add_argument("--no-one-stream-pass", action="store_true",
-                    help="--in-flight 2: skip the second, one-stream pass of the same K steps that gives the roofline's one_stream_* keys")
+                    help="--in-flight > 1: skip the second, one-stream pass of the same K steps that gives the roofline's one_stream_* keys")
     ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
                     help="f32 = the reference's default precision and the headline number; bf16 = bf16-operand "
                          "contractions (fp32 storage/accumulation), the analogue of --mixed_precision: a separate, "
@@ -150,9 +150,14 @@ class SliceRunner:
         self.images_done = 0
         self.n_t = engine.train_scheduler.config.num_train_timesteps
         self.streams = None
-        if in_flight == 2:                                      # CoalitionEngine.run_pipelined's two streams
+        if in_flight > 1:                                       # CoalitionEngine.run_pipelined's streams: [sampler, trainers ...]
             torch.cuda.synchronize(self.dev)
-            self.streams = (torch.cuda.Stream(self.dev), torch.cuda.Stream(self.dev))
+            self.streams = tuple(torch.cuda.Stream(self.dev) for _ in range(in_flight))
+            self.trainers = [self.trainer]
+            for _ in range(in_flight - 2):                      # a further training phase (another coalition's): its own model and optimizer state
+                m_, e_ = engine.load_base()
+                self.trainers.append(engine.make_trainer(m_, e_))
+            self.turn = 0
 
     def train_step(self):
         try:
@@ -188,9 +193,11 @@ class SliceRunner:
         if self.streams is not None:
             # two coalitions in flight: the training phase of one beside the sampling phase of another, each on its own HIP
             # stream (independent work: the small launches of the B = 128 training step fill the tails of the sampler's large ones)
-            with torch.cuda.stream(self.streams[0]):
+            k = self.turn = (self.turn + 1) % len(self.trainers)       # the training phases take turns (run_pipelined)
+            self.trainer = self.trainers[k]
+            with torch.cuda.stream(self.streams[1 + k]):
                 loss = self.train_step()
-            with torch.cuda.stream(self.streams[1]):
+            with torch.cuda.stream(self.streams[0]):
                 for _ in range(N_SAMPLES * DDIM_STEPS // GD_STEPS // (SAMPLE_B * FUSE)):
                     self.sampler_step()
             return loss
@@ -542,8 +549,8 @@ def measure(a, name, steps, warmup, env, headline):
         recs = []
         def show(r):
             log(f"coalition {r.removal_seed}: |S|={r.n_remaining} train {r.total_steps_time:.1f}s sample+score {r.total_sampling_time:.1f}s fid {r.fid_value:.4f}")
-        if a.in_flight == 2:
-            recs = engine.run_pipelined([rank + world * i for i in range(steps)], on_record=show)
+        if a.in_flight > 1:
+            recs = engine.run_pipelined([rank + world * i for i in range(steps)], on_record=show, n_train=a.in_flight - 1)
         else:
             for i in range(steps):                                       # (stdout carries the JSON line only)
                 recs.append(engine.run_coalition(rank + world * i, verbose=False))
@@ -593,7 +600,9 @@ def measure(a, name, steps, warmup, env, headline):
                 run.streams = keep
             n_tr = 0 if a.no_train_rate else 10
             import contextlib
-            on_train_stream = torch.cuda.stream(run.streams[0]) if run.streams is not None else contextlib.nullcontext()
+            on_train_stream = torch.cuda.stream(run.streams[1]) if run.streams is not None else contextlib.nullcontext()
+            if run.streams is not None:
+                run.trainer = run.trainers[0]
             barrier()
             t1 = time.time()
             with on_train_stream:                                       # (the stream whose allocator pool holds the trainer's blocks)
@@ -628,11 +637,11 @@ def measure(a, name, steps, warmup, env, headline):
     f32 = a.precision == "f32"
     dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
     par = {"coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
-    if wl["kind"] == "cifar" and a.in_flight == 2:
-        par = {"coalitions_in_flight": 2 * world,
-               "parallelism": (f"coalition-per-gpu x{world}, two coalitions in flight per GPU: the training phase of one beside the sampling "
-                               "phase of the previous one on two HIP streams (gad.coalition.CoalitionEngine.run_pipelined; --in-flight 1 = "
-                               "strictly sequential)")}
+    if wl["kind"] == "cifar" and a.in_flight > 1:
+        par = {"coalitions_in_flight": a.in_flight * world,
+               "parallelism": (f"coalition-per-gpu x{world}, {a.in_flight} coalitions in flight per GPU: the sampling phase of one beside the "
+                               f"training phase(s) of the next {a.in_flight - 1}, each on its own HIP stream, one optimizer step and one "
+                               "DDIM step enqueued per turn (gad.coalition.CoalitionEngine.run_pipelined; --in-flight 1 = strictly sequential)")}
     if wl["kind"] == "cifar":
         widths = list(wl["widths"]) if wl["widths"] else [128, 256, 256, 256]
         nparam = sum(p.numel() for p in run.model.parameters()) if not a.full_coalition else None
@@ -642,7 +651,7 @@ def measure(a, name, steps, warmup, env, headline):
                     + (f" {nparam / 1e6:.2f}M params" if nparam else "") + " fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; "
                     + ("step = one complete coalition" if a.full_coalition else
                        "step = 1/1000 coalition = 1 train step + 1 sampler step @B=1024"
-                       + (", enqueued on two HIP streams (the train step belongs to the next coalition: independent work)" if a.in_flight == 2 else "")))
+                       + (f", enqueued on {a.in_flight} HIP streams (the train step belongs to a later coalition: independent work)" if a.in_flight > 1 else "")))
         config = {"workload": workload, "score_tail": SCORE_TAIL, **par}
     elif wl["kind"] == "sd":
         out = {"metric": "sd_lora_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}
@@ -686,7 +695,7 @@ def measure(a, name, steps, warmup, env, headline):
         if wl["kind"] == "cifar" and one_stream is not None:
             r1, _, _, ex1 = kernel_report(one_stream, dt_one, peak_tf, a.precision, name)
             roof = out["roofline"]
-            roof["measured"] = ("timed region, two coalitions in flight: a kernel's event bracket there includes the time the other stream's "
+            roof["measured"] = ("timed region, several coalitions in flight: a kernel's event bracket there includes the time the other stream's "
                                 "kernels held part of the chip, so `frac` is the kernel's rate WHILE SHARING; the one_stream_* keys are the "
                                 "same K steps run again on one stream right after the timed region (kernel quality without sharing)")
             for k in ("frac", "achieved", "avg_launch_us", "share_of_step_time", "stage_input_us", "stage_input_gbps", "stage_input_frac_of_hbm_peak",

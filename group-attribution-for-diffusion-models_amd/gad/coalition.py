@@ -46,7 +46,8 @@ class DeviceLoader:
     index_select views; RandomHorizontalFlip is applied per sample on the device.  The last batch
     of an epoch is short (drop_last=False), as in the reference (unlearn.py:373-379)."""
 
-    def __init__(self, dataset, idx: Sequence[int], batch_size: int, device, flip=None):
+    def __init__(self, dataset, idx: Sequence[int], batch_size: int, device, flip=None, generator=None):
+        self.generator = generator                              # None: the device's default generator (seed_everything)
         self.x = dataset.device_tensor(device, idx)             # [n,3,H,W] in [-1,1]
         self.labels = torch.as_tensor([dataset.targets[i] for i in idx], device=device)
         if flip is None:                                        # the dataset's own transform chain decides (datasets.py:412-477)
@@ -58,12 +59,12 @@ class DeviceLoader:
 
     def __iter__(self):
         n = self.x.shape[0]
-        perm = torch.randperm(n, device=self.device)
+        perm = torch.randperm(n, device=self.device, generator=self.generator)
         for s in range(0, n, self.bs):
             sel = perm[s:s + self.bs]
             xb = self.x.index_select(0, sel)
             if self.flip:
-                m = torch.rand(xb.shape[0], device=self.device) < 0.5
+                m = torch.rand(xb.shape[0], device=self.device, generator=self.generator) < 0.5
                 xb = torch.where(m[:, None, None, None], xb.flip(-1), xb)
             yield xb, self.labels.index_select(0, sel)
 
@@ -202,9 +203,9 @@ class CoalitionEngine:
             self.unet_cfg.update(unet_overrides)
         self.gd_steps = gd_steps if gd_steps is not None else self.config["training_steps"]["gd"]
         self.n_samples, self.sample_batch, self.fuse = n_samples, sample_batch, fuse
-        # coalitions in flight on this GPU: 2 = the training phase of one beside the sampling phase of the previous one on two
-        # HIP streams (run_pipelined; what run_sharded / gad.launch use), 1 = strictly one after the other
-        self.in_flight = int(os.environ.get("GAD_IN_FLIGHT", "2"))
+        # coalitions in flight on this GPU: 1 = strictly one after the other; k > 1 = the sampling phase of one beside the training
+        # phases of the next k - 1, each on its own HIP stream (run_pipelined; what run_sharded / gad.launch use)
+        self.in_flight = int(os.environ.get("GAD_IN_FLIGHT", "3"))
         self.num_inference_steps, self.opt_seed, self.by_class, self.preview = num_inference_steps, opt_seed, by_class, preview
         self.dataset = create_dataset(dataset_name, train=True)
         self.n_groups = len(set(self.dataset.targets))
@@ -248,14 +249,20 @@ class CoalitionEngine:
         return global_scores_against_dataset(images01, self.dataset, self.device, 512, self.feature_net.dims)
 
     # -- the cycle -------------------------------------------------------------------------------
-    def train_phase(self, removal_seed: int):
+    def train_phase(self, removal_seed: int, own_generator=False):
         """Generator: the sparsified fine-tuning of one coalition (unlearn.py:548-644) on the CURRENT stream, yielding after every
-        enqueued optimizer step; returns the hand-over state for `sample_phase`.  No host synchronisation inside."""
+        enqueued optimizer step; returns the hand-over state for `sample_phase`.  No host synchronisation inside.
+        `own_generator`: draw from a device generator of this phase's own, seeded like `seed_everything` seeds the default one
+        (same Philox stream, same draws) - for phases that run beside other phases and must not share the default generator."""
         remaining_idx, removed_idx = self.coalition(removal_seed)
-        seed_everything(self.opt_seed)                                    # unlearn.py:359
+        gen = None
+        if own_generator:
+            gen = torch.Generator(device=self.device).manual_seed(self.opt_seed)
+        else:
+            seed_everything(self.opt_seed)                                # unlearn.py:359
         model, ema = self.load_base()
         trainer = self.make_trainer(model, ema)
-        loader = DeviceLoader(self.dataset, remaining_idx, self.config["batch_size"], self.device)
+        loader = DeviceLoader(self.dataset, remaining_idx, self.config["batch_size"], self.device, generator=gen)
         n_t = self.train_scheduler.config.num_train_timesteps
         ev0, ev1 = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         ev0.record()
@@ -263,8 +270,8 @@ class CoalitionEngine:
         loss = torch.zeros(1, device=self.device)
         while steps < self.gd_steps:                                      # unlearn.py:558-642
             for image, _ in loader:
-                noise = torch.randn_like(image)
-                ts = antithetic_timesteps(n_t, image.shape[0], self.device)
+                noise = torch.randn(image.shape, device=image.device, dtype=image.dtype, generator=gen) if gen is not None else torch.randn_like(image)
+                ts = antithetic_timesteps(n_t, image.shape[0], self.device, generator=gen)
                 loss = trainer.step(image, noise, ts)
                 steps += 1
                 yield
@@ -309,54 +316,65 @@ class CoalitionEngine:
                   f"sample+score {rec.total_sampling_time:.1f}s fid {rec.fid_value:.4f}", flush=True)
         return rec
 
-    def run_pipelined(self, seeds: Sequence[int], on_record=None, on_error=None, verbose=False) -> List[CoalitionRecord]:
-        """TWO coalitions in flight on this GPU: while coalition i samples (10 240 images x 100 DDIM steps in launches of 1024
-        images: long kernels that fill the chip) coalition i + 1 fine-tunes (B = 128: short launches that leave CUs idle), each on
-        its own HIP stream - the training step's small launches fill the tails of the sampler's large ones
-        (profiles/r04_two_streams.txt: 91.6 -> 81.7 ms per 1/1000 coalition).  One host thread enqueues both, one optimizer step
-        and one DDIM step per turn (a coalition has 1000 of each), and never runs more than `ahead` turns ahead of the GPU.
+    def run_pipelined(self, seeds: Sequence[int], on_record=None, on_error=None, verbose=False, n_train: int = 2) -> List[CoalitionRecord]:
+        """SEVERAL coalitions in flight on this GPU: while coalition i samples (10 240 images x 100 DDIM steps in launches of 1024
+        images: long kernels that fill the chip) the next coalitions fine-tune (B = 128: short launches that leave CUs idle), each
+        phase on its own HIP stream - the training steps' small launches fill the tails of the sampler's large ones and of each
+        other (profiles/r04_two_streams.txt: 91.6 -> 81.7 ms per 1/1000 coalition with one training stream, -> ~80 with two).
+        One host thread enqueues everything: per turn one DDIM step and one optimizer step (the training phases, up to
+        `n_train`, take turns; a new one starts when the others are past their first half, so that trained models arrive at the
+        rate the sampler consumes them), never more than `ahead` turns ahead of the GPU.
         Every coalition computes exactly what `run_coalition` computes - same kernels, same order on its stream, its own
-        workspace (ops.workspace is per stream), the training phase's device RNG seeded as before; the preview draw of the
-        sampling phase (unlearn.py:761-765: its images are discarded) takes a generator of its own so that it cannot interleave
-        with the next coalition's training draws - records are bit-identical to the sequential run's
-        (tests/test_gpu_engine.py::test_pipelined_coalitions_equal_sequential).
+        workspace (ops.workspace is per stream), its own device generator seeded like `seed_everything` seeds the default one;
+        the preview draw of the sampling phase (unlearn.py:761-765: its images are discarded) takes a generator of its own -
+        records are bit-identical to the sequential run's (tests/test_gpu_engine.py::test_pipelined_coalitions_equal_sequential).
         `on_record(rec)` is called as each coalition finishes (durable append); a coalition whose phase raises is reported
         through `on_error(seed, exc)` and dropped, the others carry on."""
         dev = self.device
         torch.cuda.synchronize(dev)
-        if getattr(self, "_streams", None) is None:           # one pair per engine: ops.workspace keeps 1 GiB of scratch per stream
-            self._streams = (torch.cuda.Stream(dev), torch.cuda.Stream(dev))
-        s_train, s_samp = self._streams
+        if getattr(self, "_streams", None) is None or len(self._streams) != n_train + 1:
+            # one set per engine: ops.workspace keeps 1 GiB of scratch per stream
+            self._streams = tuple(torch.cuda.Stream(dev) for _ in range(n_train + 1))
+        s_samp, s_train = self._streams[0], self._streams[1:]
         todo = list(seeds)
         recs, ahead, marks = [], 8, []
-        train = samp = ready = None           # running train phase, running sample phase, trained state waiting for the sampler
-        train_seed = samp_seed = None
+        slots = [None] * n_train              # running training phases: dict(gen, seed, done)
+        ready = []                            # trained states waiting for the sampler (FIFO)
+        samp, samp_seed, last = None, None, -1
 
         def fail(seed, exc):
             if on_error is None:
                 raise exc
             on_error(seed, exc)
-        while todo or train is not None or samp is not None or ready is not None:
-            if samp is None and ready is not None:
-                s_samp.wait_stream(s_train)                               # the EMA weights were written on the training stream
-                st, ready = ready, None
+        while todo or any(slots) or samp is not None or ready:
+            if samp is None and ready:
+                st = ready.pop(0)
+                s_samp.wait_stream(st.pop("stream"))                      # the EMA weights were written on that training stream
                 samp_seed = st["removal_seed"]
                 g = torch.Generator(device=dev).manual_seed(1_000_003 * self.opt_seed + samp_seed)
                 with torch.cuda.stream(s_samp):
                     samp = self.sample_phase(st, preview_generator=g)
-            if train is None and ready is None and todo:
-                train_seed = todo.pop(0)
-                with torch.cuda.stream(s_train):
-                    train = self.train_phase(train_seed)
-            if train is not None:
+            running = [t for t in slots if t]
+            if todo and len(running) + len(ready) < n_train and all(2 * t["done"] >= self.gd_steps for t in running):
+                k = slots.index(None)
+                seed = todo.pop(0)
+                with torch.cuda.stream(s_train[k]):
+                    slots[k] = dict(gen=self.train_phase(seed, own_generator=True), seed=seed, done=0)
+            order = [(last + 1 + i) % n_train for i in range(n_train)]
+            k = next((i for i in order if slots[i]), None)
+            if k is not None:                                             # one optimizer step, the training phases taking turns
+                last, t = k, slots[k]
                 try:
-                    with torch.cuda.stream(s_train):
-                        next(train)
+                    with torch.cuda.stream(s_train[k]):
+                        next(t["gen"])
+                    t["done"] += 1
                 except StopIteration as e:
-                    train, ready = None, e.value
+                    slots[k] = None
+                    e.value["stream"] = s_train[k]
+                    ready.append(e.value)
                 except Exception as e:                                    # this coalition only
-                    train = None
-                    fail(train_seed, e)
+                    slots[k] = None
+                    fail(t["seed"], e)
             if samp is not None:
                 try:
                     with torch.cuda.stream(s_samp):
@@ -366,17 +384,17 @@ class CoalitionEngine:
                     recs.append(e.value)
                     if verbose:
                         r = e.value
-                        print(f"[coalition {r.removal_seed}] |S|={r.n_remaining} train {r.total_steps_time:.1f}s (beside a sampling phase) "
-                              f"sample+score {r.total_sampling_time:.1f}s (beside a training phase) fid {r.fid_value:.4f}", flush=True)
+                        print(f"[coalition {r.removal_seed}] |S|={r.n_remaining} train {r.total_steps_time:.1f}s sample+score "
+                              f"{r.total_sampling_time:.1f}s (each beside other phases) fid {r.fid_value:.4f}", flush=True)
                     if on_record is not None:
                         on_record(e.value)
                 except Exception as e:
                     samp = None
                     fail(samp_seed, e)
-            # bounded run-ahead: wait for the turn `ahead` turns back on both streams
-            ev = (torch.cuda.Event(), torch.cuda.Event())
-            ev[0].record(s_train)
-            ev[1].record(s_samp)
+            # bounded run-ahead: wait for the turn `ahead` turns back on every stream
+            ev = tuple(torch.cuda.Event() for _ in self._streams)
+            for e_, st_ in zip(ev, self._streams):
+                e_.record(st_)
             marks.append(ev)
             if len(marks) > ahead:
                 for e_ in marks.pop(0):
@@ -603,7 +621,7 @@ def run_sharded(engine, seeds: Sequence[int], db_path: Optional[str] = None, ver
         def on_error(s, e):
             note_failure(s, e, "".join(traceback.format_exception(type(e), e, e.__traceback__)))
             again.append(s)
-        engine.run_pipelined(todo, on_record=on_record, on_error=on_error, verbose=verbose)
+        engine.run_pipelined(todo, on_record=on_record, on_error=on_error, verbose=verbose, n_train=engine.in_flight - 1)
         attempt, todo, failed = 1, (again if retries >= 1 else []), again
     while todo:
         again = []

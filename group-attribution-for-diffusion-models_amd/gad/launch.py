@@ -112,9 +112,9 @@ def _parse(argv=None):
     ap.add_argument("--num_inference_steps", type=int, default=100)
     ap.add_argument("--opt_seed", type=int, default=42)
     ap.add_argument("--mixed_precision", default="no", choices=["no", "fp16", "bf16"])
-    ap.add_argument("--in_flight", type=int, default=2, choices=[1, 2],
-                    help="cifar cycle: coalitions in flight per GPU - 2: the training phase of one beside the sampling phase of the "
-                         "previous one on two HIP streams (CoalitionEngine.run_pipelined); 1: one after the other")
+    ap.add_argument("--in_flight", type=int, default=3, choices=[1, 2, 3],
+                    help="cifar cycle: coalitions in flight per GPU - k > 1: the sampling phase of one beside the training phases of the "
+                         "next k - 1, each on its own HIP stream (CoalitionEngine.run_pipelined); 1: one after the other")
     ap.add_argument("--requeue", type=int, default=1, help="re-entries of the whole launch while seeds are missing")
     ap.add_argument("--retries", type=int, default=1, help="in-process retries of a coalition that raised")
     ap.add_argument("--backend", default="nccl", choices=["nccl", "gloo"])

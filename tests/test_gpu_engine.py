@@ -312,9 +312,12 @@ def test_pipelined_coalitions_equal_sequential(monkeypatch):
                           unet_overrides=dict(block_out_channels=(32, 64, 64, 64), norm_num_groups=8))
     seq = [eng.run_coalition(s) for s in (0, 1, 2)]
     seen = []
-    pip = eng.run_pipelined([0, 1, 2], on_record=seen.append)
+    pip = eng.run_pipelined([0, 1, 2], on_record=seen.append, n_train=1)
     assert [r.removal_seed for r in pip] == [0, 1, 2] and seen == pip
-    for a, b in zip(seq, pip):
+    pip2 = eng.run_pipelined([0, 1, 2, 3, 4], n_train=2)                   # two training phases taking turns beside the sampler
+    assert [r.removal_seed for r in pip2] == [0, 1, 2, 3, 4]
+    seq = seq + [eng.run_coalition(s) for s in (3, 4)]
+    for a, b in list(zip(seq, pip)) + list(zip(seq, pip2)):
         assert (a.removal_seed, a.n_remaining, a.remaining_classes, a.trained_steps) == (b.removal_seed, b.n_remaining, b.remaining_classes, b.trained_steps)
         assert a.fid_value == b.fid_value and a.loss_last == b.loss_last
         assert a.inception_score == b.inception_score and a.precision == b.precision and a.recall == b.recall

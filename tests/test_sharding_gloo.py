@@ -210,7 +210,7 @@ def test_run_sharded_uses_the_pipelined_engine_and_retries_its_failures(tmp_path
         in_flight = 2
         calls = []
 
-        def run_pipelined(self, seeds, on_record=None, on_error=None, verbose=False):
+        def run_pipelined(self, seeds, on_record=None, on_error=None, verbose=False, n_train=2):
             out = []
             for s_ in seeds:
                 self.calls.append(("pipe", s_))
