@@ -38,7 +38,7 @@ if [ "$3" = pmc ]; then
   python3 $R/tools/pmc_wino_summary.py $O $TAG > $O/${TAG}_pmc_summary.json
   cat $O/${TAG}_pmc_summary.json
   # the secondary workloads' dominant families: sd512 (single-pass attention backward at T = 4096, d = 40) and celeba (three-launch F(4x4))
-  for spec in "sd512|attn_bwd1_f32_kernel|attn_delta_kernel|attn_dq_reduce_kernel" "celeba|wino4_output_kernel|wino4_gemm_kernel|, 4, 1>(|wino4_input_kernel"; do
+  for spec in "sd512|attn_bwd1_f32_kernel<40, 4" "celeba|wino4_output_kernel|wino4_gemm_kernel|, 4, 1>("; do
     wl=${spec%%|*}; rest=${spec#*|}
     rm -rf $O/pmcw; mkdir -p $O/pmcw
     for c in FETCH_SIZE WRITE_SIZE; do
