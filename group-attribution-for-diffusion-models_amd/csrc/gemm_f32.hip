@@ -2424,6 +2424,18 @@ static Plan make_plan(const gad_gemm_args* a) {
   // measured +3..7 % on the forward / data-gradient forms (tools/sweep_gemm.py, profiles/r02_sd_gemm_tile_sweep.txt)
   const bool auto_128x64 = a->tile_hint == 0 && a->splitk_hint <= 0 && pl.bm == 64 && pl.splitk == 1 && batch == 1 &&
                            a->M >= 16384 && a->a_mode == GAD_A_KC;
+  // ... and where N is a whole number of 128-wide tiles and the launch is many rounds deep, the 128 x 128 tile measured another
+  // 3-9 % faster (attention projections / 1x1 shortcuts of the CIFAR sampler at B = 1024: tools/ab_dense_tiles.py,
+  // profiles/r04_ab_dense_tiles.txt) - N = 320 / 640 (SD) keep 128 x 64, which pads nothing there
+  if (auto_128x64 && a->N % 128 == 0 && (long)gad_ceil_div(a->M, 128) * (a->N / 128) >= 1024) {
+    pl.bm = 128; pl.bn = 128;
+    pl.tiles_m = (int)gad_ceil_div(a->M, 128);
+    pl.tiles_n = a->N / 128;
+    pl.splitk = 1;
+    pl.ktiles_per_split = kt;
+    pl.nblocks = (long)pl.tiles_m * pl.tiles_n * batch;
+    return pl;
+  }
   if ((a->tile_hint == 3 || auto_128x64) && dense_128x64_ok(a)) {
     pl.bm = 128; pl.bn = 64;
     pl.tiles_m = (int)gad_ceil_div(a->M, 128);
@@ -2747,7 +2759,8 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     // one-launch form (wino4_fused.hip): a (32 tiles x 64 channels) block carries all 36 positions, two workgroups per CU at
     // ~0.2 TF/s executed each (rounds of 512); its epilogue reads the residual under the other workgroup's K loop, which costs
     // about the residual's bytes at 2.2 TB/s (profiles/r04_ab_winograd.txt, r04_wino4_fused_experiments.txt).  Taken when it
-    // models faster than the three-launch form and its blocks fill most of a round.
+    // models no more than 5 % slower than the three-launch form (it moves a third less through HBM, and measured 0-3 % faster at
+    // the shapes where the model calls a draw: profiles/r04_wino4_fused_experiments.txt run C) and its blocks fill most of a round.
     // block shape: 32 tiles x 64 channels, or 64 tiles x 32 channels where that pads the output channels less (N = 96, 160, 224, 288 ...)
     const bool narrow = gad_ceil_div(a->N, 32) * 32 < gad_ceil_div(a->N, 64) * 64;
     const long blocks32 = narrow ? gad_ceil_div(p4.T, 64) * gad_ceil_div(a->N, 32) : gad_ceil_div(p4.T, 32) * gad_ceil_div(a->N, 64);
@@ -2760,7 +2773,7 @@ static bool use_wino(const gad_gemm_args* a, WinoPlan* wp) {
     const double mb3 = (p4.fused4 ? 24.0 : 36.0) * p4.T * a->N * 4.0;
     const double t3 = t_gemm + (mb3 + y_bytes) / 4.9e12 + 12e-6;
     const bool full_ok = !(a->flags & GAD_GEMM_GENERAL_LOADERS) && a->tile_hint != 10;
-    if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (t_full < t3 && blocks32 >= 320))) {
+    if (full_ok && (a->tile_hint == 9 || a->tile_hint == 11 || (t_full < 1.05 * t3 && blocks32 >= 320))) {
       p4.fused4 = 2;
       p4.bm = a->tile_hint == 11 ? 64 : narrow ? 65 : 32;       // 65 names the 64-tile x 32-channel shape (64: the one-workgroup-per-CU form kept for A/B)
       p4.bn = p4.bm == 65 ? 32 : 64;
