@@ -85,10 +85,11 @@ def parse():
     ap.add_argument("--no-kernel-timing", action="store_true", help="do not bracket contraction launches with events")
     ap.add_argument("--no-one-stream-pass", action="store_true",
                     help="--in-flight > 1: skip the second, one-stream pass of the same K steps that gives the roofline's one_stream_* keys")
-    ap.add_argument("--precision", choices=["f32", "bf16"], default="f32",
-                    help="f32 = the reference's default precision and the headline number; bf16 = bf16-operand "
-                         "contractions (fp32 storage/accumulation), the analogue of --mixed_precision: a separate, "
-                         "explicitly labelled line, never the default")
+    ap.add_argument("--precision", choices=["f32", "bf16", "bf16-operands"], default="f32",
+                    help="f32 = the reference's default precision and the headline number; bf16 = what the reference's SD jobs run "
+                         "(--mixed_precision=fp16, setup_train_commands.py:127): half-precision ACTIVATIONS in HBM (gad/half.py) for the "
+                         "SD workloads, bf16 operands elsewhere; bf16-operands = bf16 MFMA operands with fp32 storage everywhere (the "
+                         "earlier rounds' mode, kept for A/B).  Separate, explicitly labelled lines, never the default")
     ap.add_argument("--no-train-rate", action="store_true",
                     help="skip the separate U-Net steps/s measurement (PMC passes: keeps the launch mix = the timed region's)")
     ap.add_argument("--gd-steps", type=int, default=GD_STEPS)
@@ -412,8 +413,13 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     elif "_wino" in nm:       # Winograd F(2x2,3x3): input transform + the 16-position MFMA loop, bracketed together
         kname = (f"wino_input_kernel + wino_gemm_kernel<{'64, 128' if dom_key[1] == 128 else '128, 64'}> ({nm}: the pair is one "
                  "convolution; time = both launches)")
+    elif nm.startswith("hgemm") or nm.startswith("hconv"):      # the half-precision activation path's one contraction engine
+        inst = "2, 2, 2, 5, 32" if dom_key[1] == 320 else "2, 2, 2, 2, 64"
+        kname = f"hgemm_kernel<{inst}> ({nm}: 128 x {dom_key[1]} tiles, bf16 operands by LDS-DMA, splitk {dom_key[2]})"
     else:
         kname = f"gemm_kernel<{nm}, tile {dom_key[1]}, splitk {dom_key[2]}>"
+    if nm.startswith("attn_") and dom_key[3] == 2:
+        kname = kname.replace("_f32_kernel", "_bf16_kernel<.., HIO>").replace("attn_bwd1", "attn_bwd_dq + attn_bwd_dkv")
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json" if workload == "cifar20" else f"pmc_summary_{workload}.json")
     if precision == "f32" and os.path.exists(pmc):
@@ -635,7 +641,11 @@ def measure(a, name, steps, warmup, env, headline):
         return None
 
     f32 = a.precision == "f32"
-    dtype = "f32" if f32 else "bf16 operands, f32 accumulate/storage (NOT the reference default)"
+    half_act = a.precision == "bf16" and wl["kind"] == "sd"           # the SD U-Net has the half-precision activation path (gad/half.py)
+    dtype = ("f32" if f32 else
+             "bf16 activations + gradients in HBM, bf16 MFMA operands, f32 accumulate / statistics / LoRA master weights / optimizer "
+             "(the reference's --mixed_precision=fp16 arithmetic with bf16 as the 16-bit type)" if half_act else
+             "bf16 operands, f32 accumulate/storage (NOT the reference default)")
     par = {"coalitions_in_flight": world, "parallelism": f"coalition-per-gpu x{world}"}
     if wl["kind"] == "cifar" and a.in_flight > 1:
         par = {"coalitions_in_flight": a.in_flight * world,
@@ -658,7 +668,8 @@ def measure(a, name, steps, warmup, env, headline):
         config = {"workload": (f"SD-1.x LoRA sFT training step (BASELINE configs[3]/[4] body, train_text_to_image_lora.py:1215-1311): "
                                f"B={wl['batch']} x 4x{wl['latent']}x{wl['latent']} latents ({8 * wl['latent']}x{8 * wl['latent']} images), ctx [B,77,768], "
                                f"UNet2DConditionModel {run.n_base / 1e6:.1f}M frozen + LoRA r=256 on 32 attentions ({run.n_lora / 1e6:.1f}M trainable), "
-                               f"AdamW + clip, fp32" + ("" if f32 else " storage, bf16 MFMA operands") + "; step = one training step"),
+                               f"AdamW + clip, " + ("fp32" if f32 else "bf16 activations (gad/half.py), fp32 LoRA / optimizer" if half_act
+                                                    else "fp32 storage, bf16 MFMA operands") + "; step = one training step"),
                   "images_per_s": units * wl["batch"] / dt, **par}
     else:
         out = {"metric": "ldm_unet_train_steps_per_sec", "value": units / dt, "unit": "steps/s"}

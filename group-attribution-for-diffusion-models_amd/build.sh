@@ -7,7 +7,7 @@ HIPCC="${HIPCC:-/opt/rocm/bin/hipcc}"
 FLAGS="--offload-arch=gfx950 -O3 -std=c++17 -fPIC -I$HERE/../include -I$HERE/csrc -Wno-unused-result"
 mkdir -p "$HERE/build"
 pids=()
-for f in gemm_f32 wino4_fused attention norm elementwise optim transformer; do
+for f in gemm_f32 wino4_fused attention norm elementwise optim transformer half; do
   src="$HERE/csrc/$f.hip"; obj="$HERE/build/$f.o"
   if [ ! -f "$obj" ] || [ "$src" -nt "$obj" ] || [ "$HERE/csrc/gad_common.h" -nt "$obj" ] || [ "$HERE/csrc/gad_reduce.h" -nt "$obj" ] || [ "$HERE/../include/gad.h" -nt "$obj" ] || [ "$HERE/csrc/gemm_dev.h" -nt "$obj" ]; then
     extra=""
@@ -21,5 +21,5 @@ for f in gemm_f32 wino4_fused attention norm elementwise optim transformer; do
   fi
 done
 for p in "${pids[@]}"; do wait $p; done
-$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{gemm_f32,wino4_fused,attention,norm,elementwise,optim,transformer}.o
+$HIPCC --offload-arch=gfx950 -shared -fPIC -o "$OUT" "$HERE"/build/{gemm_f32,wino4_fused,attention,norm,elementwise,optim,transformer,half}.o
 echo "built $OUT"

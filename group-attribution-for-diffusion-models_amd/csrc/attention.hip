@@ -1076,16 +1076,31 @@ struct CfgH {
 
 __device__ __forceinline__ f32x4 mfma16h(bf16x8_t a, bf16x8_t b, f32x4 c) { return __builtin_amdgcn_mfma_f32_16x16x32_bf16(a, b, c, 0, 0, 0); }
 
-// issue the fp32 loads of rows row0 .. row0+KV-1 (zeros past T)
-template <int D>
-__device__ __forceinline__ void tile_fetch(f32x4 (&r)[CfgH<D>::SLOTS], const float* base, int ld, int row0, int T) {
+// storage type of q / k / v / o and their gradients: fp32 (operand_precision = 1 of gad_attention_*) or bf16 (gad_h_attention_*:
+// the half-precision activation path, strides in elements)
+template <bool HIO> struct IoT { typedef float type; };
+template <> struct IoT<true> { typedef unsigned short type; };
+__device__ __forceinline__ f32x4 load4(const float* p) { return *reinterpret_cast<const f32x4*>(p); }
+__device__ __forceinline__ f32x4 load4(const unsigned short* p) {
+  const unsigned long long u = *reinterpret_cast<const unsigned long long*>(p);
+  const unsigned lo = (unsigned)u, hi = (unsigned)(u >> 32);
+  return f32x4{__uint_as_float(lo << 16), __uint_as_float(lo & 0xffff0000u), __uint_as_float(hi << 16), __uint_as_float(hi & 0xffff0000u)};
+}
+__device__ __forceinline__ void store4(float* p, f32x4 v) { *reinterpret_cast<f32x4*>(p) = v; }
+__device__ __forceinline__ void store4(unsigned short* p, f32x4 v) {
+  const bf16x4_t h = {(__bf16)v[0], (__bf16)v[1], (__bf16)v[2], (__bf16)v[3]};
+  *reinterpret_cast<bf16x4_t*>(p) = h;
+}
+// issue the loads of rows row0 .. row0+KV-1 (zeros past T)
+template <int D, typename T>
+__device__ __forceinline__ void tile_fetch(f32x4 (&r)[CfgH<D>::SLOTS], const T* base, int ld, int row0, int T_) {
   using C = CfgH<D>;
 #pragma unroll
   for (int i = 0; i < C::SLOTS; ++i) {
     const int f = threadIdx.x + NT * i;
     const int row = f / (D / 4), c4 = (f - row * (D / 4)) * 4;
-    const bool ok = f < C::NF4 && row0 + row < T;
-    r[i] = ok ? *reinterpret_cast<const f32x4*>(base + (long)(row0 + row) * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const bool ok = f < C::NF4 && row0 + row < T_;
+    r[i] = ok ? load4(base + (long)(row0 + row) * ld + c4) : f32x4{0.f, 0.f, 0.f, 0.f};
   }
 }
 // convert and write a fetched tile into a row-major bf16 image with row stride S
@@ -1102,6 +1117,41 @@ __device__ __forceinline__ void tile_commit(unsigned short* img, const f32x4 (&r
     }
   }
 }
+// one streamed tile's registers: fp32 storage -> float4 slots converted at the commit; bf16 storage -> 16-byte slots copied as they are
+template <int D, bool HIO>
+struct TileIO {
+  f32x4 r[CfgH<D>::SLOTS];
+  __device__ __forceinline__ void fetch(const float* base, int ld, int row0, int T_) { tile_fetch<D>(r, base, ld, row0, T_); }
+  template <int S>
+  __device__ __forceinline__ void commit(unsigned short* img) const { tile_commit<D, S>(img, r); }
+};
+template <int D>
+struct TileIO<D, true> {
+  typedef unsigned int u32x4_t __attribute__((ext_vector_type(4)));
+  static constexpr int N8 = KV * D / 8, SLOTS8 = (N8 + NT - 1) / NT;
+  u32x4_t r[SLOTS8];
+  __device__ __forceinline__ void fetch(const unsigned short* base, int ld, int row0, int T_) {
+#pragma unroll
+    for (int i = 0; i < SLOTS8; ++i) {
+      const int f = threadIdx.x + NT * i;
+      const int row = f / (D / 8), c8 = (f - row * (D / 8)) * 8;
+      const bool ok = f < N8 && row0 + row < T_;
+      r[i] = ok ? *reinterpret_cast<const u32x4_t*>(base + (long)(row0 + row) * ld + c8) : u32x4_t{0u, 0u, 0u, 0u};
+    }
+  }
+  template <int S>
+  __device__ __forceinline__ void commit(unsigned short* img) const {
+    static_assert((S * 2) % 16 == 0, "image rows must keep 16-byte alignment");
+#pragma unroll
+    for (int i = 0; i < SLOTS8; ++i) {
+      const int f = threadIdx.x + NT * i;
+      if (f < N8) {
+        const int row = f / (D / 8), c8 = (f - row * (D / 8)) * 8;
+        *reinterpret_cast<u32x4_t*>(img + row * S + c8) = r[i];
+      }
+    }
+  }
+};
 // fragment whose lanes run along the image's rows: lane (row r0 + (l & 15), k group g = l >> 4) -> k = 32 s + 8 g + j
 template <int S>
 __device__ __forceinline__ bf16x8_t row_frag_h(const unsigned short* img, int r0, int s) {
@@ -1119,18 +1169,18 @@ __device__ __forceinline__ bf16x8_t col_frag_h(const unsigned short* img, int rb
   const s16x8_t both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
   return __builtin_bit_cast(bf16x8_t, both);
 }
-// loop-invariant row fragments straight from global memory (fp32 -> bf16, zero past the head dim / the sequence)
-template <int D>
-__device__ __forceinline__ void row_frag_global_h(const float* base, int ld, int row, bool ok, float mul, bf16x8_t (&f)[CfgH<D>::KS]) {
+// loop-invariant row fragments straight from global memory (-> bf16, zero past the head dim / the sequence)
+template <int D, typename T>
+__device__ __forceinline__ void row_frag_global_h(const T* base, int ld, int row, bool ok, float mul, bf16x8_t (&f)[CfgH<D>::KS]) {
   using C = CfgH<D>;
   const int g = (threadIdx.x & 63) >> 4;
-  const float* p = base + (long)(ok ? row : 0) * ld;
+  const T* p = base + (long)(ok ? row : 0) * ld;
 #pragma unroll
   for (int s = 0; s < C::KS; ++s) {
     const int k = 32 * s + 8 * g;
     const bool in = ok && k < D;                      // D % 8 == 0: a group of 8 is all inside or all outside
-    const f32x4 a = in ? *reinterpret_cast<const f32x4*>(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
-    const f32x4 b = in ? *reinterpret_cast<const f32x4*>(p + k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 a = in ? load4(p + k) : f32x4{0.f, 0.f, 0.f, 0.f};
+    const f32x4 b = in ? load4(p + k + 4) : f32x4{0.f, 0.f, 0.f, 0.f};
     f[s] = bf16x8_t{(__bf16)(a[0] * mul), (__bf16)(a[1] * mul), (__bf16)(a[2] * mul), (__bf16)(a[3] * mul),
                     (__bf16)(b[0] * mul), (__bf16)(b[1] * mul), (__bf16)(b[2] * mul), (__bf16)(b[3] * mul)};
   }
@@ -1142,16 +1192,17 @@ __device__ __forceinline__ void zero_lds(unsigned short* lds, int n_elems) {
   for (int i = threadIdx.x * 8; i < n_elems; i += NT * 8) *reinterpret_cast<f32x4*>(lds + i) = f32x4{0.f, 0.f, 0.f, 0.f};
 }
 
-template <int D, int NQ>
+template <int D, int NQ, bool HIO = false>
 __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
   using C = CfgH<D>;
+  using T = typename IoT<HIO>::type;
   constexpr int KIMG = KV * C::SK, VIMG = KV * C::SV, BUF = (KIMG + VIMG + 7) / 8 * 8;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image]
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
-  const float* Q = p.q + b * p.sq + h * D;
-  const float* K = p.k + b * p.sk + h * D;
-  const float* V = p.v + b * p.sv + h * D;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.sq + h * D;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.sk + h * D;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.sv + h * D;
   const int qw = blk * (64 * NQ) + wave * (16 * NQ);
 
   bf16x8_t qf[NQ][C::KS];
@@ -1168,11 +1219,11 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
 
   zero_lds(ldsh, 2 * BUF);          // pad columns (k >= D of the K image, dv >= D of the V image) stay zero for good
   __syncthreads();
-  f32x4 rk[C::SLOTS], rv[C::SLOTS];
-  tile_fetch<D>(rk, K, p.ldk, 0, p.Tk);
-  tile_fetch<D>(rv, V, p.ldv, 0, p.Tk);
-  tile_commit<D, C::SK>(ldsh, rk);
-  tile_commit<D, C::SV>(ldsh + KIMG, rv);
+  TileIO<D, HIO> rk, rv;
+  rk.fetch(K, p.ldk, 0, p.Tk);
+  rv.fetch(V, p.ldv, 0, p.Tk);
+  rk.template commit<C::SK>(ldsh);
+  rv.template commit<C::SV>(ldsh + KIMG);
   __syncthreads();
 
   const int ntiles = (p.Tk + KV - 1) / KV;
@@ -1181,8 +1232,8 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
     const unsigned short* vimg = kimg + KIMG;
     const bool more = it + 1 < ntiles;
     if (more) {
-      tile_fetch<D>(rk, K, p.ldk, (it + 1) * KV, p.Tk);
-      tile_fetch<D>(rv, V, p.ldv, (it + 1) * KV, p.Tk);
+      rk.fetch(K, p.ldk, (it + 1) * KV, p.Tk);
+      rv.fetch(V, p.ldv, (it + 1) * KV, p.Tk);
     }
     f32x4 s[2][NQ];
 #pragma unroll
@@ -1236,13 +1287,13 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
     }
     if (more) {
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
-      tile_commit<D, C::SK>(nb, rk);
-      tile_commit<D, C::SV>(nb + KIMG, rv);
+      rk.template commit<C::SK>(nb);
+      rv.template commit<C::SV>(nb + KIMG);
     }
     __syncthreads();
   }
 
-  float* O = p.o + b * p.so + h * D;
+  T* O = reinterpret_cast<T*>(p.o) + b * p.so + h * D;
 #pragma unroll
   for (int t = 0; t < NQ; ++t) {
     const float lt = xsum16_32(l[t]);
@@ -1252,7 +1303,7 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
 #pragma unroll
       for (int i = 0; i < C::NDV; ++i) {
         const int dv = 16 * i + 4 * g;
-        if (dv < D) *reinterpret_cast<f32x4*>(O + (long)row * p.ldo + dv) = o[i][t] * inv;
+        if (dv < D) store4(O + (long)row * p.ldo + dv, o[i][t] * inv);
       }
       if (g == 0 && p.lse) p.lse[(long)bh * p.Tq + row] = m[t] + __builtin_amdgcn_logf(lt);
     }
@@ -1262,20 +1313,21 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
 // dQ, bf16 operands: workgroup = 64 queries, wave = 16; K and V tiles in ONE image type (row stride SV) read both along
 // rows (S^T = K Q^T, dP^T = V dO^T) and transposed (dQ^T += K^T dS^T).  Row reads past the head dim meet zero B
 // operands (the loop-invariant fragments are zero there), so whatever finite bf16 they pick up contributes nothing.
-template <int D>
+template <int D, bool HIO = false>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
   using C = CfgH<D>;
+  using T = typename IoT<HIO>::type;
   constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];          // [2][K image | V image] + tail pad
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
-  const float* K = p.k + b * p.sk + h * D;
-  const float* V = p.v + b * p.sv + h * D;
+  const T* K = reinterpret_cast<const T*>(p.k) + b * p.sk + h * D;
+  const T* V = reinterpret_cast<const T*>(p.v) + b * p.sv + h * D;
   const int row = blk * 64 + wave * 16 + c;
   const bool rok = row < p.Tq;
   bf16x8_t qf[C::KS], dof[C::KS];
-  row_frag_global_h<D>(p.q + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
-  row_frag_global_h<D>(p.d_o + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
+  row_frag_global_h<D>(reinterpret_cast<const T*>(p.q) + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
+  row_frag_global_h<D>(reinterpret_cast<const T*>(p.d_o) + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
   const float L2 = rok ? p.lse[(long)bh * p.Tq + row] : 0.f;
   const float dl = rok ? p.delta[(long)bh * p.Tq + row] : 0.f;
   f32x4 dq[C::NDV];
@@ -1284,11 +1336,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
 
   zero_lds(ldsh, 2 * BUF + 64);
   __syncthreads();
-  f32x4 rk[C::SLOTS], rv[C::SLOTS];
-  tile_fetch<D>(rk, K, p.ldk, 0, p.Tk);
-  tile_fetch<D>(rv, V, p.ldv, 0, p.Tk);
-  tile_commit<D, C::SV>(ldsh, rk);
-  tile_commit<D, C::SV>(ldsh + IMG, rv);
+  TileIO<D, HIO> rk, rv;
+  rk.fetch(K, p.ldk, 0, p.Tk);
+  rv.fetch(V, p.ldv, 0, p.Tk);
+  rk.template commit<C::SV>(ldsh);
+  rv.template commit<C::SV>(ldsh + IMG);
   __syncthreads();
   const int ntiles = (p.Tk + KV - 1) / KV;
   for (int it = 0; it < ntiles; ++it) {
@@ -1296,8 +1348,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
     const unsigned short* vimg = kimg + IMG;
     const bool more = it + 1 < ntiles;
     if (more) {
-      tile_fetch<D>(rk, K, p.ldk, (it + 1) * KV, p.Tk);
-      tile_fetch<D>(rv, V, p.ldv, (it + 1) * KV, p.Tk);
+      rk.fetch(K, p.ldk, (it + 1) * KV, p.Tk);
+      rv.fetch(V, p.ldv, (it + 1) * KV, p.Tk);
     }
     f32x4 ds[2];
 #pragma unroll
@@ -1320,37 +1372,38 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
     for (int i = 0; i < C::NDV; ++i) dq[i] = mfma16h(col_frag_h<C::SV>(kimg, 0, 16 * i), dsb, dq[i]);
     if (more) {
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
-      tile_commit<D, C::SV>(nb, rk);
-      tile_commit<D, C::SV>(nb + IMG, rv);
+      rk.template commit<C::SV>(nb);
+      rv.template commit<C::SV>(nb + IMG);
     }
     __syncthreads();
   }
   if (rok) {
-    float* DQ = p.dq + b * p.sdq + h * D + (long)row * p.lddq;
+    T* DQ = reinterpret_cast<T*>(p.dq) + b * p.sdq + h * D + (long)row * p.lddq;
 #pragma unroll
     for (int i = 0; i < C::NDV; ++i) {
       const int kk = 16 * i + 4 * g;
-      if (kk < D) *reinterpret_cast<f32x4*>(DQ + kk) = dq[i] * p.scale;
+      if (kk < D) store4(DQ + kk, dq[i] * p.scale);
     }
   }
 }
 
 // dK / dV, bf16 operands: workgroup = 64 keys, wave = 16; Q and dO tiles in one image type, read along rows for
 // S = Q K^T and dP = dO V^T and transposed for dV^T += dO^T P and dK^T += Q^T dS.
-template <int D>
+template <int D, bool HIO = false>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) {
   using C = CfgH<D>;
+  using T = typename IoT<HIO>::type;
   constexpr int IMG = KV * C::SV, BUF = 2 * IMG;
   extern __shared__ __attribute__((aligned(16))) unsigned short ldsh[];
   const int wave = threadIdx.x >> 6, lane = threadIdx.x & 63, c = lane & 15, g = lane >> 4;
   const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
-  const float* Q = p.q + b * p.sq + h * D;
-  const float* DO = p.d_o + b * p.sdo + h * D;
+  const T* Q = reinterpret_cast<const T*>(p.q) + b * p.sq + h * D;
+  const T* DO = reinterpret_cast<const T*>(p.d_o) + b * p.sdo + h * D;
   const int key = blk * 64 + wave * 16 + c;
   const bool kok = key < p.Tk;
   bf16x8_t kf[C::KS], vf[C::KS];
-  row_frag_global_h<D>(p.k + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
-  row_frag_global_h<D>(p.v + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
+  row_frag_global_h<D>(reinterpret_cast<const T*>(p.k) + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
+  row_frag_global_h<D>(reinterpret_cast<const T*>(p.v) + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
   f32x4 dk[C::NDV], dv[C::NDV];
 #pragma unroll
   for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
@@ -1359,11 +1412,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
 
   zero_lds(ldsh, 2 * BUF + 64);
   __syncthreads();
-  f32x4 rq[C::SLOTS], rg[C::SLOTS];
-  tile_fetch<D>(rq, Q, p.ldq, 0, p.Tq);
-  tile_fetch<D>(rg, DO, p.lddo, 0, p.Tq);
-  tile_commit<D, C::SV>(ldsh, rq);
-  tile_commit<D, C::SV>(ldsh + IMG, rg);
+  TileIO<D, HIO> rq, rg;
+  rq.fetch(Q, p.ldq, 0, p.Tq);
+  rg.fetch(DO, p.lddo, 0, p.Tq);
+  rq.template commit<C::SV>(ldsh);
+  rg.template commit<C::SV>(ldsh + IMG);
   __syncthreads();
   const int ntiles = (p.Tq + KV - 1) / KV;
   for (int it = 0; it < ntiles; ++it) {
@@ -1371,8 +1424,8 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
     const unsigned short* gimg = qimg + IMG;
     const bool more = it + 1 < ntiles;
     if (more) {
-      tile_fetch<D>(rq, Q, p.ldq, (it + 1) * KV, p.Tq);
-      tile_fetch<D>(rg, DO, p.lddo, (it + 1) * KV, p.Tq);
+      rq.fetch(Q, p.ldq, (it + 1) * KV, p.Tq);
+      rg.fetch(DO, p.lddo, (it + 1) * KV, p.Tq);
     }
     f32x4 pr[2], ds[2];
 #pragma unroll
@@ -1401,20 +1454,20 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
     }
     if (more) {
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
-      tile_commit<D, C::SV>(nb, rq);
-      tile_commit<D, C::SV>(nb + IMG, rg);
+      rq.template commit<C::SV>(nb);
+      rg.template commit<C::SV>(nb + IMG);
     }
     __syncthreads();
   }
   if (kok) {
-    float* DK = p.dk + b * p.sdk + h * D + (long)key * p.lddk;
-    float* DV = p.dv + b * p.sdv + h * D + (long)key * p.lddv;
+    T* DK = reinterpret_cast<T*>(p.dk) + b * p.sdk + h * D + (long)key * p.lddk;
+    T* DV = reinterpret_cast<T*>(p.dv) + b * p.sdv + h * D + (long)key * p.lddv;
 #pragma unroll
     for (int i = 0; i < C::NDV; ++i) {
       const int kk = 16 * i + 4 * g;
       if (kk < D) {
-        *reinterpret_cast<f32x4*>(DK + kk) = dk[i] * p.scale;
-        *reinterpret_cast<f32x4*>(DV + kk) = dv[i];
+        store4(DK + kk, dk[i] * p.scale);
+        store4(DV + kk, dv[i]);
       }
     }
   }
@@ -1616,6 +1669,74 @@ static int launch_bwd_h(AttnDev d, float* delta, hipStream_t st) {
   return 0;
 }
 
+// ---- half-precision I/O launchers (gad_h_attention_*): the bf16-operand kernels with 16-bit loads / stores ----
+template <int D>
+__global__ void attn_delta_h_kernel(const AttnDev p, float* delta) {
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+  const long total = (long)p.B * p.Tq * p.heads;
+  if (idx >= total) return;
+  const int h = (int)(idx % p.heads);
+  const long bq = idx / p.heads;
+  const int q = (int)(bq % p.Tq), b = (int)(bq / p.Tq);
+  const unsigned short* o = reinterpret_cast<const unsigned short*>(p.o) + b * p.so + (long)q * p.ldo + h * D;
+  const unsigned short* g = reinterpret_cast<const unsigned short*>(p.d_o) + b * p.sdo + (long)q * p.lddo + h * D;
+  float acc = 0.f;
+#pragma unroll
+  for (int i = 0; i < D; i += 4) {
+    const f32x4 a = load4(o + i), d = load4(g + i);
+    acc += a[0] * d[0] + a[1] * d[1] + a[2] * d[2] + a[3] * d[3];
+  }
+  delta[((long)b * p.heads + h) * p.Tq + q] = acc;
+}
+template <int D, int NQ>
+static int launch_fwd_hio(AttnDev d, hipStream_t st) {
+  using C = CfgH<D>;
+  static unsigned lds_set = 0;
+  const int bytes = 2 * ((KV * C::SK + KV * C::SV + 7) / 8 * 8) * (int)sizeof(unsigned short);
+  if (set_lds(attn_fwd_bf16_kernel<D, NQ, true>, bytes, "gad_h_attention_fwd", &lds_set)) return 1;
+  const dim3 grid = grid_of(d, d.Tq, 64 * NQ);
+  hipLaunchKernelGGL((attn_fwd_bf16_kernel<D, NQ, true>), grid, dim3(NT), bytes, st, d);
+  return 0;
+}
+template <int D>
+static int launch_bwd_hio(AttnDev d, float* delta, hipStream_t st) {
+  using C = CfgH<D>;
+  static unsigned lds_set_q = 0, lds_set_kv = 0;
+  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short);
+  if (set_lds(attn_bwd_dq_bf16_kernel<D, true>, bytes, "gad_h_attention_bwd", &lds_set_q) ||
+      set_lds(attn_bwd_dkv_bf16_kernel<D, true>, bytes, "gad_h_attention_bwd", &lds_set_kv)) return 1;
+  const long total = (long)d.B * d.Tq * d.heads;
+  hipLaunchKernelGGL((attn_delta_h_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
+  dim3 grid = grid_of(d, d.Tq, 64);
+  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
+  grid = grid_of(d, d.Tk, 64);
+  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
+  return 0;
+}
+template <int D>
+static int fwd_dim_hio(const AttnDev& d, hipStream_t st, bool wide) {
+  if constexpr (D <= 96) { if (wide) return launch_fwd_hio<D, 2>(d, st); }
+  return launch_fwd_hio<D, 1>(d, st);
+}
+// bf16 I/O contract: head dim an exact instance (multiple of 8, <= 160), 16-byte aligned rows (strides multiples of 8 elements)
+static int check_hio(const gad_attention_args* a, bool bwd, const char* who) {
+  if (check_common(a, who)) return 1;
+  GAD_CHECK(exact_instance(a->d) && a->d <= 160, "%s: head dim %d has no bf16-I/O instance", who, a->d);
+  auto al = [](const void* p) { return (reinterpret_cast<uintptr_t>(p) & 15) == 0; };
+  GAD_CHECK(al(a->q) && al(a->k) && al(a->v) && al(a->o), "%s: q / k / v / o must be 16-byte aligned", who);
+  GAD_CHECK(a->ldq % 8 == 0 && a->ldk % 8 == 0 && a->ldv % 8 == 0 && a->ldo % 8 == 0 && a->stride_q % 8 == 0 && a->stride_k % 8 == 0 &&
+            a->stride_v % 8 == 0 && a->stride_o % 8 == 0, "%s: strides must be multiples of 8 elements", who);
+  if (bwd) {
+    GAD_CHECK(a->lse && a->d_o && a->delta && a->dq && a->dk && a->dv, "%s: null pointer (lse / d_o / delta / dq / dk / dv)", who);
+    GAD_CHECK(al(a->d_o) && al(a->dq) && al(a->dk) && al(a->dv), "%s: gradients must be 16-byte aligned", who);
+    GAD_CHECK(a->ld_do % 8 == 0 && a->ld_dq % 8 == 0 && a->ld_dk % 8 == 0 && a->ld_dv % 8 == 0 && a->stride_do % 8 == 0 &&
+              a->stride_dq % 8 == 0 && a->stride_dk % 8 == 0 && a->stride_dv % 8 == 0, "%s: gradient strides must be multiples of 8 elements", who);
+    const int w = a->heads * a->d;
+    GAD_CHECK(a->ld_do >= w && a->ld_dq >= w && a->ld_dk >= w && a->ld_dv >= w, "%s: a gradient row stride is smaller than heads*d = %d", who, w);
+  }
+  return 0;
+}
+
 // one instance dim: pick the form (RG / bf16 / f32, queries per workgroup)
 template <int D>
 static int fwd_dim(const AttnDev& d, hipStream_t st, bool rg, bool bf16, bool wide, bool two_kernel_legacy) {
@@ -1690,5 +1811,36 @@ extern "C" int gad_attention_bwd(const gad_attention_args* a, void* stream) {
   }
   if (rc) return rc;
   GAD_LAUNCH_CHECK("gad_attention_bwd");
+  return 0;
+}
+
+#define GAD_ATTN_HIO_DIMS(X) X(16) X(24) X(32) X(40) X(48) X(64) X(80) X(96) X(128) X(160)
+extern "C" int gad_h_attention_fwd(const gad_attention_args* a, void* stream) {
+  if (check_hio(a, false, "gad_h_attention_fwd")) return 1;
+  const AttnDev d = make_dev(a);
+  hipStream_t st = (hipStream_t)stream;
+  const bool wide = gad_ceil_div(a->Tq, 128) * a->B * a->heads >= 512;
+  int rc = 1;
+  switch (a->d) {
+#define X(DIM) case DIM: rc = fwd_dim_hio<DIM>(d, st, wide); break;
+    GAD_ATTN_HIO_DIMS(X)
+#undef X
+  }
+  if (rc) return rc;
+  GAD_LAUNCH_CHECK("gad_h_attention_fwd");
+  return 0;
+}
+extern "C" int gad_h_attention_bwd(const gad_attention_args* a, void* stream) {
+  if (check_hio(a, true, "gad_h_attention_bwd")) return 1;
+  const AttnDev d = make_dev(a);
+  hipStream_t st = (hipStream_t)stream;
+  int rc = 1;
+  switch (a->d) {
+#define X(DIM) case DIM: rc = launch_bwd_hio<DIM>(d, a->delta, st); break;
+    GAD_ATTN_HIO_DIMS(X)
+#undef X
+  }
+  if (rc) return rc;
+  GAD_LAUNCH_CHECK("gad_h_attention_bwd");
   return 0;
 }

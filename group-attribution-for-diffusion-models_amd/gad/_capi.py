@@ -64,6 +64,23 @@ class AttentionArgs(C.Structure):
 ATTN_TWO_KERNEL_BWD, ATTN_NARROW_FWD = 1, 2
 
 
+class HGemmArgs(C.Structure):
+    """gad_hgemm_args (include/gad.h): the half-precision activation path's contraction"""
+    _fields_ = [("A", C.c_void_p), ("A2", C.c_void_p), ("B", C.c_void_p), ("B2", C.c_void_p), ("C", C.c_void_p),
+                ("M", C.c_int32), ("N", C.c_int32), ("K", C.c_int32),
+                ("lda", C.c_int32), ("lda2", C.c_int32), ("ldb", C.c_int32), ("ldb2", C.c_int32), ("ldc", C.c_int32),
+                ("k_split", C.c_int32), ("conv", C.c_int32),
+                ("H", C.c_int32), ("W", C.c_int32), ("Cin", C.c_int32),
+                ("Ho", C.c_int32), ("Wo", C.c_int32), ("KH", C.c_int32), ("KW", C.c_int32), ("stride", C.c_int32),
+                ("pad_t", C.c_int32), ("pad_l", C.c_int32), ("upsample", C.c_int32),
+                ("alpha", C.c_float), ("bias", C.c_void_p), ("rowadd", C.c_void_p),
+                ("rows_per_group", C.c_int32), ("ld_rowadd", C.c_int32),
+                ("residual", C.c_void_p), ("ldr", C.c_int32),
+                ("out_f32", C.c_int32), ("accumulate", C.c_int32),
+                ("ws", C.c_void_p), ("ws_bytes", C.c_int64),
+                ("tile_hint", C.c_int32), ("splitk_hint", C.c_int32)]
+
+
 class AdamArgs(C.Structure):
     _fields_ = [("p", C.c_void_p), ("g", C.c_void_p), ("m", C.c_void_p), ("v", C.c_void_p), ("ema", C.c_void_p),
                 ("n", C.c_int64), ("sumsq", C.c_void_p), ("max_norm", C.c_float),
@@ -128,6 +145,23 @@ SIGNATURES = {
     "gad_sumsq": (C.c_int, [_vp, _vp, _i64, _vp, _i64, _vp]),
     "gad_clip_adam_ema": (C.c_int, [C.POINTER(AdamArgs), _vp]),
     "gad_ema_update": (C.c_int, [_vp, _vp, _i64, _f32, _vp]),
+    # half-precision activation path (csrc/half.hip, csrc/attention.hip)
+    "gad_hgemm_workspace_bytes": (_i64, [C.POINTER(HGemmArgs)]),
+    "gad_hgemm_plan": (C.c_int, [C.POINTER(HGemmArgs), C.POINTER(_i32), C.POINTER(_i32)]),
+    "gad_hgemm": (C.c_int, [C.POINTER(HGemmArgs), _vp]),
+    "gad_h_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
+    "gad_h_cast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "gad_h_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
+    "gad_h_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
+    "gad_h_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_h_groupnorm_silu_bwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),
+    "gad_h_layernorm_fwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _f32, _vp]),
+    "gad_h_layernorm_bwd": (C.c_int, [_vp, _vp, _vp, _vp, _vp, _vp, _vp, _i64, _i32, _vp]),
+    "gad_h_geglu_fwd": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "gad_h_geglu_bwd": (C.c_int, [_vp, _vp, _vp, _i64, _i32, _vp]),
+    "gad_h_upsample2x_bwd": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _vp]),
+    "gad_h_attention_fwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
+    "gad_h_attention_bwd": (C.c_int, [C.POINTER(AttentionArgs), _vp]),
 }
 
 _lib = None

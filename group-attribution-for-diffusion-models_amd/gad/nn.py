@@ -61,7 +61,7 @@ class Linear(nn.Module):
             return ops.linear(x, self.weight, self.bias, residual)
         # y = xW^T + b + scale * up(down(x))  (LoRACompatibleLinear)
         ll = self.lora_layer
-        if ops.lora_fusable(self.weight.shape[1], self.weight.shape[0], ll.rank):
+        if x.dtype == torch.bfloat16 or ops.lora_fusable(self.weight.shape[1], self.weight.shape[0], ll.rank):      # (the half path pads ragged ranks)
             s = scale * (ll.network_alpha / ll.rank if ll.network_alpha is not None else 1.0)
             return ops.lora_linear(x, self.weight, self.bias, ll.down.weight, ll.up.weight, s, residual)   # one K-concatenated launch
         # ragged ranks that are not multiples of 4: the side path accumulates into the base GEMM's output (two launches)
@@ -123,7 +123,7 @@ class ResnetBlock2D(nn.Module):
 
     def forward(self, x, temb_act, x2=None):
         """x2: the block input is cat([x, x2], channels) (up blocks); norm1 and conv_shortcut read both in place."""
-        if not torch.is_grad_enabled():
+        if not torch.is_grad_enabled() and x.dtype != torch.bfloat16:
             # sampling: each norm -> silu -> conv half is one fused op - where the convolution takes the Winograd F(4x4) route the
             # norm writes the route's transformed input directly (ops.gn_silu_conv3x3_raw), else the two ordinary launches run
             n1, n2 = self.norm1, self.norm2
@@ -144,7 +144,7 @@ class ResnetBlock2D(nn.Module):
 
     def cat_in_place_ok(self, x, x2):
         """Inference only, and only when both consumers of the concatenation can gather from two sources."""
-        return (not torch.is_grad_enabled() and self.conv_shortcut is not None
+        return (not torch.is_grad_enabled() and self.conv_shortcut is not None and x.dtype != torch.bfloat16
                 and ops.two_source_ok(x.shape[-1], x2.shape[-1])
                 and ops.group_norm_two_source_ok(x, x2, self.norm1.num_groups))
 

@@ -108,7 +108,9 @@ def _deliver(param, grad):
 # ----------------------------------------------------------------------------------
 # raw contraction launches
 # ----------------------------------------------------------------------------------
-OPERAND_PRECISION = [0]      # 0: fp32 operands (reference default); 1: bf16 operands allowed (see gad.h)
+OPERAND_PRECISION = [0]      # 0: fp32 operands (reference default); 1: bf16 operands, fp32 storage (see gad.h); 2: bf16 ACTIVATIONS
+#                              (gad/half.py: models that support it keep activations and their gradients in bf16; everything
+#                              that still flows as fp32 - conv_in, the time-embedding MLP - runs as mode 1)
 
 
 class operand_precision:
@@ -118,9 +120,9 @@ class operand_precision:
     everything else, and all storage, stays fp32."""
 
     def __init__(self, name):
-        if name not in ("f32", "fp32", "no", "bf16"):
-            raise ValueError(f"operand precision {name!r}: use 'f32' or 'bf16'")
-        self.value = 1 if name == "bf16" else 0
+        if name not in ("f32", "fp32", "no", "bf16", "bf16-operands", "bf16-activations"):
+            raise ValueError(f"operand precision {name!r}: use 'f32', 'bf16' (= 'bf16-activations') or 'bf16-operands'")
+        self.value = {"bf16": 2, "bf16-activations": 2, "bf16-operands": 1}.get(name, 0)
 
     def __enter__(self):
         self.prev = OPERAND_PRECISION[0]
@@ -134,9 +136,16 @@ class operand_precision:
 
 def set_operand_precision(name):
     """Process-wide form of `operand_precision` for the entry points' --mixed_precision flag.  "fp16" maps to
-    bf16 operands: bf16 is the MI355X-native 16-bit operand type and, with fp32's exponent range, needs no loss
-    scaling (the reference's GradScaler, accelerate's fp16 path) - storage and accumulation stay fp32 either way."""
+    bf16: the MI355X-native 16-bit type, which with fp32's exponent range needs no loss scaling (the reference's
+    GradScaler, accelerate's fp16 path).  "fp16" / "bf16" = half-precision ACTIVATIONS where the model supports them
+    (UNet2DConditionModel: what the reference's SD jobs run) and bf16 operands elsewhere; "bf16-operands" = bf16
+    operands with fp32 storage everywhere (the round-2..4 mode, kept for A/B)."""
     OPERAND_PRECISION[0] = 0 if name in (None, "no", "f32", "fp32") else operand_precision("bf16" if name in ("fp16", "bf16") else name).value
+
+
+def half_activations() -> bool:
+    """Is the half-precision activation path selected? (models that support it cast at their boundary: gad/sd.py)"""
+    return OPERAND_PRECISION[0] == 2
 
 
 # Kernel-family switches for A/B tools and the invariance tests (never set in production): they travel in the argument
@@ -220,7 +229,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ldr = ldr
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
-    a.operand_precision = OPERAND_PRECISION[0]
+    a.operand_precision = 1 if OPERAND_PRECISION[0] else 0
     a.flags = KERNEL_FLAGS["gemm"]
     if A2 is not None:
         a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]
@@ -316,7 +325,25 @@ class GemmProfiler:
             stage = (mid, 4.0 * a_elems + v_bytes if mid is not None else 0.0, v_bytes + 4.0 * (b_elems * npos / 9.0 + a.M * a.N + extra))
         self.records.append((key, flops, nbytes, s, e, executed, stage))
 
-    def attention(self, fn, a, what):
+    def hgemm(self, lib, a):
+        """Bracket a half-precision-path contraction (gad_hgemm): bf16 operands and output (fp32 output for parameter gradients)."""
+        tile, sk = C.c_int32(), C.c_int32()
+        check(lib.gad_hgemm_plan(C.byref(a), C.byref(tile), C.byref(sk)), "gad_hgemm_plan")
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        s.record()
+        check(lib.gad_hgemm(C.byref(a), _stream()), "gad_hgemm")
+        e.record()
+        if a.conv:
+            name = f"hconv{a.KH}x{a.KW}" + ("_s2dgrad" if a.conv == 2 else "_s2" if a.stride == 2 else "_up" if a.upsample else "")
+            a_elems = (a.M // max(1, a.Ho * a.Wo)) * a.H * a.W * a.Cin
+        else:
+            name = "hgemm_wgrad" if a.out_f32 else "hgemm_lora" if a.A2 else "hgemm"
+            a_elems = a.M * a.K
+        nbytes = 2.0 * (a_elems + a.N * a.K + (a.M * a.N if a.residual else 0)) + (4.0 if a.out_f32 else 2.0) * a.M * a.N
+        flops = 2.0 * a.M * a.N * a.K
+        self.records.append(((name, (128, 320)[tile.value - 1], sk.value, 8), flops, nbytes, s, e, flops, None))
+
+    def attention(self, fn, a, what, elem_bytes=4):
         """Bracket a fused attention launch.  Algorithmic FLOPs: forward 4 B h Tq Tk d (Q K^T and P V), backward
         10 B h Tq Tk d (the five products of the minimal scheme; the recomputing kernels execute seven).  Bytes: q, k,
         v, o once forward; those plus dO, dq, dk, dv backward."""
@@ -326,9 +353,9 @@ class GemmProfiler:
         e.record()
         d_alg = getattr(a, "alg_d", a.d)               # zero-padded heads (ops.PadHeadsFn): count the TRUE head dim's FLOPs
         unit = float(a.B) * a.heads * a.Tq * a.Tk * d_alg
-        qb, kb = 4.0 * a.B * a.Tq * a.heads * d_alg, 4.0 * a.B * a.Tk * a.heads * d_alg
+        qb, kb = float(elem_bytes) * a.B * a.Tq * a.heads * d_alg, float(elem_bytes) * a.B * a.Tk * a.heads * d_alg
         flops, nbytes = (4.0 * unit, 2 * qb + 2 * kb) if what == "fwd" else (10.0 * unit, 4 * qb + 4 * kb)
-        self.records.append(((f"attn_{what}_d{d_alg}", a.Tq, a.Tk, 4), flops, nbytes, s, e, flops, None))
+        self.records.append(((f"attn_{what}_d{d_alg}", a.Tq, a.Tk, elem_bytes), flops, nbytes, s, e, flops, None))
 
     def summary(self):
         """{key: dict(launches, ms, flops, bytes, executed[, ms_input, bytes_input, bytes_rest])} - call after a device
@@ -394,7 +421,7 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
              tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1, wino_input=wino_input,
              B_wino=wino_weight(w, 2) if (wino_ok and (tile_hint == 7 or (tile_hint == 0 and not f4_maps))) else None,
              B_wino4=wino_weight(w, 4) if (wino_ok and tile_hint != 7 and f4_maps) else None,
-             B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] == 1 and KH == 3 and Cin % 32 == 0 and x2 is None
+             B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] >= 1 and KH == 3 and Cin % 32 == 0 and x2 is None
                                        and not torch.cuda.is_current_stream_capturing()) else None)
     return y if launched is not False else None
 
@@ -582,7 +609,7 @@ def wino_weight(w, f=2):
     per form, refreshed by a single launch when the weights changed (the keys of `bf16_weight`); any other weight caches its
     own transform per version."""
     co, ci = w.shape[0], w.shape[1]
-    if (tuple(w.shape[2:]) != (3, 3) or not _wino_ok(co, ci) or OPERAND_PRECISION[0] == 1
+    if (tuple(w.shape[2:]) != (3, 3) or not _wino_ok(co, ci) or OPERAND_PRECISION[0] >= 1
             or KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K)
             or (f == 4 and KERNEL_FLAGS.get("no_wino4"))):
         return None
@@ -777,7 +804,14 @@ class Conv2dFn(torch.autograd.Function):
         return dx, dw, db, dr, dres, None, None, None
 
 
+def _half():
+    from . import half
+    return half
+
+
 def conv2d(x, w, bias=None, rowadd=None, residual=None, stride=1, pad=(1, 1, 1, 1), upsample=False):
+    if x.dtype == torch.bfloat16:
+        return _half().conv2d(x, w, bias, rowadd, residual, stride, pad, upsample)
     return Conv2dFn.apply(x, w, bias, rowadd, residual, stride, pad, upsample)
 
 
@@ -806,6 +840,8 @@ class LinearFn(torch.autograd.Function):
 
 
 def linear(x, w, bias=None, residual=None):
+    if x.dtype == torch.bfloat16:
+        return _half().linear(x, w, bias, residual)
     return LinearFn.apply(x, w, bias, residual)
 
 
@@ -866,6 +902,8 @@ class LoraLinearFn(torch.autograd.Function):
 
 
 def lora_linear(x, w, bias, down, up, s=1.0, residual=None):
+    if x.dtype == torch.bfloat16:
+        return _half().lora_linear(x, w, bias, down, up, s, residual)
     return LoraLinearFn.apply(x, w, bias, down, up, float(s), residual)
 
 
@@ -948,12 +986,16 @@ class GroupNormBypassFn(GroupNormSiluFn):
 
 def group_norm_bypass(x, gamma, beta, G, eps, silu):
     """-> (GroupNorm(+SiLU)(x), alias of x for the residual branch); see GroupNormBypassFn."""
+    if x.dtype == torch.bfloat16:
+        return _half().group_norm_bypass(x, gamma, beta, G, eps, silu)
     if not (torch.is_grad_enabled() and x.requires_grad):
         return group_norm(x, gamma, beta, G, eps, silu), x
     return GroupNormBypassFn.apply(x, gamma, beta, G, eps, silu)
 
 
 def group_norm(x, gamma, beta, G, eps, silu):
+    if x.dtype == torch.bfloat16:
+        return _half().group_norm(x, gamma, beta, G, eps, silu)
     return GroupNormSiluFn.apply(x, gamma, beta, G, eps, silu)
 
 
@@ -1031,6 +1073,8 @@ class ConcatFn(torch.autograd.Function):
 
 
 def concat(a, b):
+    if a.dtype == torch.bfloat16:
+        return _half().concat(a, b)
     return ConcatFn.apply(a, b)
 
 
@@ -1102,7 +1146,7 @@ def attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, need_lse=Tru
     o = _out((Bn, Tq, heads * d), q.device)
     lse = _out((Bn, heads, Tq), q.device) if need_lse else None
     a = _attention_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ldq, ldk, ldv, Tq * ldq, Tk * ldk, Tk * ldv, scale)
-    a.operand_precision = OPERAND_PRECISION[0]         # bf16 mode: bf16-operand instance of the fused kernel
+    a.operand_precision = 1 if OPERAND_PRECISION[0] else 0         # bf16 modes: bf16-operand instance of the fused kernel
     a.flags = _capi.ATTN_NARROW_FWD if KERNEL_FLAGS.get("narrow_attn_fwd") else 0
     if PROFILER is not None:
         PROFILER.attention(_capi.load().gad_attention_fwd, a, "fwd")
@@ -1126,7 +1170,7 @@ class AttentionCoreFn(torch.autograd.Function):
         d = Cq // heads
         o, lse = attention_fwd_raw(q, k, v, Bn, heads, Tq, Tk, d, Cq, Cq, Cq, need_lse=True, scale=scale)
         ctx.save_for_backward(q, k, v, o, lse)
-        ctx.heads, ctx.prec, ctx.scale = heads, OPERAND_PRECISION[0], scale
+        ctx.heads, ctx.prec, ctx.scale = heads, (1 if OPERAND_PRECISION[0] else 0), scale
         return o
 
     @staticmethod
@@ -1249,6 +1293,8 @@ def pad_heads(w, heads, d, dpad, axis):
 
 
 def attention_core(q, k, v, heads, scale=None):
+    if q.dtype == torch.bfloat16:
+        return _half().attention_core(q, k, v, heads, scale)
     d = q.shape[-1] // heads
     # Training at one wide head over a short sequence (CIFAR: d = 256 / 192, T <= 256) keeps the three-launch route: S is a
     # few MB there, and the recomputing backward (7 products, 1 wave per SIMD at d >= 192) measured 0.48 ms against
@@ -1415,10 +1461,14 @@ class LayerNormBypassFn(LayerNormFn):
 
 
 def layer_norm(x, gamma, beta, eps=1e-5):
+    if x.dtype == torch.bfloat16:
+        return _half().layer_norm(x, gamma, beta, eps)
     return LayerNormFn.apply(x, gamma, beta, eps)
 
 
 def layer_norm_bypass(x, gamma, beta, eps=1e-5):
+    if x.dtype == torch.bfloat16:
+        return _half().layer_norm_bypass(x, gamma, beta, eps)
     if not (torch.is_grad_enabled() and x.requires_grad):
         return layer_norm(x, gamma, beta, eps), x
     return LayerNormBypassFn.apply(x, gamma, beta, eps)
@@ -1448,6 +1498,8 @@ class GegluFn(torch.autograd.Function):
 
 
 def geglu(h):
+    if h.dtype == torch.bfloat16:
+        return _half().geglu(h)
     return GegluFn.apply(h)
 
 

@@ -223,6 +223,13 @@ class UNet2DConditionModel(nn.Module):
         temb_act = ops.silu(self.time_embedding(emb))
         context = context.to(torch.float32).contiguous()
         h = self.conv_in(x)
+        half = ops.half_activations()
+        if half:
+            # the half-precision activation path (gad/half.py; the reference's `--mixed_precision=fp16` jobs,
+            # text_to_image/experiments/setup_train_commands.py:127): from here to conv_out every activation and gradient is bf16
+            from . import half as H
+            h = H.ToHalfFn.apply(h)
+            context = H.to_half(context)
         skips = (h,)
         for blk in self.down_blocks:
             h, outs = blk(h, temb_act, context, scale)
@@ -232,7 +239,8 @@ class UNet2DConditionModel(nn.Module):
             n = len(blk.resnets)
             res, skips = skips[-n:], skips[:-n]
             h = blk(h, res, temb_act, context, scale)
-        return self.conv_out(self.conv_norm_out(h, silu=True))
+        y = self.conv_out(self.conv_norm_out(h, silu=True))
+        return H.ToFloatFn.apply(y) if half else y
 
     def forward(self, sample, timestep, encoder_hidden_states, cross_attention_kwargs=None):
         if not sample.is_cuda:

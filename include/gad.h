@@ -370,6 +370,87 @@ int gad_clip_adam_ema(const gad_adam_args* a, void* stream);
 /* standalone EMAModel.step (diffusers training_utils; main.py:725): ema -= (1-decay) * (ema - p) */
 int gad_ema_update(float* ema, const float* p, int64_t n, float decay, void* stream);
 
+
+/* ==============================================================================
+ * Half-precision activation path ("--mixed_precision fp16|bf16" of the reference's Stable-Diffusion jobs:
+ * text_to_image/experiments/setup_train_commands.py:127,142,165, setup_unlearn_commands.py:166; frozen weights cast to the
+ * 16-bit type and autocast around the U-Net, text_to_image/train_text_to_image_lora.py:752-760,1268-1270).  bf16 is the
+ * MI355X-native 16-bit type (fp32's exponent range: no loss scaling).  On this path ACTIVATIONS AND THEIR GRADIENTS LIVE IN
+ * HBM AS bf16 (NHWC / [rows][C]); frozen weights are bf16 copies made once; LoRA A / B, their gradients and the optimizer
+ * state stay fp32 (train_text_to_image_lora.py:777: "LoRA weights in fp32") with a bf16 shadow refreshed per step;
+ * accumulation, normalisation statistics, softmax statistics and every epilogue are fp32.
+ * All `void*` activation pointers below are bf16 (uint16 storage) unless a field says fp32.
+ * ============================================================================== */
+/* hgemm: C[m][n] = epilogue( alpha * sum_k A(m, k) * B[n][k] )   - v_mfma_f32_32x32x16_bf16, operands streamed by LDS-DMA.
+ * B is always [n][k] with k contiguous (torch Linear / [Cout][KH][KW][Cin] conv storage; data gradients use transposed /
+ * rotated bf16 copies of the frozen weights, made once).  A is
+ *   conv == 0: dense A[m][k], row stride lda;
+ *   conv == 1: the im2col gather of an NHWC tensor: m = (img, oy, ox), k = (r, s, c): pixel (oy*stride - pad_t + r,
+ *              ox*stride - pad_l + s) of image img (>> 1 each if upsample: nearest-2x fused), zero outside;
+ *   conv == 2: the gather of a stride-2 convolution's data gradient: m = (img, y, x) on the INPUT grid, k = (r, s, co) with
+ *              the ROTATED weight: pixel ((y - pad_t + r) / 2, (x - pad_l + s) / 2) of dy where both are even, else zero.
+ * The contraction axis may continue in a second operand pair: dense: k >= k_split reads A2[m][k - k_split] (row stride lda2)
+ * and B2[n][k - k_split] (ldb2) - the fused LoRA linear (y = x W^T + mid up^T; dx = dy W + dmid down) -; conv: channels
+ * c >= k_split of every tap come from A2 (pixel stride lda2) - UpBlock2D's torch.cat without the copy - while B stays one
+ * [N][taps * C] matrix.  Every segment length and k_split must be a multiple of 8.
+ * Epilogue (fp32): + bias[n] + rowadd[m / rows_per_group][n] (time-embedding add) + residual[m][n] (bf16), stored as bf16
+ * (out_f32 == 0) or fp32 (out_f32 == 1; accumulate != 0 adds to what C holds: parameter-gradient slots).
+ * ws: gad_hgemm_workspace_bytes(args) bytes for split-K partials (fp32 slabs reduced in a fixed order by a second launch).
+ * Replaces cuDNN / cuBLAS half-precision kernels under the autocast U-Net (train_text_to_image_lora.py:1268-1270). */
+typedef struct gad_hgemm_args {
+  const void* A; const void* A2; const void* B; const void* B2;
+  void* C;
+  int32_t M, N, K;          /* K = total contraction length (conv: KH*KW*Cin)                                   */
+  int32_t lda, lda2, ldb, ldb2, ldc;
+  int32_t k_split;          /* dense: first segment's length (== K: single segment); conv: channels of source 1 */
+  int32_t conv;             /* 0 / 1 / 2 as above                                                               */
+  int32_t H, W, Cin;        /* gathered tensor (stored size), total channels                                    */
+  int32_t Ho, Wo, KH, KW, stride, pad_t, pad_l, upsample;   /* Ho x Wo: the GEMM rows' pixel grid             */
+  float alpha;
+  const float* bias;        /* fp32 [N] or NULL                                                                 */
+  const float* rowadd;      /* fp32 [M / rows_per_group][ld_rowadd] or NULL                                     */
+  int32_t rows_per_group, ld_rowadd;
+  const void* residual;     /* bf16 [M][ldr] or NULL                                                            */
+  int32_t ldr;
+  int32_t out_f32, accumulate;
+  void* ws; int64_t ws_bytes;
+  int32_t tile_hint;        /* 0 auto; 1: 128 x 128 tiles; 2: 128 x 320 (tests, A/B tools)                          */
+  int32_t splitk_hint;      /* 0 auto; > 0 force                                                                */
+} gad_hgemm_args;
+int64_t gad_hgemm_workspace_bytes(const gad_hgemm_args* a);
+int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: 1 / 2 as tile_hint */
+int gad_hgemm(const gad_hgemm_args* a, void* stream);
+/* dst[c][r] = bf16(src[r][c]) for `batch` matrices (strides in elements); src fp32 (src_f32 != 0) or bf16; the operand
+ * transposes of the LoRA parameter gradients (dUp = dy^T mid, dDown = dmid^T x) and of the per-step bf16 shadows of the
+ * LoRA matrices' transposes */
+int gad_h_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, int32_t src_f32,
+                    void* stream);
+/* dst = bf16(src) (to_f32 == 0: src fp32) or dst = fp32(src) (to_f32 != 0: src bf16) */
+int gad_h_cast(const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
+/* GroupNorm (+ SiLU) with bf16 x / y / dy / dx, fp32 gamma / beta / mean / rstd: the fields of gad_groupnorm_args read as
+ * bf16 where they are activations.  Forward reads two sources (x2 / C1) in place; backward computes dx only (frozen norm:
+ * dgamma / dbeta must be NULL) and adds dx_add (bf16) in its store.  ws: gad_h_groupnorm_workspace_bytes(). */
+int64_t gad_h_groupnorm_workspace_bytes(const gad_groupnorm_args* a);
+int gad_h_groupnorm_silu_fwd(const gad_groupnorm_args* a, void* stream);
+int gad_h_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* stream);
+/* LayerNorm over the last dim, bf16 x / y / dy / dx / dx_add, fp32 gamma / beta / mean / rstd; backward: dx only */
+int gad_h_layernorm_fwd(const void* x, void* y, const float* gamma, const float* beta, float* mean, float* rstd, int64_t rows,
+                        int32_t C, float eps, void* stream);
+int gad_h_layernorm_bwd(const void* x, const void* dy, void* dx, const void* dx_add, const float* gamma, const float* mean,
+                        const float* rstd, int64_t rows, int32_t C, void* stream);
+/* GEGLU on bf16: out = h[:, :F] * gelu(h[:, F:]) and its backward */
+int gad_h_geglu_fwd(const void* h, void* out, int64_t M, int32_t F, void* stream);
+int gad_h_geglu_bwd(const void* h, const void* dout, void* dh, int64_t M, int32_t F, void* stream);
+/* dx[b][h][w][c] = sum of the 2 x 2 block of dy (bf16 in / out, fp32 sum) */
+int gad_h_upsample2x_bwd(const void* dy, void* dx, int32_t B, int32_t H, int32_t W, int32_t C, void* stream);
+/* out = a + b (bf16, fp32 sum): skip-connection gradient sums the autograd engine would otherwise run as at::add */
+int gad_h_add(const void* a, const void* b, void* out, int64_t n, void* stream);
+/* Fused attention with bf16 q / k / v / o / d_o / dq / dk / dv (fp32 lse / delta): the fields of gad_attention_args read as
+ * bf16, strides in elements; head dims that are multiples of 8 up to 160.  Same kernels as operand_precision = 1 of
+ * gad_attention_fwd / _bwd with 16-bit tile loads and stores. */
+int gad_h_attention_fwd(const gad_attention_args* a, void* stream);
+int gad_h_attention_bwd(const gad_attention_args* a, void* stream);
+
 #ifdef __cplusplus
 }
 #endif

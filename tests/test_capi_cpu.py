@@ -29,7 +29,7 @@ def test_struct_layout_matches_header(tmp_path):
     mirror in gad/_capi.py (guards against a field drifting between the two)."""
     import subprocess
     structs = {"gad_conv_geom": _capi.ConvGeom, "gad_gemm_args": _capi.GemmArgs, "gad_groupnorm_args": _capi.GroupNormArgs,
-               "gad_adam_args": _capi.AdamArgs, "gad_attention_args": _capi.AttentionArgs}
+               "gad_adam_args": _capi.AdamArgs, "gad_attention_args": _capi.AttentionArgs, "gad_hgemm_args": _capi.HGemmArgs}
     src = ['#include <stdio.h>', '#include <stddef.h>', '#include "gad.h"', 'int main(void) {']
     for cname, cls in structs.items():
         src.append(f'  printf("{cname} %zu\\n", sizeof({cname}));')

@@ -179,7 +179,7 @@ def test_sd_lora_entry_point(tmp_path):
     try:
         b = T.parse_args(common + ["--method", "retrain", "--rank", "4", "--max_train_steps", "2", "--snr_gamma", "5.0",
                                    "--noise_offset", "0.1", "--mixed_precision", "fp16"])
-        assert T.main(b) and gad.ops.OPERAND_PRECISION[0] == 1
+        assert T.main(b) and gad.ops.OPERAND_PRECISION[0] == 2      # fp16 -> half-precision activations (gad/half.py)
     finally:
         gad.set_operand_precision("no")
 
