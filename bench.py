@@ -776,16 +776,27 @@ def main():
         # the other workloads of the path, timed the same way after the headline (N = 1 only: the N > 1 runs stay short)
         import gc
         out["secondary"] = {}
-        for name in SECONDARY:
+        import copy
+        # (name, precision): the fp32 workloads, then the SD steps in the arithmetic the reference's SD jobs actually run
+        # (--mixed_precision=fp16 -> half-precision activations, gad/half.py), labelled by their key and their `dtype`
+        todo = [(n, a.precision, n) for n in SECONDARY]
+        if a.precision == "f32":
+            todo += [("sd512", "bf16", "sd512-bf16"), ("sd256", "bf16", "sd256-bf16")]
+        for name, prec, key in todo:
             gc.collect()
             torch.cuda.empty_cache()
+            a2 = copy.copy(a)
+            a2.precision = prec
             try:
-                sec = measure(a, name, a.secondary_steps, a.warmup, env, headline=False)
+                gad.set_operand_precision(prec)
+                sec = measure(a2, name, a.secondary_steps, a.warmup, env, headline=False)
                 sec.pop("contraction_kernels", None)                    # the per-instance table of the headline is enough
-                out["secondary"][name] = sec
+                out["secondary"][key] = sec
             except Exception as e:                                      # a secondary line never costs the headline
-                out["secondary"][name] = {"error": f"{type(e).__name__}: {e}"}
-                log(f"secondary workload {name} failed: {type(e).__name__}: {e}")
+                out["secondary"][key] = {"error": f"{type(e).__name__}: {e}"}
+                log(f"secondary workload {key} failed: {type(e).__name__}: {e}")
+            finally:
+                gad.set_operand_precision(a.precision)
     if rank == 0:
         print(json.dumps(out), flush=True)
     if world > 1:

@@ -58,6 +58,8 @@ struct HDev {
   float* ws;
   int tiles_m, tiles_n, splitk, steps_per_split, steps;
   int vec;                  // the epilogue's operands (or the split-K slabs) can be moved as aligned 16-byte vectors
+  int vec_out;              // the output-side operands can (the split-K reduce's epilogue)
+  int dbg_zero;             // A/B tools only (tile_hint + 100): every DMA reads the zero block - the kernel without its memory system
 };
 
 // epilogue of one output element
@@ -74,8 +76,68 @@ __device__ __forceinline__ void epi_store(const HDev& p, int m, int n, int img, 
   }
 }
 
-template <int WM, int WN, int TM, int TN, int BKT>
-__global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
+// epilogue of 8 consecutive columns of one output row (v0 | v1: the raw accumulators), or their split-K slab store
+__device__ __forceinline__ void epi_row8(const HDev& p, float* slab, int m, int n, const f32x4& v0, const f32x4& v1) {
+  float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
+  if (slab) {
+    float* dst = slab + (long)m * p.N + n;
+    if (p.vec) {
+      *reinterpret_cast<f32x4*>(dst) = v0;
+      *reinterpret_cast<f32x4*>(dst + 4) = v1;
+    } else {
+      for (int k = 0; k < 8 && n + k < p.N; ++k) dst[k] = v[k];
+    }
+    return;
+  }
+  const int img = p.rowadd ? m / p.rpg : 0;
+  if (p.vec) {
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
+    if (p.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+    }
+    if (p.rowadd) {
+      const float* ra = p.rowadd + (long)img * p.ld_rowadd + n;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(ra), b1 = *reinterpret_cast<const f32x4*>(ra + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+    }
+    if (p.residual) {
+      float rr[8];
+      unpack8(*reinterpret_cast<const u32x4*>(p.residual + (long)m * p.ldr + n), rr);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += rr[k];
+    }
+    if (p.out_f32) {
+      float* cdst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cdst), c1 = *reinterpret_cast<const f32x4*>(cdst + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += c0[k]; v[4 + k] += c1[k]; }
+      }
+      *reinterpret_cast<f32x4*>(cdst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(cdst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.C) + (long)m * p.ldc + n) = pack8(v);
+    }
+  } else {
+    for (int k = 0; k < 8 && n + k < p.N; ++k) epi_store(p, m, n + k, img, v[k]);
+  }
+}
+
+template <int N>
+__device__ __forceinline__ void barrier_vm() {          // all but this wave's N youngest vector-memory operations are done, then the
+  static_assert(N >= 0 && N < 64, "vmcnt is 6 bits");   // workgroup barrier - NOT __syncthreads(), whose fence drains every LDS-DMA in flight
+  asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
+}
+
+// NST = 2: two stage buffers, the next K step's DMA issued before this step's MFMAs, two workgroups per CU cover each other's waits.
+// NST >= 3: a ring of NST stage buffers with the DMA running NST - 1 K steps ahead (counted s_waitcnt vmcnt, one raw barrier per step),
+//           one workgroup per CU.
+template <int WM, int WN, int TM, int TN, int BKT, int NST>
+__global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(const HDev p) {
   constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int CPR = BKT / 8, RPI = 64 / CPR;             // 16-B chunks per tile row; tile rows per DMA wave-instruction
   constexpr int AI = BM / RPI / NW, BI = BN / RPI / NW;   // DMA instructions per wave per K step
@@ -132,7 +194,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
   }
 
   const int spg = p.n1 + p.n2;                 // K steps per group (tap)
-  auto stage = [&](int step, int buf) {
+  auto stage = [&](int step, int buf, bool live = true) {
     const int grp = step / spg, u = step - grp * spg;
     const bool s2 = u >= p.n1;
     const int kk = (s2 ? u - p.n1 : u) * BKT;                 // offset inside the segment
@@ -143,7 +205,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
     if (p.conv) { r = grp / p.KW; s = grp - r * p.KW; }
 #pragma unroll
     for (int i = 0; i < AI; ++i) {
-      bool ok = aok[i] && kk + ach[i] < klim;
+      bool ok = live && aok[i] && kk + ach[i] < klim;
       const u16* src;
       if (p.conv) {
         int yy = ay[i] + r, xx = ax[i] + s;
@@ -164,7 +226,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
     const long kb = b_second ? kk : (long)grp * (p.len1 + p.len2) + (s2 ? p.len1 : 0) + kk;
 #pragma unroll
     for (int i = 0; i < BI; ++i) {
-      const bool ok = bok[i] && kk + bch[i] < klim;
+      const bool ok = live && bok[i] && kk + bch[i] < klim;
       const u16* src = b_second ? p.B2 + b2off[i] : p.B + boff[i];
       src = ok ? src + kb + bch[i] : reinterpret_cast<const u16*>(g_zero);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
@@ -187,14 +249,7 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
 
   const int t0 = z * p.steps_per_split;
   const int t1 = min(p.steps, t0 + p.steps_per_split);
-  if (t0 < t1) {
-    stage(t0, 0);
-    __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the DMA is a VMEM operation
-    __syncthreads();
-  }
-  for (int st = t0; st < t1; ++st) {
-    const int buf = (st - t0) & 1;
-    if (st + 1 < t1) stage(st + 1, buf ^ 1);
+  auto compute = [&](int buf) {
     const unsigned char* sb = lds + buf * STAGE;
 #pragma unroll
     for (int kk = 0; kk < BKT / 16; ++kk) {
@@ -209,8 +264,34 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
 #pragma unroll
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
-    __builtin_amdgcn_s_waitcnt(0x0F70);
-    __syncthreads();
+  };
+  if constexpr (NST == 2) {
+    if (t0 < t1) {
+      stage(t0, 0, !p.dbg_zero);
+      __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the DMA is a VMEM operation
+      __syncthreads();
+    }
+    for (int st = t0; st < t1; ++st) {
+      const int buf = (st - t0) & 1;
+      if (st + 1 < t1) stage(st + 1, buf ^ 1, !p.dbg_zero);
+      compute(buf);
+      __builtin_amdgcn_s_waitcnt(0x0F70);
+      __syncthreads();
+    }
+  } else {
+    constexpr int D = NST - 1, NDMA = AI + BI;
+    static_assert((D - 1) * NDMA < 64, "vmcnt range");
+#pragma unroll
+    for (int s_ = 0; s_ < D; ++s_) stage(min(t0 + s_, p.steps - 1), s_, t0 + s_ < t1);
+    int rd = 0, wr = D;                          // ring positions: read this step / refill (the buffer read in the previous step)
+    for (int st = t0; st < t1; ++st) {
+      barrier_vm<(D - 1) * NDMA>();              // this step's stage has landed; every wave is past the previous step's reads
+      stage(min(st + D, p.steps - 1), wr, st + D < t1);
+      compute(rd);
+      rd = rd + 1 == NST ? 0 : rd + 1;
+      wr = wr + 1 == NST ? 0 : wr + 1;
+    }
+    barrier_vm<0>();                             // nothing may still be landing in LDS when the epilogue reuses it
   }
 
   // ---- epilogue ----
@@ -240,63 +321,236 @@ __global__ __launch_bounds__(WM* WN * 64, 2) void hgemm_kernel(const HDev p) {
         const int r = task / CH, c = (task - r * CH) * 8;
         const int m = row0 + (wm * TM + i) * 32 + 16 * hf + r, n = col0 + wn * EW + c;
         const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c), v1 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c + 4);
-        float v[8] = {v0[0], v0[1], v0[2], v0[3], v1[0], v1[1], v1[2], v1[3]};
         if (m >= p.M || n >= p.N) continue;
-        if (slab) {
-          float* dst = slab + (long)m * p.N + n;
-          if (p.vec) {
-            *reinterpret_cast<f32x4*>(dst) = v0;
-            *reinterpret_cast<f32x4*>(dst + 4) = v1;
-          } else {
-            for (int k = 0; k < 8 && n + k < p.N; ++k) dst[k] = v[k];
-          }
-          continue;
-        }
-        const int img = p.rowadd ? m / p.rpg : 0;
-        if (p.vec) {
-#pragma unroll
-          for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
-          if (p.bias) {
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
-          }
-          if (p.rowadd) {
-            const float* ra = p.rowadd + (long)img * p.ld_rowadd + n;
-            const f32x4 b0 = *reinterpret_cast<const f32x4*>(ra), b1 = *reinterpret_cast<const f32x4*>(ra + 4);
-#pragma unroll
-            for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
-          }
-          if (p.residual) {
-            float rr[8];
-            unpack8(*reinterpret_cast<const u32x4*>(p.residual + (long)m * p.ldr + n), rr);
-#pragma unroll
-            for (int k = 0; k < 8; ++k) v[k] += rr[k];
-          }
-          if (p.out_f32) {
-            float* cdst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
-            if (p.accumulate) {
-              const f32x4 c0 = *reinterpret_cast<const f32x4*>(cdst), c1 = *reinterpret_cast<const f32x4*>(cdst + 4);
-#pragma unroll
-              for (int k = 0; k < 4; ++k) { v[k] += c0[k]; v[4 + k] += c1[k]; }
-            }
-            *reinterpret_cast<f32x4*>(cdst) = f32x4{v[0], v[1], v[2], v[3]};
-            *reinterpret_cast<f32x4*>(cdst + 4) = f32x4{v[4], v[5], v[6], v[7]};
-          } else {
-            *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.C) + (long)m * p.ldc + n) = pack8(v);
-          }
-        } else {
-          for (int k = 0; k < 8 && n + k < p.N; ++k) epi_store(p, m, n + k, img, v[k]);
-        }
+        epi_row8(p, slab, m, n, v0, v1);
       }
     }
   }
 }
 
-// split-K: sum the slabs in a fixed order and run the epilogue
-__global__ void hgemm_reduce_kernel(const HDev p) {
-  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
+// ---------------------------------------------------------------------------------------------------------------
+// hgemm8_kernel: the 256 x 320 tile on EIGHT waves (4 x 2, each 64 x 160 as in the 128 x 320 form), one workgroup per CU.
+// Against two co-resident 128 x 320 workgroups: the same two waves per SIMD, but (i) 0.65x the operand bytes through L2 per
+// FLOP, (ii) a ring of four 36 KB stage buffers with the LDS-DMA running THREE K steps (= 3 x 1280 MFMA cycles per SIMD) ahead
+// - the 128 x 320 form waits for every step's DMA after one step of compute and is latency-bound even with every source in
+// cache (tools/ab_hgemm_zero.py) -, (iii) the DMA split by role: waves 0-3 stream the weights (5 wave-instructions per step),
+// waves 4-7 the activations / the convolution gather (4), so a wave carries one kind of addressing, in 32-bit offsets.
+// One raw barrier per K step with a counted vmcnt (two stages stay in flight across it).
+// ---------------------------------------------------------------------------------------------------------------
+__global__ __launch_bounds__(512, 2) void hgemm8_kernel(const HDev p) {
+  constexpr int TM = 2, TN = 5, BKT = 32, NST = 4, D = NST - 1;
+  constexpr int BM = 256, BN = 320, RPI = 16;              // 4 chunks per 64-byte tile row, 16 rows per DMA wave-instruction
+  constexpr int AI = 4, BI = 5;                            // per A-role / B-role wave and K step
+  constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = A_BYTES + B_BYTES;
+  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
+
+  const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * BM, col0 = tile_n * BN;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  const bool role_b = wave < 4;
+  const int lrow = lane >> 2, slot = lane & 3;
+  auto swz = [](int row) { return (row >> 2) & 3; };
+
+  // per-lane DMA sources of this wave's role (element offsets fit 32 bits: host check)
+  int off1[BI], off2[BI], yy0[AI], xx0[AI], chn[BI];
+  unsigned okm = 0;
+#pragma unroll
+  for (int i = 0; i < BI; ++i) { off1[i] = off2[i] = chn[i] = 0; }
+#pragma unroll
+  for (int i = 0; i < AI; ++i) { yy0[i] = xx0[i] = 0; }
+  if (role_b) {
+#pragma unroll
+    for (int i = 0; i < BI; ++i) {
+      const int rl = (wave * BI + i) * RPI + lrow, n = col0 + rl;
+      okm |= (unsigned)(n < p.N) << i;
+      chn[i] = (slot ^ swz(rl)) * 8;
+      off1[i] = n * p.ldb;
+      off2[i] = n * p.ldb2;
+    }
+  } else {
+#pragma unroll
+    for (int i = 0; i < AI; ++i) {
+      const int rl = ((wave - 4) * AI + i) * RPI + lrow, m = row0 + rl;
+      const bool ok = m < p.M;
+      okm |= (unsigned)ok << i;
+      chn[i] = (slot ^ swz(rl)) * 8;
+      if (p.conv) {
+        const int hw = p.Ho * p.Wo, mm = ok ? m : 0;
+        const int img = mm / hw, rem = mm - img * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
+        off1[i] = img * p.H * p.W;                // image base pixel
+        yy0[i] = oy * p.stride - p.pad_t;
+        xx0[i] = ox * p.stride - p.pad_l;
+      } else {
+        off1[i] = m * p.lda;
+        off2[i] = m * p.lda2;
+      }
+    }
+  }
+
+  const int spg = p.n1 + p.n2;
+  auto stage = [&](int step, int buf, bool live) {
+    const int grp = step / spg, u = step - grp * spg;
+    const bool s2 = u >= p.n1;
+    const int kk = (s2 ? u - p.n1 : u) * BKT;
+    const int klim = s2 ? p.len2 : p.len1;
+    if (role_b) {
+      unsigned char* dst = lds + buf * STAGE + A_BYTES + (wave * BI) * 1024;
+      const bool second = s2 && p.B2 != nullptr;
+      const u16* base = second ? p.B2 : p.B;
+      const int kb = second ? kk : grp * (p.len1 + p.len2) + (s2 ? p.len1 : 0) + kk;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const bool ok = live && ((okm >> i) & 1u) && kk + chn[i] < klim;
+        const u16* src = ok ? base + (long)(second ? off2[i] : off1[i]) + kb + chn[i] : reinterpret_cast<const u16*>(g_zero);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    } else {
+      unsigned char* dst = lds + buf * STAGE + ((wave - 4) * AI) * 1024;
+      int r = 0, s = 0;
+      if (p.conv) { r = grp / p.KW; s = grp - r * p.KW; }
+      const u16* base = s2 ? p.A2 : p.A;
+      const int ld = s2 ? p.lda2 : p.lda;
+#pragma unroll
+      for (int i = 0; i < AI; ++i) {
+        bool ok = live && ((okm >> i) & 1u) && kk + chn[i] < klim;
+        long eo;
+        if (p.conv) {
+          int yy = yy0[i] + r, xx = xx0[i] + s;
+          if (p.ups) { ok = ok && yy >= 0 && xx >= 0 && yy < 2 * p.H && xx < 2 * p.W; yy >>= 1; xx >>= 1; }
+          if (p.conv == 2) { ok = ok && !(yy & 1) && !(xx & 1); yy >>= 1; xx >>= 1; }
+          ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
+          eo = (long)(off1[i] + yy * p.W + xx) * ld;
+        } else {
+          eo = s2 ? off2[i] : off1[i];
+        }
+        const u16* src = ok ? base + eo + kk + chn[i] : reinterpret_cast<const u16*>(g_zero);
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
+      }
+    }
+  };
+
+  f32x16 acc[TM][TN];
+#pragma unroll
+  for (int i = 0; i < TM; ++i)
+#pragma unroll
+    for (int j = 0; j < TN; ++j)
+#pragma unroll
+      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
+
+  const int l31 = lane & 31, h = lane >> 5;
+  const int swl = swz(l31);
+  const int a_base = (wm * TM * 32 + l31) * (BKT * 2);
+  const int b_base = A_BYTES + (wn * TN * 32 + l31) * (BKT * 2);
+  const int t0 = z * p.steps_per_split;
+  const int t1 = min(p.steps, t0 + p.steps_per_split);
+
+#pragma unroll
+  for (int s_ = 0; s_ < D; ++s_) stage(min(t0 + s_, p.steps - 1), s_, t0 + s_ < t1 && !p.dbg_zero);
+  int rd = 0, wr = D;
+  for (int st = t0; st < t1; ++st) {
+    if (role_b) barrier_vm<(D - 1) * BI>(); else barrier_vm<(D - 1) * AI>();     // this step's stage landed; everyone is past the last step's reads
+    stage(min(st + D, p.steps - 1), wr, st + D < t1 && !p.dbg_zero);
+    const unsigned char* sb = lds + rd * STAGE;
+#pragma unroll
+    for (int kk = 0; kk < BKT / 16; ++kk) {
+      const int off = ((2 * kk + h) ^ swl) * 16;
+      bf16x8 af[TM], bfr[TN];
+#pragma unroll
+      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 32 * BKT * 2 + off);
+#pragma unroll
+      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * 32 * BKT * 2 + off);
+#pragma unroll
+      for (int i = 0; i < TM; ++i)
+#pragma unroll
+        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
+    rd = rd + 1 == NST ? 0 : rd + 1;
+    wr = wr + 1 == NST ? 0 : wr + 1;
+  }
+  barrier_vm<0>();
+
+  // ---- epilogue: as hgemm_kernel's (wave-private LDS patch -> 16-byte row vectors) ----
+  constexpr int EW = TN * 32, ELD = EW + 4, CH = EW / 8, TASKS = 16 * CH / 64;
+  float* patch = reinterpret_cast<float*>(lds) + wave * (16 * ELD);
+  float* slab = p.splitk > 1 ? p.ws + (long)z * p.M * p.N : nullptr;
+#pragma clang loop unroll(full)
+  for (int i = 0; i < TM; ++i) {
+#pragma clang loop unroll(full)
+    for (int hf = 0; hf < 2; ++hf) {
+#pragma clang loop unroll(full)
+      for (int j = 0; j < TN; ++j)
+#pragma clang loop unroll(full)
+        for (int q = 0; q < 2; ++q)
+#pragma clang loop unroll(full)
+          for (int e4 = 0; e4 < 4; ++e4)
+            patch[(e4 + 8 * q + 4 * h) * ELD + j * 32 + l31] = acc[i][j][(2 * hf + q) * 4 + e4];
+#pragma clang loop unroll(full)
+      for (int tk = 0; tk < TASKS; ++tk) {
+        const int task = lane + 64 * tk;
+        const int r = task / CH, c = (task - r * CH) * 8;
+        const int m = row0 + (wm * TM + i) * 32 + 16 * hf + r, n = col0 + wn * EW + c;
+        const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c), v1 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c + 4);
+        if (m >= p.M || n >= p.N) continue;
+        epi_row8(p, slab, m, n, v0, v1);
+      }
+    }
+  }
+}
+
+// split-K: sum the slabs in a fixed order and run the epilogue (8 columns per thread where the operands allow 16-byte vectors)
+__global__ __launch_bounds__(256) void hgemm_reduce_kernel(const HDev p) {
   const long total = (long)p.M * p.N;
+  if (p.vec_out) {
+    const long idx = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
+    if (idx >= total) return;
+    const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
+    float v[8] = {0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f, 0.f};
+    for (int zz = 0; zz < p.splitk; ++zz) {
+      const float* src = p.ws + (long)zz * total + idx;
+      const f32x4 a0 = *reinterpret_cast<const f32x4*>(src), a1 = *reinterpret_cast<const f32x4*>(src + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += a0[k]; v[4 + k] += a1[k]; }
+    }
+#pragma unroll
+    for (int k = 0; k < 8; ++k) v[k] *= p.alpha;
+    if (p.bias) {
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(p.bias + n), b1 = *reinterpret_cast<const f32x4*>(p.bias + n + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+    }
+    if (p.rowadd) {
+      const float* ra = p.rowadd + (long)(m / p.rpg) * p.ld_rowadd + n;
+      const f32x4 b0 = *reinterpret_cast<const f32x4*>(ra), b1 = *reinterpret_cast<const f32x4*>(ra + 4);
+#pragma unroll
+      for (int k = 0; k < 4; ++k) { v[k] += b0[k]; v[4 + k] += b1[k]; }
+    }
+    if (p.residual) {
+      float rr[8];
+      unpack8(*reinterpret_cast<const u32x4*>(p.residual + (long)m * p.ldr + n), rr);
+#pragma unroll
+      for (int k = 0; k < 8; ++k) v[k] += rr[k];
+    }
+    if (p.out_f32) {
+      float* cdst = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+      if (p.accumulate) {
+        const f32x4 c0 = *reinterpret_cast<const f32x4*>(cdst), c1 = *reinterpret_cast<const f32x4*>(cdst + 4);
+#pragma unroll
+        for (int k = 0; k < 4; ++k) { v[k] += c0[k]; v[4 + k] += c1[k]; }
+      }
+      *reinterpret_cast<f32x4*>(cdst) = f32x4{v[0], v[1], v[2], v[3]};
+      *reinterpret_cast<f32x4*>(cdst + 4) = f32x4{v[4], v[5], v[6], v[7]};
+    } else {
+      *reinterpret_cast<u32x4*>(reinterpret_cast<u16*>(p.C) + (long)m * p.ldc + n) = pack8(v);
+    }
+    return;
+  }
+  const long idx = (long)blockIdx.x * blockDim.x + threadIdx.x;
   if (idx >= total) return;
   const int m = (int)(idx / p.N), n = (int)(idx - (long)m * p.N);
   float v = 0.f;
@@ -323,6 +577,32 @@ __global__ __launch_bounds__(256) void transpose_kernel(const void* src, u16* ds
   for (int i = ty; i < 64; i += 4) {
     const int c = c0 + i, r = r0 + tx;
     if (c < cols && r < rows) dst[(long)c * ld_dst + r] = tile[tx][i];
+  }
+}
+// bf16 -> bf16 with 16-byte global accesses on both sides: 64 x 64 tiles, rows and columns multiples of 8, aligned bases / strides
+__global__ __launch_bounds__(256) void transpose16_kernel(const u16* __restrict__ src, u16* __restrict__ dst, int rows, int cols, int ld_src, int ld_dst) {
+  __shared__ __attribute__((aligned(16))) u16 tile[64][72];
+  const int r0 = blockIdx.y * 64, c0 = blockIdx.x * 64;
+  const int q = threadIdx.x & 7, rr = threadIdx.x >> 3;          // 8 chunks per tile row, 32 tile rows per pass
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int r = r0 + rr + 32 * i, c = c0 + q * 8;
+    u32x4 v = {0u, 0u, 0u, 0u};
+    if (r < rows && c < cols) v = *reinterpret_cast<const u32x4*>(src + (long)r * ld_src + c);
+    *reinterpret_cast<u32x4*>(&tile[rr + 32 * i][q * 8]) = v;
+  }
+  __syncthreads();
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int c = c0 + rr + 32 * i, r = r0 + q * 8;               // output row c, 8 consecutive source rows
+    if (c < cols && r < rows) {
+      u16 e[8];
+#pragma unroll
+      for (int k = 0; k < 8; ++k) e[k] = tile[q * 8 + k][rr + 32 * i];
+      *reinterpret_cast<u32x4*>(dst + (long)c * ld_dst + r) =
+          u32x4{(unsigned)e[0] | ((unsigned)e[1] << 16), (unsigned)e[2] | ((unsigned)e[3] << 16), (unsigned)e[4] | ((unsigned)e[5] << 16),
+                (unsigned)e[6] | ((unsigned)e[7] << 16)};
+    }
   }
 }
 
@@ -667,12 +947,31 @@ static int hgemm_check(const gad_hgemm_args* a) {
 }
 
 static HPlan hgemm_plan(const gad_hgemm_args* a) {
+  // Measured on the SD step's shapes (tools/ab_hgemm.py, profiles/r04_ab_hgemm.txt): the 128 x 320 tile wins wherever it yields a full
+  // round of workgroups (2 per CU); below that, LONG contractions (3x3 convolutions: K >= 2304) are split along K - the fp32 slabs
+  // cost less than idle CUs -, SHORT ones take 128 x 128 tiles instead (more workgroups, no slab traffic); the ring forms (one
+  // workgroup per CU, DMA three steps ahead) lose to two co-resident workgroups everywhere and are kept for A/B only.
   HPlan pl{};
-  const bool wide = a->N % 320 == 0;
-  pl.tile = (a->tile_hint == 1 || a->tile_hint == 2) ? a->tile_hint : (wide ? 2 : 1);
-  pl.bk = pl.tile == 2 ? 32 : 64;
-  pl.bm = 128;
-  pl.bn = pl.tile == 1 ? 128 : 320;
+  const long tm = (a->M + 127) / 128;
+  const long tiles2 = tm * ((a->N + 319) / 320), tiles1 = tm * ((a->N + 127) / 128);
+  const bool long_k = a->K >= 2304;
+  int tile;
+  // 32-bit element offsets in the eight-wave kernel
+  const long amax = a->conv ? (long)(a->M / (a->Ho * a->Wo)) * a->H * a->W * (a->lda > a->lda2 ? a->lda : a->lda2)
+                            : (long)a->M * (a->lda > a->lda2 ? a->lda : a->lda2);
+  const bool fits32 = amax < (1L << 31) && (long)a->N * (a->ldb > a->ldb2 ? a->ldb : a->ldb2) < (1L << 31);
+  const long tiles8 = ((a->M + 255) / 256) * ((a->N + 319) / 320);
+  if (a->tile_hint % 100 >= 1 && a->tile_hint % 100 <= 5) tile = a->tile_hint % 100;
+  else if (a->N % 320 != 0) tile = 1;
+  else if (fits32 && tiles8 >= 224) tile = 5;                      // a full round of 256 x 320 tiles, one per CU
+  else if (tiles2 >= 400 || long_k) tile = 2;
+  else tile = tiles1 * 2 > tiles2 * 3 ? 1 : 2;
+  if (tile == 5 && !fits32) tile = 2;
+  pl.tile = tile;
+  const bool t320 = tile == 2 || tile == 3 || tile == 5;
+  pl.bk = t320 ? 32 : 64;
+  pl.bm = tile == 5 ? 256 : 128;
+  pl.bn = t320 ? 320 : 128;
   const int groups = a->conv ? a->KH * a->KW : 1;
   pl.len1 = a->k_split;
   pl.len2 = (a->conv ? a->Cin : a->K) - a->k_split;
@@ -684,14 +983,17 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
   const long tiles = (long)pl.tiles_m * pl.tiles_n;
   int sk = 1;
   if (a->splitk_hint > 0) sk = a->splitk_hint;
-  else {
-    const int slots = 512;                                       // workgroups the chip holds at once (2 per CU)
-    const int min_steps = 256 / pl.bk;                           // at least 256 of K per slice
-    if (tiles * 2 <= slots && pl.steps >= 2 * min_steps) {
-      sk = (int)(slots / tiles);
-      if (sk > pl.steps / min_steps) sk = pl.steps / min_steps;
-      if (sk > 128) sk = 128;
-    }
+  else if (a->out_f32 && tiles <= 16 && a->K >= 1024) {
+    // parameter gradients (a LoRA matrix: a handful of tiles, the whole token axis to contract): slices of >= 256
+    sk = (int)(512 / tiles);
+    if (sk > a->K / 256) sk = a->K / 256;
+    if (sk > 128) sk = 128;
+  } else if (long_k && tiles < 400) {
+    const int slots = tile >= 3 ? 256 : 512;                     // workgroups the chip holds at once (ring forms: one per CU)
+    sk = (int)((slots + tiles / 2) / tiles);
+    const int max_sk = a->K / 1152;                               // at least 1152 of K per slice
+    if (sk > max_sk) sk = max_sk;
+    if (sk > 128) sk = 128;
   }
   if (sk > pl.steps) sk = pl.steps;
   if (sk < 1) sk = 1;
@@ -700,10 +1002,10 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
   return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int BKT>
+template <int WM, int WN, int TM, int TN, int BKT, int NST>
 static int hgemm_launch(const HDev& d, hipStream_t st) {
-  constexpr int LDS = 2 * (WM * TM * 32 + WN * TN * 32) * BKT * 2;
-  auto kern = hgemm_kernel<WM, WN, TM, TN, BKT>;
+  constexpr int LDS = NST * (WM * TM * 32 + WN * TN * 32) * BKT * 2;
+  auto kern = hgemm_kernel<WM, WN, TM, TN, BKT, NST>;
   if (LDS > 64 * 1024) {
     static unsigned done = 0;
     int dev = 0;
@@ -789,20 +1091,36 @@ extern "C" int gad_hgemm(const gad_hgemm_args* a, void* stream) {
   d.ws = (float*)a->ws;
   d.tiles_m = pl.tiles_m; d.tiles_n = pl.tiles_n; d.splitk = pl.splitk; d.steps = pl.steps;
   d.steps_per_split = (pl.steps + pl.splitk - 1) / pl.splitk;
-  if (pl.splitk > 1) {
-    d.vec = a->N % 8 == 0 && gad_aligned16(a->ws);
-  } else {
-    d.vec = a->N % 8 == 0 && gad_aligned16(a->C) && a->ldc % (a->out_f32 ? 4 : 8) == 0 && (!a->bias || gad_aligned16(a->bias)) &&
-            (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
-            (!a->residual || (gad_aligned16(a->residual) && a->ldr % 8 == 0));
-  }
+  d.dbg_zero = a->tile_hint >= 100;
+  d.vec_out = a->N % 8 == 0 && gad_aligned16(a->C) && a->ldc % (a->out_f32 ? 4 : 8) == 0 && (!a->bias || gad_aligned16(a->bias)) &&
+              (!a->rowadd || (gad_aligned16(a->rowadd) && a->ld_rowadd % 4 == 0)) &&
+              (!a->residual || (gad_aligned16(a->residual) && a->ldr % 8 == 0));
+  d.vec = pl.splitk > 1 ? (a->N % 8 == 0 && gad_aligned16(a->ws)) : d.vec_out;
+  if (pl.splitk > 1 && !d.vec) d.vec_out = 0;                      // (slabs with ragged rows: the scalar reduce)
   int rc;
-  if (pl.tile == 1) rc = hgemm_launch<2, 2, 2, 2, 64>(d, st);
-  else if (pl.tile == 2) rc = hgemm_launch<2, 2, 2, 5, 32>(d, st);
+  if (pl.tile == 1) rc = hgemm_launch<2, 2, 2, 2, 64, 2>(d, st);
+  else if (pl.tile == 2) rc = hgemm_launch<2, 2, 2, 5, 32, 2>(d, st);
+  else if (pl.tile == 3) rc = hgemm_launch<2, 2, 2, 5, 32, 4>(d, st);
+  else if (pl.tile == 4) rc = hgemm_launch<2, 2, 2, 2, 64, 3>(d, st);
+  else if (pl.tile == 5) {
+    constexpr int LDS8 = 4 * (256 + 320) * 32 * 2;
+    static unsigned done = 0;
+    int dev = 0;
+    (void)hipGetDevice(&dev);
+    const unsigned bit = 1u << (dev & 31);
+    if (!(__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) {
+      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hgemm8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
+      GAD_CHECK(e == hipSuccess, "gad_hgemm: cannot reserve %d bytes of LDS: %s", LDS8, hipGetErrorString(e));
+      __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
+    }
+    hipLaunchKernelGGL(hgemm8_kernel, dim3(d.tiles_m * d.tiles_n, d.splitk), dim3(512), LDS8, st, d);
+    GAD_LAUNCH_CHECK("hgemm8_kernel");
+    rc = 0;
+  }
   else { gad_set_error("gad_hgemm: tile_hint %d", pl.tile); return 1; }
   if (rc) return rc;
   if (pl.splitk > 1) {
-    const long total = (long)a->M * a->N;
+    const long total = d.vec_out ? (long)a->M * a->N / 8 : (long)a->M * a->N;
     hipLaunchKernelGGL(hgemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d);
     GAD_LAUNCH_CHECK("hgemm_reduce_kernel");
   }
@@ -813,6 +1131,11 @@ extern "C" int gad_h_transpose(const void* src, void* dst, int32_t rows, int32_t
                                void* stream) {
   GAD_CHECK(src && dst && rows > 0 && cols > 0 && ld_src >= cols && ld_dst >= rows, "gad_h_transpose: bad arguments");
   const dim3 grid((cols + 63) / 64, (rows + 63) / 64);
+  if (!src_f32 && rows % 8 == 0 && cols % 8 == 0 && ld_src % 8 == 0 && ld_dst % 8 == 0 && gad_aligned16(src) && gad_aligned16(dst)) {
+    hipLaunchKernelGGL(transpose16_kernel, grid, dim3(256), 0, (hipStream_t)stream, (const u16*)src, (u16*)dst, rows, cols, ld_src, ld_dst);
+    GAD_LAUNCH_CHECK("h_transpose");
+    return 0;
+  }
   if (src_f32) hipLaunchKernelGGL(transpose_kernel<true>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, rows, cols, ld_src, ld_dst);
   else hipLaunchKernelGGL(transpose_kernel<false>, grid, dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, rows, cols, ld_src, ld_dst);
   GAD_LAUNCH_CHECK("h_transpose");

@@ -135,6 +135,45 @@ def half_weight_rot(w):
     return _cached(w, "_gad_hrot", make)
 
 
+def _flat_half(flat):
+    """ONE bf16 cast of a whole flat parameter buffer per optimizer step (the LoRA matrices all live in one:
+    training.flatten_params); slices of it serve every projection."""
+    key = (flat._version, ops.WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
+    c = getattr(flat, "_gad_hflat", None)
+    if c is None or c[0] != key:
+        c = (key, to_half(flat.detach()))
+        flat._gad_hflat = c
+    return c[1]
+
+
+def _half_of(w):
+    """bf16 copy of a 2-D parameter: a slice of its flat buffer's shadow where it lives in one"""
+    if ops._in_flat_buffer(w):
+        flat, off, n = w._gad_flat
+        return _flat_half(flat)[off:off + n].view(w.shape)
+    return to_half(w.detach())
+
+
+_TCACHE = {"epoch": -1}
+
+
+def _transposed_cached(x2d):
+    """x^T for the parameter gradients of one backward pass: the projections of an attention share their input (to_q / to_k /
+    to_v read the same h; to_k / to_v the same context), so its transpose is made once per step.  Only while a FusedTrainer
+    backward is running (ops.begin_backward_step): entries hold their source tensor, so an address cannot be reused under them."""
+    if not ops._SINK_ACTIVE[0]:
+        return transpose_raw(x2d)
+    if _TCACHE["epoch"] != ops._SINK_EPOCH[0]:
+        _TCACHE.clear()
+        _TCACHE["epoch"] = ops._SINK_EPOCH[0]
+    key = (x2d.data_ptr(), tuple(x2d.shape), x2d.stride(0))
+    hit = _TCACHE.get(key)
+    if hit is None:
+        hit = (x2d, transpose_raw(x2d))
+        _TCACHE[key] = hit
+    return hit[1]
+
+
 def lora_half(down, up):
     """bf16 shadows of a LoRA pair, the rank padded with zeros to a multiple of 8 (ragged pruned ranks,
     text_to_image/prune_lora.py:173-180): (down [r8][K], up [N][r8], down^T [K][r8], up^T [r8][N]); refreshed when either
@@ -146,7 +185,7 @@ def lora_half(down, up):
         N = up.shape[0]
         r8 = (r + 7) // 8 * 8
         if r8 == r:
-            dh, uh = to_half(down.detach()), to_half(up.detach())
+            dh, uh = _half_of(down), _half_of(up)
         else:
             dh = torch.zeros((r8, K), device=down.device, dtype=BF16)
             uh = torch.zeros((N, r8), device=down.device, dtype=BF16)
@@ -198,7 +237,7 @@ def hgemm_raw(A, B, out, M, N, K, lda, ldb, ldc, *, A2=None, B2=None, lda2=0, ld
 
 
 def conv_fwd_raw(x, wh, bias, KH, KW, stride=1, pad=(1, 1, 1, 1), upsample=False, rowadd=None, residual=None, x2=None,
-                 conv=1, out_hw=None, out_f32=False):
+                 conv=1, out_hw=None, out_f32=False, tile_hint=0):
     """x [B,H,W,C1] (+ x2 [B,H,W,C2]: channel concat read in place) bf16, wh bf16 [Cout][KH][KW][Cin] -> [B,Ho,Wo,Cout]."""
     Bn, H, W, C1 = x.shape
     Cin = C1 + (x2.shape[-1] if x2 is not None else 0)
@@ -215,7 +254,7 @@ def conv_fwd_raw(x, wh, bias, KH, KW, stride=1, pad=(1, 1, 1, 1), upsample=False
     geom = (H, W, Cin, Ho, Wo, KH, KW, stride, pad[0], pad[2], int(upsample))
     hgemm_raw(x, wh, y, Bn * Ho * Wo, Cout, KH * KW * Cin, C1, KH * KW * Cin, Cout, A2=x2,
               lda2=(x2.shape[-1] if x2 is not None else 0), k_split=C1, conv=conv, geom=geom, bias=bias, rowadd=rowadd,
-              rows_per_group=Ho * Wo, residual=residual, ldr=Cout, out_f32=out_f32)
+              rows_per_group=Ho * Wo, residual=residual, ldr=Cout, out_f32=out_f32, tile_hint=tile_hint)
     return y
 
 
@@ -237,7 +276,7 @@ def wgrad_raw(dy2d, x2d, out, accumulate):
     same engine (split-K)."""
     N, K = out.shape
     dyt = transpose_raw(dy2d)[:N]
-    xt = transpose_raw(x2d)[:K]
+    xt = _transposed_cached(x2d)[:K]
     linear_raw(dyt, xt, out=out, out_f32=True, accumulate=accumulate)
 
 
