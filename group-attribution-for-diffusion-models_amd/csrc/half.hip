@@ -59,6 +59,7 @@ struct HDev {
   int tiles_m, tiles_n, splitk, steps_per_split, steps;
   int vec;                  // the epilogue's operands (or the split-K slabs) can be moved as aligned 16-byte vectors
   int vec_out;              // the output-side operands can (the split-K reduce's epilogue)
+  const u16* zero;          // the zero block (a DMA source like any other)
   int dbg_zero;             // A/B tools only (tile_hint + 100): every DMA reads the zero block - the kernel without its memory system
 };
 
@@ -133,15 +134,26 @@ __device__ __forceinline__ void barrier_vm() {          // all but this wave's N
   asm volatile("s_waitcnt vmcnt(%0)\n\ts_barrier" ::"n"(N) : "memory");
 }
 
-// NST = 2: two stage buffers, the next K step's DMA issued before this step's MFMAs, two workgroups per CU cover each other's waits.
-// NST >= 3: a ring of NST stage buffers with the DMA running NST - 1 K steps ahead (counted s_waitcnt vmcnt, one raw barrier per step),
-//           one workgroup per CU.
-template <int WM, int WN, int TM, int TN, int BKT, int NST>
-__global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(const HDev p) {
+// ---------------------------------------------------------------------------------------------------------------
+// hgemm_kernel<WM, WN, TM, TN, BKT, NST, ROLES, GATHER>
+//   WM x WN waves, each TM x TN tiles of 32 x 32 (v_mfma_f32_32x32x16_bf16); K steps of BKT.
+//   NST = 2: two stage buffers, the next step's DMA issued before this step's MFMAs; two workgroups per CU cover each other's waits.
+//   NST >= 3: a ring with the DMA NST - 1 steps ahead (counted vmcnt, one raw barrier per step), one workgroup per CU.
+//   ROLES: the lower half of the waves streams B (weights), the upper half A (activations / the gather): a wave carries one kind of
+//          addressing.  GATHER: 0 dense A (+ K concatenation), 1 convolution gather, 2 gather with the nearest-2x / stride-2-transposed forms.
+// The DMA issue path is the part that competes with the MFMAs for the vector issue slots (an MFMA leaves 24 of its 32 cycles to other
+// vector instructions), so it is kept lean: 32-bit element offsets fixed before the loop, one chunk index per wave (rows are dealt to the
+// DMA instructions so that the XOR swizzle is the same for all of a wave's instructions), the walk over (tap, segment, k) carried in
+// scalars, the zero block's address in a kernel argument, no branches.
+// ---------------------------------------------------------------------------------------------------------------
+template <int WM, int WN, int TM, int TN, int BKT, int NST, bool ROLES, int GATHER>
+__global__ __launch_bounds__(WM* WN * 64, (NST == 2 || WM * WN == 8) ? 2 : 1) void hgemm_kernel(const HDev p) {
   constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int CPR = BKT / 8, RPI = 64 / CPR;             // 16-B chunks per tile row; tile rows per DMA wave-instruction
-  constexpr int AI = BM / RPI / NW, BI = BN / RPI / NW;   // DMA instructions per wave per K step
-  static_assert(BM % (RPI * NW) == 0 && BN % (RPI * NW) == 0, "tile rows must divide over the waves' DMA instructions");
+  constexpr int NWA = ROLES ? NW / 2 : NW, NWB = NWA;      // waves that issue A / B DMAs
+  constexpr int AI = BM / RPI / NWA, BI = BN / RPI / NWB;  // DMA instructions per issuing wave and K step
+  static_assert(BM % (RPI * NWA) == 0 && BN % (RPI * NWB) == 0, "tile rows must divide over the waves' DMA instructions");
+  static_assert(NWA % 2 == 0, "interleaved row dealing keeps the swizzle per wave only for an even wave count");
   constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = A_BYTES + B_BYTES;
   extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
 
@@ -152,85 +164,102 @@ __global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(co
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave / WN, wn = wave - wm * WN;
+  const bool does_b = !ROLES || wave < NWB, does_a = !ROLES || wave >= NWB;
+  const int wa = ROLES ? wave - NWB : wave, wb = wave;     // index among the A / B issuing waves
   const int lrow = lane / CPR, slot = lane % CPR;
   auto swz = [](int row) { return BKT == 64 ? (row >> 1) & 7 : (row >> 2) & 3; };
+  // DMA instruction ii of an operand covers tile rows [ii * RPI, (ii + 1) * RPI); wave w issues ii = i * NWx + w, so (ii * RPI + lrow)'s
+  // swizzle bits do not depend on i: one source chunk per wave and operand
+  const int cha = (slot ^ swz(wa * RPI + lrow)) * 8, chb = (slot ^ swz(wb * RPI + lrow)) * 8;
 
-  // ---- per-thread DMA sources ----
-  long aoff[AI], a2off[AI];      // element offset of this lane's row (dense) / image base pixel (conv)
-  int ay[AI], ax[AI];            // conv: oy*stride - pad_t, ox*stride - pad_l
-  int ach[AI];                   // source chunk (swizzled) in elements
+  int aoff[AI], aoff2[GATHER ? 1 : AI], ay[GATHER ? AI : 1], ax[GATHER ? AI : 1];
   bool aok[AI];
 #pragma unroll
   for (int i = 0; i < AI; ++i) {
-    const int rl = (wave * AI + i) * RPI + lrow;
-    const int m = row0 + rl;
-    aok[i] = m < p.M;
-    ach[i] = (slot ^ swz(rl)) * 8;
-    if (p.conv) {
-      const int hw = p.Ho * p.Wo;
-      const int mm = aok[i] ? m : 0;
+    const int rl = (i * NWA + wa) * RPI + lrow, m = row0 + rl;
+    aok[i] = does_a && m < p.M;
+    if constexpr (GATHER != 0) {
+      const int hw = p.Ho * p.Wo, mm = aok[i] ? m : 0;
       const int img = mm / hw, rem = mm - img * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-      aoff[i] = (long)img * p.H * p.W;
-      a2off[i] = 0;
+      aoff[i] = img * p.H * p.W;                      // image base pixel
       ay[i] = oy * p.stride - p.pad_t;
       ax[i] = ox * p.stride - p.pad_l;
     } else {
-      aoff[i] = (long)m * p.lda;
-      a2off[i] = (long)m * p.lda2;
-      ay[i] = ax[i] = 0;
+      aoff[i] = m * p.lda + cha;
+      aoff2[i] = m * p.lda2 + cha;
     }
   }
-  long boff[BI], b2off[BI];
-  int bch[BI];
+  int boff[BI], boff2[GATHER ? 1 : BI];
   bool bok[BI];
 #pragma unroll
   for (int i = 0; i < BI; ++i) {
-    const int rl = (wave * BI + i) * RPI + lrow;
-    const int n = col0 + rl;
-    bok[i] = n < p.N;
-    bch[i] = (slot ^ swz(rl)) * 8;
-    boff[i] = (long)n * p.ldb;
-    b2off[i] = (long)n * p.ldb2;
+    const int rl = (i * NWB + wb) * RPI + lrow, n = col0 + rl;
+    bok[i] = does_b && n < p.N;
+    boff[i] = n * p.ldb + chb;
+    if constexpr (GATHER == 0) boff2[i] = n * p.ldb2 + chb;
   }
 
-  const int spg = p.n1 + p.n2;                 // K steps per group (tap)
-  auto stage = [&](int step, int buf, bool live = true) {
-    const int grp = step / spg, u = step - grp * spg;
-    const bool s2 = u >= p.n1;
-    const int kk = (s2 ? u - p.n1 : u) * BKT;                 // offset inside the segment
-    const int klim = s2 ? p.len2 : p.len1;
-    unsigned char* dstA = lds + buf * STAGE + (wave * AI) * 1024;
-    unsigned char* dstB = lds + buf * STAGE + A_BYTES + (wave * BI) * 1024;
-    int r = 0, s = 0;
-    if (p.conv) { r = grp / p.KW; s = grp - r * p.KW; }
+  // the walk over K steps: group (tap) sg, step su inside the group; conv taps (sr, ss)
+  const int spg = p.n1 + p.n2;
+  const int t0 = z * p.steps_per_split;
+  const int t1 = min(p.steps, t0 + p.steps_per_split);
+  int sg = t0 / spg, su = t0 - sg * spg, sr = 0, ss = 0;
+  if constexpr (GATHER != 0) { sr = sg / p.KW; ss = sg - sr * p.KW; }
+  const u16* const zero = p.zero;
+  auto stage = [&](int buf, bool live) {                 // issues the DMAs of the walk's current step, then advances the walk
+    const bool s2 = su >= p.n1;
+    const int kk = (s2 ? su - p.n1 : su) * BKT;
+    const int rem = (s2 ? p.len2 : p.len1) - kk;         // valid K left in this segment (>= BKT except on a segment's last step)
+    if (does_a) {
+      unsigned char* dst = lds + buf * STAGE + wa * 1024;
+      const bool tail_ok = cha < rem;
+      if constexpr (GATHER != 0) {
+        const u16* base = s2 ? p.A2 : p.A;
+        const int ld = s2 ? p.lda2 : p.lda;
 #pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      bool ok = live && aok[i] && kk + ach[i] < klim;
-      const u16* src;
-      if (p.conv) {
-        int yy = ay[i] + r, xx = ax[i] + s;
-        if (p.ups) { ok = ok && yy >= 0 && xx >= 0 && yy < 2 * p.H && xx < 2 * p.W; yy >>= 1; xx >>= 1; }
-        if (p.conv == 2) { ok = ok && !(yy & 1) && !(xx & 1); yy >>= 1; xx >>= 1; }
-        ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-        const long pix = aoff[i] + (long)yy * p.W + xx;
-        src = s2 ? p.A2 + pix * p.lda2 : p.A + pix * p.lda;
+        for (int i = 0; i < AI; ++i) {
+          int yy = ay[i] + sr, xx = ax[i] + ss;
+          bool ok = live && aok[i] && tail_ok;
+          if constexpr (GATHER == 2) {
+            if (p.ups) { ok = ok && (unsigned)yy < 2u * p.H && (unsigned)xx < 2u * p.W; yy >>= 1; xx >>= 1; }
+            if (p.conv == 2) { ok = ok && !((yy | xx) & 1); yy >>= 1; xx >>= 1; }
+          }
+          ok = ok && (unsigned)yy < (unsigned)p.H && (unsigned)xx < (unsigned)p.W;
+          const int off = (aoff[i] + yy * p.W + xx) * ld + kk + cha;
+          const u16* src = ok ? base + off : zero;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst + i * (NWA * 1024)), 16, 0, 0);
+        }
       } else {
-        src = s2 ? p.A2 + a2off[i] : p.A + aoff[i];
-      }
-      src = ok ? src + kk + ach[i] : reinterpret_cast<const u16*>(g_zero);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dstA + i * 1024), 16, 0, 0);
-    }
-    // B: one [N][taps * (len1 + len2)] matrix, or (dense K concatenation) a second matrix for segment 2
-    const bool b_second = s2 && p.B2 != nullptr;
-    const long kb = b_second ? kk : (long)grp * (p.len1 + p.len2) + (s2 ? p.len1 : 0) + kk;
+        const u16* base = s2 ? p.A2 : p.A;
 #pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const bool ok = live && bok[i] && kk + bch[i] < klim;
-      const u16* src = b_second ? p.B2 + b2off[i] : p.B + boff[i];
-      src = ok ? src + kb + bch[i] : reinterpret_cast<const u16*>(g_zero);
-      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                       (__attribute__((address_space(3))) void*)(dstB + i * 1024), 16, 0, 0);
+        for (int i = 0; i < AI; ++i) {
+          const bool ok = live && aok[i] && tail_ok;
+          const u16* src = ok ? base + ((s2 ? aoff2[i] : aoff[i]) + kk) : zero;
+          __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                           (__attribute__((address_space(3))) void*)(dst + i * (NWA * 1024)), 16, 0, 0);
+        }
+      }
+    }
+    if (does_b) {
+      unsigned char* dst = lds + buf * STAGE + A_BYTES + wb * 1024;
+      const bool tail_ok = chb < rem;
+      const bool second = GATHER == 0 && s2 && p.B2 != nullptr;
+      const u16* base = second ? p.B2 : p.B;
+      const int kb = second ? kk : sg * (p.len1 + p.len2) + (s2 ? p.len1 : 0) + kk;
+#pragma unroll
+      for (int i = 0; i < BI; ++i) {
+        const bool ok = live && bok[i] && tail_ok;
+        const int o = GATHER == 0 ? (second ? boff2[i] : boff[i]) : boff[i];
+        const u16* src = ok ? base + (o + kb) : zero;
+        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
+                                         (__attribute__((address_space(3))) void*)(dst + i * (NWB * 1024)), 16, 0, 0);
+      }
+    }
+    if (++su == spg) {
+      su = 0;
+      ++sg;
+      if constexpr (GATHER != 0) { if (++ss == p.KW) { ss = 0; ++sr; } }
     }
   };
 
@@ -246,9 +275,6 @@ __global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(co
   const int swl = swz(l31);
   const int a_base = (wm * TM * 32 + l31) * (BKT * 2);
   const int b_base = A_BYTES + (wn * TN * 32 + l31) * (BKT * 2);
-
-  const int t0 = z * p.steps_per_split;
-  const int t1 = min(p.steps, t0 + p.steps_per_split);
   auto compute = [&](int buf) {
     const unsigned char* sb = lds + buf * STAGE;
 #pragma unroll
@@ -265,28 +291,30 @@ __global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(co
         for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
     }
   };
+  const bool live0 = !p.dbg_zero;
   if constexpr (NST == 2) {
     if (t0 < t1) {
-      stage(t0, 0, !p.dbg_zero);
+      stage(0, live0);
       __builtin_amdgcn_s_waitcnt(0x0F70);        // vmcnt(0): the DMA is a VMEM operation
       __syncthreads();
     }
     for (int st = t0; st < t1; ++st) {
       const int buf = (st - t0) & 1;
-      if (st + 1 < t1) stage(st + 1, buf ^ 1, !p.dbg_zero);
+      if (st + 1 < t1) stage(buf ^ 1, live0);
       compute(buf);
       __builtin_amdgcn_s_waitcnt(0x0F70);
       __syncthreads();
     }
   } else {
-    constexpr int D = NST - 1, NDMA = AI + BI;
-    static_assert((D - 1) * NDMA < 64, "vmcnt range");
+    constexpr int D = NST - 1;
+    constexpr int NDA = ROLES ? AI : AI + BI, NDB = ROLES ? BI : AI + BI;      // DMAs per step of an A-issuing / B-issuing wave
+    static_assert((D - 1) * NDA < 64 && (D - 1) * NDB < 64, "vmcnt range");
 #pragma unroll
-    for (int s_ = 0; s_ < D; ++s_) stage(min(t0 + s_, p.steps - 1), s_, t0 + s_ < t1);
+    for (int s_ = 0; s_ < D; ++s_) stage(s_, live0 && t0 + s_ < t1);
     int rd = 0, wr = D;                          // ring positions: read this step / refill (the buffer read in the previous step)
     for (int st = t0; st < t1; ++st) {
-      barrier_vm<(D - 1) * NDMA>();              // this step's stage has landed; every wave is past the previous step's reads
-      stage(min(st + D, p.steps - 1), wr, st + D < t1);
+      if (ROLES && wave >= NWB) barrier_vm<(D - 1) * NDA>(); else barrier_vm<(D - 1) * NDB>();   // this step's stage landed; all past the last step's reads
+      stage(wr, live0 && st + D < t1);
       compute(rd);
       rd = rd + 1 == NST ? 0 : rd + 1;
       wr = wr + 1 == NST ? 0 : wr + 1;
@@ -302,6 +330,7 @@ __global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(co
   // segments per wave-instruction.  (The LDS operations of one wave complete in order: no barrier inside a wave's patch.)
   constexpr int EW = TN * 32, ELD = EW + 4, CH = EW / 8, TASKS = 16 * CH / 64;
   static_assert((16 * CH) % 64 == 0, "patch chunks must divide over the lanes");
+  static_assert(NW * 16 * ELD * 4 <= NST * STAGE, "the patches live in the stage buffers");
   float* patch = reinterpret_cast<float*>(lds) + wave * (16 * ELD);
   float* slab = p.splitk > 1 ? p.ws + (long)z * p.M * p.N : nullptr;
 #pragma clang loop unroll(full)
@@ -328,180 +357,6 @@ __global__ __launch_bounds__(WM* WN * 64, NST == 2 ? 2 : 1) void hgemm_kernel(co
   }
 }
 
-// ---------------------------------------------------------------------------------------------------------------
-// hgemm8_kernel: the 256 x 320 tile on EIGHT waves (4 x 2, each 64 x 160 as in the 128 x 320 form), one workgroup per CU.
-// Against two co-resident 128 x 320 workgroups: the same two waves per SIMD, but (i) 0.65x the operand bytes through L2 per
-// FLOP, (ii) a ring of four 36 KB stage buffers with the LDS-DMA running THREE K steps (= 3 x 1280 MFMA cycles per SIMD) ahead
-// - the 128 x 320 form waits for every step's DMA after one step of compute and is latency-bound even with every source in
-// cache (tools/ab_hgemm_zero.py) -, (iii) the DMA split by role: waves 0-3 stream the weights (5 wave-instructions per step),
-// waves 4-7 the activations / the convolution gather (4), so a wave carries one kind of addressing, in 32-bit offsets.
-// One raw barrier per K step with a counted vmcnt (two stages stay in flight across it).
-// ---------------------------------------------------------------------------------------------------------------
-__global__ __launch_bounds__(512, 2) void hgemm8_kernel(const HDev p) {
-  constexpr int TM = 2, TN = 5, BKT = 32, NST = 4, D = NST - 1;
-  constexpr int BM = 256, BN = 320, RPI = 16;              // 4 chunks per 64-byte tile row, 16 rows per DMA wave-instruction
-  constexpr int AI = 4, BI = 5;                            // per A-role / B-role wave and K step
-  constexpr int A_BYTES = BM * BKT * 2, B_BYTES = BN * BKT * 2, STAGE = A_BYTES + B_BYTES;
-  extern __shared__ __attribute__((aligned(1024))) unsigned char lds[];
-
-  const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
-  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
-  const int row0 = tile_m * BM, col0 = tile_n * BN;
-  const int z = blockIdx.y;
-  const int tid = threadIdx.x, lane = tid & 63;
-  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
-  const int wm = wave >> 1, wn = wave & 1;
-  const bool role_b = wave < 4;
-  const int lrow = lane >> 2, slot = lane & 3;
-  auto swz = [](int row) { return (row >> 2) & 3; };
-
-  // per-lane DMA sources of this wave's role (element offsets fit 32 bits: host check)
-  int off1[BI], off2[BI], yy0[AI], xx0[AI], chn[BI];
-  unsigned okm = 0;
-#pragma unroll
-  for (int i = 0; i < BI; ++i) { off1[i] = off2[i] = chn[i] = 0; }
-#pragma unroll
-  for (int i = 0; i < AI; ++i) { yy0[i] = xx0[i] = 0; }
-  if (role_b) {
-#pragma unroll
-    for (int i = 0; i < BI; ++i) {
-      const int rl = (wave * BI + i) * RPI + lrow, n = col0 + rl;
-      okm |= (unsigned)(n < p.N) << i;
-      chn[i] = (slot ^ swz(rl)) * 8;
-      off1[i] = n * p.ldb;
-      off2[i] = n * p.ldb2;
-    }
-  } else {
-#pragma unroll
-    for (int i = 0; i < AI; ++i) {
-      const int rl = ((wave - 4) * AI + i) * RPI + lrow, m = row0 + rl;
-      const bool ok = m < p.M;
-      okm |= (unsigned)ok << i;
-      chn[i] = (slot ^ swz(rl)) * 8;
-      if (p.conv) {
-        const int hw = p.Ho * p.Wo, mm = ok ? m : 0;
-        const int img = mm / hw, rem = mm - img * hw, oy = rem / p.Wo, ox = rem - oy * p.Wo;
-        off1[i] = img * p.H * p.W;                // image base pixel
-        yy0[i] = oy * p.stride - p.pad_t;
-        xx0[i] = ox * p.stride - p.pad_l;
-      } else {
-        off1[i] = m * p.lda;
-        off2[i] = m * p.lda2;
-      }
-    }
-  }
-
-  const int spg = p.n1 + p.n2;
-  auto stage = [&](int step, int buf, bool live) {
-    const int grp = step / spg, u = step - grp * spg;
-    const bool s2 = u >= p.n1;
-    const int kk = (s2 ? u - p.n1 : u) * BKT;
-    const int klim = s2 ? p.len2 : p.len1;
-    if (role_b) {
-      unsigned char* dst = lds + buf * STAGE + A_BYTES + (wave * BI) * 1024;
-      const bool second = s2 && p.B2 != nullptr;
-      const u16* base = second ? p.B2 : p.B;
-      const int kb = second ? kk : grp * (p.len1 + p.len2) + (s2 ? p.len1 : 0) + kk;
-#pragma unroll
-      for (int i = 0; i < BI; ++i) {
-        const bool ok = live && ((okm >> i) & 1u) && kk + chn[i] < klim;
-        const u16* src = ok ? base + (long)(second ? off2[i] : off1[i]) + kb + chn[i] : reinterpret_cast<const u16*>(g_zero);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-      }
-    } else {
-      unsigned char* dst = lds + buf * STAGE + ((wave - 4) * AI) * 1024;
-      int r = 0, s = 0;
-      if (p.conv) { r = grp / p.KW; s = grp - r * p.KW; }
-      const u16* base = s2 ? p.A2 : p.A;
-      const int ld = s2 ? p.lda2 : p.lda;
-#pragma unroll
-      for (int i = 0; i < AI; ++i) {
-        bool ok = live && ((okm >> i) & 1u) && kk + chn[i] < klim;
-        long eo;
-        if (p.conv) {
-          int yy = yy0[i] + r, xx = xx0[i] + s;
-          if (p.ups) { ok = ok && yy >= 0 && xx >= 0 && yy < 2 * p.H && xx < 2 * p.W; yy >>= 1; xx >>= 1; }
-          if (p.conv == 2) { ok = ok && !(yy & 1) && !(xx & 1); yy >>= 1; xx >>= 1; }
-          ok = ok && yy >= 0 && yy < p.H && xx >= 0 && xx < p.W;
-          eo = (long)(off1[i] + yy * p.W + xx) * ld;
-        } else {
-          eo = s2 ? off2[i] : off1[i];
-        }
-        const u16* src = ok ? base + eo + kk + chn[i] : reinterpret_cast<const u16*>(g_zero);
-        __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)src,
-                                         (__attribute__((address_space(3))) void*)(dst + i * 1024), 16, 0, 0);
-      }
-    }
-  };
-
-  f32x16 acc[TM][TN];
-#pragma unroll
-  for (int i = 0; i < TM; ++i)
-#pragma unroll
-    for (int j = 0; j < TN; ++j)
-#pragma unroll
-      for (int e = 0; e < 16; ++e) acc[i][j][e] = 0.f;
-
-  const int l31 = lane & 31, h = lane >> 5;
-  const int swl = swz(l31);
-  const int a_base = (wm * TM * 32 + l31) * (BKT * 2);
-  const int b_base = A_BYTES + (wn * TN * 32 + l31) * (BKT * 2);
-  const int t0 = z * p.steps_per_split;
-  const int t1 = min(p.steps, t0 + p.steps_per_split);
-
-#pragma unroll
-  for (int s_ = 0; s_ < D; ++s_) stage(min(t0 + s_, p.steps - 1), s_, t0 + s_ < t1 && !p.dbg_zero);
-  int rd = 0, wr = D;
-  for (int st = t0; st < t1; ++st) {
-    if (role_b) barrier_vm<(D - 1) * BI>(); else barrier_vm<(D - 1) * AI>();     // this step's stage landed; everyone is past the last step's reads
-    stage(min(st + D, p.steps - 1), wr, st + D < t1 && !p.dbg_zero);
-    const unsigned char* sb = lds + rd * STAGE;
-#pragma unroll
-    for (int kk = 0; kk < BKT / 16; ++kk) {
-      const int off = ((2 * kk + h) ^ swl) * 16;
-      bf16x8 af[TM], bfr[TN];
-#pragma unroll
-      for (int i = 0; i < TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 32 * BKT * 2 + off);
-#pragma unroll
-      for (int j = 0; j < TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * 32 * BKT * 2 + off);
-#pragma unroll
-      for (int i = 0; i < TM; ++i)
-#pragma unroll
-        for (int j = 0; j < TN; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_32x32x16_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
-    }
-    rd = rd + 1 == NST ? 0 : rd + 1;
-    wr = wr + 1 == NST ? 0 : wr + 1;
-  }
-  barrier_vm<0>();
-
-  // ---- epilogue: as hgemm_kernel's (wave-private LDS patch -> 16-byte row vectors) ----
-  constexpr int EW = TN * 32, ELD = EW + 4, CH = EW / 8, TASKS = 16 * CH / 64;
-  float* patch = reinterpret_cast<float*>(lds) + wave * (16 * ELD);
-  float* slab = p.splitk > 1 ? p.ws + (long)z * p.M * p.N : nullptr;
-#pragma clang loop unroll(full)
-  for (int i = 0; i < TM; ++i) {
-#pragma clang loop unroll(full)
-    for (int hf = 0; hf < 2; ++hf) {
-#pragma clang loop unroll(full)
-      for (int j = 0; j < TN; ++j)
-#pragma clang loop unroll(full)
-        for (int q = 0; q < 2; ++q)
-#pragma clang loop unroll(full)
-          for (int e4 = 0; e4 < 4; ++e4)
-            patch[(e4 + 8 * q + 4 * h) * ELD + j * 32 + l31] = acc[i][j][(2 * hf + q) * 4 + e4];
-#pragma clang loop unroll(full)
-      for (int tk = 0; tk < TASKS; ++tk) {
-        const int task = lane + 64 * tk;
-        const int r = task / CH, c = (task - r * CH) * 8;
-        const int m = row0 + (wm * TM + i) * 32 + 16 * hf + r, n = col0 + wn * EW + c;
-        const f32x4 v0 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c), v1 = *reinterpret_cast<const f32x4*>(patch + r * ELD + c + 4);
-        if (m >= p.M || n >= p.N) continue;
-        epi_row8(p, slab, m, n, v0, v1);
-      }
-    }
-  }
-}
 
 // split-K: sum the slabs in a fixed order and run the epilogue (8 columns per thread where the operands allow 16-byte vectors)
 __global__ __launch_bounds__(256) void hgemm_reduce_kernel(const HDev p) {
@@ -922,7 +777,7 @@ __global__ void gn_apply_kernel(const GnDev p) {
 // ---------------------------------------------------------------------------------------------------------------
 // host side
 // ---------------------------------------------------------------------------------------------------------------
-struct HPlan { int tile, splitk, bk, bm, bn, steps, n1, n2, len1, len2, tiles_m, tiles_n; };
+struct HPlan { int tile, splitk, bk, bm, bn, steps, n1, n2, len1, len2, tiles_m, tiles_n, fits32; };
 
 static int hgemm_check(const gad_hgemm_args* a) {
   GAD_CHECK(a && a->A && a->B && a->C, "gad_hgemm: null operand");
@@ -961,14 +816,16 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
                             : (long)a->M * (a->lda > a->lda2 ? a->lda : a->lda2);
   const bool fits32 = amax < (1L << 31) && (long)a->N * (a->ldb > a->ldb2 ? a->ldb : a->ldb2) < (1L << 31);
   const long tiles8 = ((a->M + 255) / 256) * ((a->N + 319) / 320);
-  if (a->tile_hint % 100 >= 1 && a->tile_hint % 100 <= 5) tile = a->tile_hint % 100;
+  const int hint = a->tile_hint % 100;
+  if (hint == 1 || hint == 2 || hint == 5) tile = hint;
   else if (a->N % 320 != 0) tile = 1;
-  else if (fits32 && tiles8 >= 224) tile = 5;                      // a full round of 256 x 320 tiles, one per CU
+  else if (tiles8 >= 224) tile = 5;                                // a full round of 256 x 320 tiles, one per CU
+  else if (long_k && tiles8 >= 48) tile = 5;                       // ... or one made of K slices (16x16 / 32x32 maps)
   else if (tiles2 >= 400 || long_k) tile = 2;
   else tile = tiles1 * 2 > tiles2 * 3 ? 1 : 2;
-  if (tile == 5 && !fits32) tile = 2;
   pl.tile = tile;
-  const bool t320 = tile == 2 || tile == 3 || tile == 5;
+  pl.fits32 = fits32;
+  const bool t320 = tile == 2 || tile == 5;
   pl.bk = t320 ? 32 : 64;
   pl.bm = tile == 5 ? 256 : 128;
   pl.bn = t320 ? 320 : 128;
@@ -989,8 +846,9 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
     if (sk > a->K / 256) sk = a->K / 256;
     if (sk > 128) sk = 128;
   } else if (long_k && tiles < 400) {
-    const int slots = tile >= 3 ? 256 : 512;                     // workgroups the chip holds at once (ring forms: one per CU)
+    const int slots = tile == 5 ? 256 : 512;                     // workgroups the chip holds at once (the eight-wave form: one per CU)
     sk = (int)((slots + tiles / 2) / tiles);
+    if (tile == 5 && tiles >= 224) sk = 1;
     const int max_sk = a->K / 1152;                               // at least 1152 of K per slice
     if (sk > max_sk) sk = max_sk;
     if (sk > 128) sk = 128;
@@ -1002,10 +860,10 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
   return pl;
 }
 
-template <int WM, int WN, int TM, int TN, int BKT, int NST>
-static int hgemm_launch(const HDev& d, hipStream_t st) {
+template <int WM, int WN, int TM, int TN, int BKT, int NST, bool ROLES, int GATHER>
+static int hgemm_launch_g(const HDev& d, hipStream_t st) {
   constexpr int LDS = NST * (WM * TM * 32 + WN * TN * 32) * BKT * 2;
-  auto kern = hgemm_kernel<WM, WN, TM, TN, BKT, NST>;
+  auto kern = hgemm_kernel<WM, WN, TM, TN, BKT, NST, ROLES, GATHER>;
   if (LDS > 64 * 1024) {
     static unsigned done = 0;
     int dev = 0;
@@ -1020,6 +878,28 @@ static int hgemm_launch(const HDev& d, hipStream_t st) {
   hipLaunchKernelGGL(kern, dim3(d.tiles_m * d.tiles_n, d.splitk), dim3(WM * WN * 64), LDS, st, d);
   GAD_LAUNCH_CHECK("hgemm_kernel");
   return 0;
+}
+template <int WM, int WN, int TM, int TN, int BKT, int NST, bool ROLES>
+static int hgemm_launch(const HDev& d, hipStream_t st) {
+  if (!d.conv) return hgemm_launch_g<WM, WN, TM, TN, BKT, NST, ROLES, 0>(d, st);
+  if (d.conv == 1 && !d.ups) return hgemm_launch_g<WM, WN, TM, TN, BKT, NST, ROLES, 1>(d, st);
+  return hgemm_launch_g<WM, WN, TM, TN, BKT, NST, ROLES, 2>(d, st);
+}
+
+// the zero block's device address (per device; a static __device__ array of this translation unit)
+static const u16* zero_block() {
+  static const u16* addr[32] = {};
+  int dev = 0;
+  (void)hipGetDevice(&dev);
+  dev &= 31;
+  const u16* p = __atomic_load_n(&addr[dev], __ATOMIC_ACQUIRE);
+  if (!p) {
+    void* sym = nullptr;
+    if (hipGetSymbolAddress(&sym, HIP_SYMBOL(g_zero)) != hipSuccess || !sym) return nullptr;
+    p = reinterpret_cast<const u16*>(sym);
+    __atomic_store_n(&addr[dev], p, __ATOMIC_RELEASE);
+  }
+  return p;
 }
 
 static int64_t gn_chunks(const gad_groupnorm_args* a, int* rows_per_chunk, int* NO, int* RP) {
@@ -1074,6 +954,7 @@ extern "C" int64_t gad_hgemm_workspace_bytes(const gad_hgemm_args* a) {
 extern "C" int gad_hgemm(const gad_hgemm_args* a, void* stream) {
   if (hgemm_check(a)) return 1;
   const HPlan pl = hgemm_plan(a);
+  GAD_CHECK(pl.fits32, "gad_hgemm: an operand spans 2^31 elements or more (the kernels address in 32-bit element offsets)");
   hipStream_t st = (hipStream_t)stream;
   if (pl.splitk > 1)
     GAD_CHECK(a->ws && a->ws_bytes >= (int64_t)pl.splitk * a->M * a->N * 4, "gad_hgemm: split-K workspace too small (%lld needed)",
@@ -1098,25 +979,11 @@ extern "C" int gad_hgemm(const gad_hgemm_args* a, void* stream) {
   d.vec = pl.splitk > 1 ? (a->N % 8 == 0 && gad_aligned16(a->ws)) : d.vec_out;
   if (pl.splitk > 1 && !d.vec) d.vec_out = 0;                      // (slabs with ragged rows: the scalar reduce)
   int rc;
-  if (pl.tile == 1) rc = hgemm_launch<2, 2, 2, 2, 64, 2>(d, st);
-  else if (pl.tile == 2) rc = hgemm_launch<2, 2, 2, 5, 32, 2>(d, st);
-  else if (pl.tile == 3) rc = hgemm_launch<2, 2, 2, 5, 32, 4>(d, st);
-  else if (pl.tile == 4) rc = hgemm_launch<2, 2, 2, 2, 64, 3>(d, st);
-  else if (pl.tile == 5) {
-    constexpr int LDS8 = 4 * (256 + 320) * 32 * 2;
-    static unsigned done = 0;
-    int dev = 0;
-    (void)hipGetDevice(&dev);
-    const unsigned bit = 1u << (dev & 31);
-    if (!(__atomic_load_n(&done, __ATOMIC_ACQUIRE) & bit)) {
-      hipError_t e = hipFuncSetAttribute(reinterpret_cast<const void*>(hgemm8_kernel), hipFuncAttributeMaxDynamicSharedMemorySize, LDS8);
-      GAD_CHECK(e == hipSuccess, "gad_hgemm: cannot reserve %d bytes of LDS: %s", LDS8, hipGetErrorString(e));
-      __atomic_fetch_or(&done, bit, __ATOMIC_RELEASE);
-    }
-    hipLaunchKernelGGL(hgemm8_kernel, dim3(d.tiles_m * d.tiles_n, d.splitk), dim3(512), LDS8, st, d);
-    GAD_LAUNCH_CHECK("hgemm8_kernel");
-    rc = 0;
-  }
+  d.zero = zero_block();
+  GAD_CHECK(d.zero != nullptr, "gad_hgemm: cannot resolve the zero block's device address");
+  if (pl.tile == 1) rc = hgemm_launch<2, 2, 2, 2, 64, 2, false>(d, st);
+  else if (pl.tile == 2) rc = hgemm_launch<2, 2, 2, 5, 32, 2, false>(d, st);
+  else if (pl.tile == 5) rc = hgemm_launch<4, 2, 2, 5, 32, 4, true>(d, st);
   else { gad_set_error("gad_hgemm: tile_hint %d", pl.tile); return 1; }
   if (rc) return rc;
   if (pl.splitk > 1) {

@@ -414,11 +414,11 @@ typedef struct gad_hgemm_args {
   int32_t ldr;
   int32_t out_f32, accumulate;
   void* ws; int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 auto; 1: 128 x 128 tiles; 2: 128 x 320; 5: 256 x 320 on eight waves; 3 / 4: ring forms of 2 / 1 (A/B) */
+  int32_t tile_hint;        /* 0 auto; 1: 128 x 128 tiles; 2: 128 x 320; 5: 256 x 320 on eight waves (tests, A/B tools)        */
   int32_t splitk_hint;      /* 0 auto; > 0 force                                                                */
 } gad_hgemm_args;
 int64_t gad_hgemm_workspace_bytes(const gad_hgemm_args* a);
-int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: 1 .. 5 as tile_hint */
+int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: 1 / 2 / 5 as tile_hint */
 int gad_hgemm(const gad_hgemm_args* a, void* stream);
 /* dst[c][r] = bf16(src[r][c]) for `batch` matrices (strides in elements); src fp32 (src_f32 != 0) or bf16; the operand
  * transposes of the LoRA parameter gradients (dUp = dy^T mid, dDown = dmid^T x) and of the per-step bf16 shadows of the
