@@ -1419,13 +1419,30 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
   rg.template commit<C::SV>(ldsh + IMG);
   __syncthreads();
   const int ntiles = (p.Tq + KV - 1) / KV;
+  // the tile's log-sum-exp / delta rows (query row 16 t + 4 g + e of the tile), fetched one tile ahead like the tile itself: read at
+  // their point of use they were eight dependent global loads in front of every tile's exponentials
+  f32x4 nl[2], nd[2];
+  auto fetch_stats = [&](int tile) {
+#pragma unroll
+    for (int t = 0; t < 2; ++t)
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int qrow = tile * KV + 16 * t + 4 * g + e;
+        const bool qok = qrow < p.Tq;
+        nl[t][e] = qok ? lse[qrow] : 0.f;
+        nd[t][e] = qok ? dlt[qrow] : 0.f;
+      }
+  };
+  fetch_stats(0);
   for (int it = 0; it < ntiles; ++it) {
     const unsigned short* qimg = ldsh + (it & 1) * BUF;
     const unsigned short* gimg = qimg + IMG;
     const bool more = it + 1 < ntiles;
+    const f32x4 cl[2] = {nl[0], nl[1]}, cd[2] = {nd[0], nd[1]};
     if (more) {
       rq.fetch(Q, p.ldq, (it + 1) * KV, p.Tq);
       rg.fetch(DO, p.lddo, (it + 1) * KV, p.Tq);
+      fetch_stats(it + 1);
     }
     f32x4 pr[2], ds[2];
 #pragma unroll
@@ -1440,10 +1457,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
       for (int e = 0; e < 4; ++e) {
         const int qrow = it * KV + 16 * t + 4 * g + e;
         const bool qok = qrow < p.Tq;
-        const float L2 = qok ? lse[qrow] : 0.f, dl = qok ? dlt[qrow] : 0.f;
-        const float pe = qok ? ex2(s[e] - L2) : 0.f;
+        const float pe = qok ? ex2(s[e] - cl[t][e]) : 0.f;
         pr[t][e] = pe;
-        ds[t][e] = pe * (dp[e] - dl);
+        ds[t][e] = pe * (dp[e] - cd[t][e]);
       }
     }
     const bf16x8_t pb = pack8(pr[0], pr[1]), dsb = pack8(ds[0], ds[1]);

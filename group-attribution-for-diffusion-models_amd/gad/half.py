@@ -392,10 +392,23 @@ class HLoraLinearFn(torch.autograd.Function):
         if need_x:
             dx = linear_raw(dy2, half_weight_t(w), A2=dmid, B2=dht).view(shp)                 # dy W + dmid A
         dd = du = None
-        if ctx.needs_input_grad[3]:
-            dd = _param_grad32(down, dmid, x2)                                                # dmid^T x
-        if ctx.needs_input_grad[4]:
-            du = _param_grad32(up, dy2, mid)                                                  # dy^T mid
+        r, K = down.shape
+        if ctx.needs_input_grad[3] and ctx.needs_input_grad[4] and N * K <= 1.5 * r * (N + K):
+            # Wide ranks (the reference's r = 256 on 320-wide projections): the two LoRA gradients through the FULL-weight gradient
+            # G = dy^T x (fp32, [N][K]):  dB = s G A^T,  dA = s B^T G  - the same sums reassociated.  One contraction over the
+            # token axis instead of two (2 M N K against 2 M r (N + K) FLOPs), one operand transpose (dy; x's is shared by the
+            # projections of an attention) instead of three; the two [N x K x r] products that follow are small fp32 GEMMs.
+            G = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+            wgrad_raw(dy2, x2, G, accumulate=False)
+            du = _small_grad32(up, lambda o, acc: ops.gemm_raw(G, down.detach(), o, ops.A_KC, ops.B_KC, N, r, K, K, K, r, alpha=s,
+                                                             residual=(o if acc else None), ldr=r, force_f32=True))
+            dd = _small_grad32(down, lambda o, acc: ops.gemm_raw(up.detach(), G, o, ops.A_MC, ops.B_MC, r, K, N, r, K, K, alpha=s,
+                                                               residual=(o if acc else None), ldr=K, force_f32=True))
+        else:
+            if ctx.needs_input_grad[3]:
+                dd = _param_grad32(down, dmid, x2)                                            # dmid^T x
+            if ctx.needs_input_grad[4]:
+                du = _param_grad32(up, dy2, mid)                                              # dy^T mid
         dres = dy if (has_res and ctx.needs_input_grad[6]) else None
         return dx, None, None, dd, du, None, dres
 
@@ -408,6 +421,18 @@ def _param_grad32(param, dy2d, x2d):
         return None
     out = torch.empty(param.shape, device=dy2d.device, dtype=torch.float32)
     wgrad_raw(dy2d, x2d, out, accumulate=False)
+    return out
+
+
+def _small_grad32(param, launch):
+    """launch(out, accumulate) writes an fp32 gradient of param's shape: into the flat-buffer slot (first gradient of the step
+    overwrites, later ones add) or a fresh tensor handed back to autograd"""
+    v, first = ops._sink(param)
+    if v is not None:
+        launch(v, not first)
+        return None
+    out = torch.empty(param.shape, device=param.device, dtype=torch.float32)
+    launch(out, False)
     return out
 
 

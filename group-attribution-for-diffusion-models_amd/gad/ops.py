@@ -210,8 +210,9 @@ def _out(shape, device):
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False, wino_input=None):
-    """`wino_input(V)`: the caller supplies the F(4x4) Winograd input transform itself (GroupNorm writing V directly,
+             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False, wino_input=None, force_f32=False):
+    """`force_f32`: exact fp32 products whatever the process-wide operand precision (small parameter-gradient products).
+    `wino_input(V)`: the caller supplies the F(4x4) Winograd input transform itself (GroupNorm writing V directly,
     `gn_silu_conv3x3_raw`): if the planner puts this launch on an F(4x4) route the callback is run on the route's scratch and
     the convolution starts behind its input stage (-> True); on any other route nothing is launched (-> False)."""
     lib = _capi.load()
@@ -234,7 +235,7 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
     a.ldr = ldr
     a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
     a.tile_hint, a.splitk_hint = tile_hint, splitk_hint
-    a.operand_precision = 1 if OPERAND_PRECISION[0] else 0
+    a.operand_precision = 1 if (OPERAND_PRECISION[0] and not force_f32) else 0
     a.flags = KERNEL_FLAGS["gemm"]
     if A2 is not None:
         a.A2, a.a_split, a.ldx2 = A2.data_ptr(), a_split, A2.shape[-1]

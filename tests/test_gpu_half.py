@@ -312,6 +312,38 @@ def test_h_lora_linear_autograd(M, K, N, r):
     assert rel(dp.grad, dr.grad) < 6e-3 and rel(upp.grad, ur.grad) < 6e-3
 
 
+@pytest.mark.parametrize("r", [256, 24])
+def test_h_lora_gradients_into_flat_slots(r):
+    """FusedTrainer's route: the LoRA gradients land in the flat gradient buffer's slots (first use overwrites, a second use of
+    the same matrices adds) and equal what autograd receives without sinks - for the full-weight-gradient form (r = 256) and the
+    direct form (r = 24)."""
+    from gad import ops
+    from gad.training import flatten_params
+    M, K, N, s = 384, 320, 320, 0.5
+    x1, x2 = (rnd(M, K, seed=i).to(BF).to(dev) for i in (1, 2))
+    dy1, dy2 = (rnd(M, N, seed=i).to(BF).to(dev) for i in (3, 4))
+    w = torch.nn.Parameter(rnd(N, K, seed=5, scale=0.05).to(dev), requires_grad=False)
+
+    def fresh():
+        return torch.nn.Parameter(rnd(r, K, seed=6, scale=0.1).to(dev)), torch.nn.Parameter(rnd(N, r, seed=7, scale=0.1).to(dev))
+    down, up = fresh()
+    for xx, dd in ((x1, dy1), (x2, dy2)):
+        ops.lora_linear(xx.clone().requires_grad_(True), w, None, down, up, s, None).backward(dd)
+    want_d, want_u = down.grad.clone(), up.grad.clone()                      # autograd accumulated the two uses
+    down, up = fresh()
+    flat, gflat = flatten_params([down, up])
+    gflat.fill_(123.0)                                                        # stale values a first write must overwrite
+    ops.begin_backward_step()
+    try:
+        for xx, dd in ((x1, dy1), (x2, dy2)):
+            ops.lora_linear(xx.clone().requires_grad_(True), w, None, down, up, s, None).backward(dd)
+    finally:
+        ops.end_backward_step()
+    assert down.grad is None and up.grad is None
+    for got, want in ((down._gad_sink, want_d), (up._gad_sink, want_u)):
+        assert (got - want).abs().max() <= 1e-5 * want.abs().max() + 1e-6
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # the whole SD U-Net: bf16 activations vs the fp32 path
 # ---------------------------------------------------------------------------------------------------------------

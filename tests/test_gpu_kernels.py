@@ -854,7 +854,7 @@ def test_linear_and_attention_scores_bf16_operands(ops):
     want = _bf16_round(x) @ _bf16_round(w).T + b.double()
     with ops.operand_precision("bf16"):
         got = ops.linear_fwd_raw(x.to(dev), w.to(dev), b.to(dev))
-        assert ops.OPERAND_PRECISION[0] == 1
+        assert ops.OPERAND_PRECISION[0] >= 1          # ("bf16" selects half-precision activations where a model has them: mode 2; fp32 tensors take the bf16-operand kernels either way)
     assert ops.OPERAND_PRECISION[0] == 0
     close(got, want, rtol=1e-5, atol=2e-6 * 16)
     # K = 27 (conv_in) has no 16-B aligned float4 path: the flag is a permission, the launch stays fp32-exact
