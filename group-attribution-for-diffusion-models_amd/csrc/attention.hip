@@ -1313,7 +1313,9 @@ __global__ __launch_bounds__(NT) void attn_fwd_bf16_kernel(const AttnDev p) {
 // dQ, bf16 operands: workgroup = 64 queries, wave = 16; K and V tiles in ONE image type (row stride SV) read both along
 // rows (S^T = K Q^T, dP^T = V dO^T) and transposed (dQ^T += K^T dS^T).  Row reads past the head dim meet zero B
 // operands (the loop-invariant fragments are zero there), so whatever finite bf16 they pick up contributes nothing.
-template <int D, bool HIO = false>
+// NU: 16-row groups per wave (1 or 2).  With two, a wave's streamed-tile fragments (the LDS reads) serve twice the MFMA work and a
+// workgroup covers 128 rows: per-tile costs - barrier, tile copy, fragment reads - are paid half as often per FLOP.
+template <int D, bool HIO = false, int NU = 1>
 __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
   using C = CfgH<D>;
   using T = typename IoT<HIO>::type;
@@ -1323,16 +1325,22 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
   const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
   const T* K = reinterpret_cast<const T*>(p.k) + b * p.sk + h * D;
   const T* V = reinterpret_cast<const T*>(p.v) + b * p.sv + h * D;
-  const int row = blk * 64 + wave * 16 + c;
-  const bool rok = row < p.Tq;
-  bf16x8_t qf[C::KS], dof[C::KS];
-  row_frag_global_h<D>(reinterpret_cast<const T*>(p.q) + b * p.sq + h * D, p.ldq, row, rok, p.scale * LOG2E, qf);
-  row_frag_global_h<D>(reinterpret_cast<const T*>(p.d_o) + b * p.sdo + h * D, p.lddo, row, rok, 1.f, dof);
-  const float L2 = rok ? p.lse[(long)bh * p.Tq + row] : 0.f;
-  const float dl = rok ? p.delta[(long)bh * p.Tq + row] : 0.f;
-  f32x4 dq[C::NDV];
+  int row[NU];
+  bool rok[NU];
+  bf16x8_t qf[NU][C::KS], dof[NU][C::KS];
+  float L2[NU], dl[NU];
+  f32x4 dq[NU][C::NDV];
 #pragma unroll
-  for (int i = 0; i < C::NDV; ++i) dq[i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  for (int u = 0; u < NU; ++u) {
+    row[u] = blk * (64 * NU) + wave * (16 * NU) + 16 * u + c;
+    rok[u] = row[u] < p.Tq;
+    row_frag_global_h<D>(reinterpret_cast<const T*>(p.q) + b * p.sq + h * D, p.ldq, row[u], rok[u], p.scale * LOG2E, qf[u]);
+    row_frag_global_h<D>(reinterpret_cast<const T*>(p.d_o) + b * p.sdo + h * D, p.lddo, row[u], rok[u], 1.f, dof[u]);
+    L2[u] = rok[u] ? p.lse[(long)bh * p.Tq + row[u]] : 0.f;
+    dl[u] = rok[u] ? p.delta[(long)bh * p.Tq + row[u]] : 0.f;
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) dq[u][i] = f32x4{0.f, 0.f, 0.f, 0.f};
+  }
 
   zero_lds(ldsh, 2 * BUF + 64);
   __syncthreads();
@@ -1351,25 +1359,37 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
       rk.fetch(K, p.ldk, (it + 1) * KV, p.Tk);
       rv.fetch(V, p.ldv, (it + 1) * KV, p.Tk);
     }
-    f32x4 ds[2];
+    f32x4 ds[NU][2];
 #pragma unroll
     for (int kt = 0; kt < 2; ++kt) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8_t ka[C::KS], va[C::KS];
 #pragma unroll
-      for (int st = 0; st < C::KS; ++st) {
-        s = mfma16h(row_frag_h<C::SV>(kimg, 16 * kt, st), qf[st], s);
-        dp = mfma16h(row_frag_h<C::SV>(vimg, 16 * kt, st), dof[st], dp);
-      }
+      for (int st = 0; st < C::KS; ++st) { ka[st] = row_frag_h<C::SV>(kimg, 16 * kt, st); va[st] = row_frag_h<C::SV>(vimg, 16 * kt, st); }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
-        const float pe = kok ? ex2(s[e] - L2) : 0.f;
-        ds[kt][e] = pe * (dp[e] - dl);
+      for (int u = 0; u < NU; ++u) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) {
+          s = mfma16h(ka[st], qf[u][st], s);
+          dp = mfma16h(va[st], dof[u][st], dp);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const bool kok = it * KV + 16 * kt + 4 * g + e < p.Tk;
+          const float pe = kok ? ex2(s[e] - L2[u]) : 0.f;
+          ds[u][kt][e] = pe * (dp[e] - dl[u]);
+        }
       }
     }
-    const bf16x8_t dsb = pack8(ds[0], ds[1]);
+    bf16x8_t dsb[NU];
 #pragma unroll
-    for (int i = 0; i < C::NDV; ++i) dq[i] = mfma16h(col_frag_h<C::SV>(kimg, 0, 16 * i), dsb, dq[i]);
+    for (int u = 0; u < NU; ++u) dsb[u] = pack8(ds[u][0], ds[u][1]);
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) {
+      const bf16x8_t kc = col_frag_h<C::SV>(kimg, 0, 16 * i);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) dq[u][i] = mfma16h(kc, dsb[u], dq[u][i]);
+    }
     if (more) {
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
       rk.template commit<C::SV>(nb);
@@ -1377,19 +1397,21 @@ __global__ __launch_bounds__(NT) void attn_bwd_dq_bf16_kernel(const AttnDev p) {
     }
     __syncthreads();
   }
-  if (rok) {
-    T* DQ = reinterpret_cast<T*>(p.dq) + b * p.sdq + h * D + (long)row * p.lddq;
 #pragma unroll
-    for (int i = 0; i < C::NDV; ++i) {
-      const int kk = 16 * i + 4 * g;
-      if (kk < D) store4(DQ + kk, dq[i] * p.scale);
+  for (int u = 0; u < NU; ++u)
+    if (rok[u]) {
+      T* DQ = reinterpret_cast<T*>(p.dq) + b * p.sdq + h * D + (long)row[u] * p.lddq;
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        const int kk = 16 * i + 4 * g;
+        if (kk < D) store4(DQ + kk, dq[u][i] * p.scale);
+      }
     }
-  }
 }
 
-// dK / dV, bf16 operands: workgroup = 64 keys, wave = 16; Q and dO tiles in one image type, read along rows for
+// dK / dV, bf16 operands: workgroup = 64 NU keys, wave = 16 NU; Q and dO tiles in one image type, read along rows for
 // S = Q K^T and dP = dO V^T and transposed for dV^T += dO^T P and dK^T += Q^T dS.
-template <int D, bool HIO = false>
+template <int D, bool HIO = false, int NU = 1>
 __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) {
   using C = CfgH<D>;
   using T = typename IoT<HIO>::type;
@@ -1399,14 +1421,19 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
   const int bh = blockIdx.x / p.nblk, blk = blockIdx.x - bh * p.nblk, b = bh / p.heads, h = bh - b * p.heads;
   const T* Q = reinterpret_cast<const T*>(p.q) + b * p.sq + h * D;
   const T* DO = reinterpret_cast<const T*>(p.d_o) + b * p.sdo + h * D;
-  const int key = blk * 64 + wave * 16 + c;
-  const bool kok = key < p.Tk;
-  bf16x8_t kf[C::KS], vf[C::KS];
-  row_frag_global_h<D>(reinterpret_cast<const T*>(p.k) + b * p.sk + h * D, p.ldk, key, kok, p.scale * LOG2E, kf);
-  row_frag_global_h<D>(reinterpret_cast<const T*>(p.v) + b * p.sv + h * D, p.ldv, key, kok, 1.f, vf);
-  f32x4 dk[C::NDV], dv[C::NDV];
+  int key[NU];
+  bool kok[NU];
+  bf16x8_t kf[NU][C::KS], vf[NU][C::KS];
+  f32x4 dk[NU][C::NDV], dv[NU][C::NDV];
 #pragma unroll
-  for (int i = 0; i < C::NDV; ++i) { dk[i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  for (int u = 0; u < NU; ++u) {
+    key[u] = blk * (64 * NU) + wave * (16 * NU) + 16 * u + c;
+    kok[u] = key[u] < p.Tk;
+    row_frag_global_h<D>(reinterpret_cast<const T*>(p.k) + b * p.sk + h * D, p.ldk, key[u], kok[u], p.scale * LOG2E, kf[u]);
+    row_frag_global_h<D>(reinterpret_cast<const T*>(p.v) + b * p.sv + h * D, p.ldv, key[u], kok[u], 1.f, vf[u]);
+#pragma unroll
+    for (int i = 0; i < C::NDV; ++i) { dk[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; dv[u][i] = f32x4{0.f, 0.f, 0.f, 0.f}; }
+  }
   const float* lse = p.lse + (long)bh * p.Tq;
   const float* dlt = p.delta + (long)bh * p.Tq;
 
@@ -1419,54 +1446,56 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
   rg.template commit<C::SV>(ldsh + IMG);
   __syncthreads();
   const int ntiles = (p.Tq + KV - 1) / KV;
-  // the tile's log-sum-exp / delta rows (query row 16 t + 4 g + e of the tile), fetched one tile ahead like the tile itself: read at
-  // their point of use they were eight dependent global loads in front of every tile's exponentials
-  f32x4 nl[2], nd[2];
-  auto fetch_stats = [&](int tile) {
-#pragma unroll
-    for (int t = 0; t < 2; ++t)
-#pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int qrow = tile * KV + 16 * t + 4 * g + e;
-        const bool qok = qrow < p.Tq;
-        nl[t][e] = qok ? lse[qrow] : 0.f;
-        nd[t][e] = qok ? dlt[qrow] : 0.f;
-      }
-  };
-  fetch_stats(0);
   for (int it = 0; it < ntiles; ++it) {
     const unsigned short* qimg = ldsh + (it & 1) * BUF;
     const unsigned short* gimg = qimg + IMG;
     const bool more = it + 1 < ntiles;
-    const f32x4 cl[2] = {nl[0], nl[1]}, cd[2] = {nd[0], nd[1]};
     if (more) {
       rq.fetch(Q, p.ldq, (it + 1) * KV, p.Tq);
       rg.fetch(DO, p.lddo, (it + 1) * KV, p.Tq);
-      fetch_stats(it + 1);
     }
-    f32x4 pr[2], ds[2];
+    f32x4 pr[NU][2], ds[NU][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
-      f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+      bf16x8_t qa[C::KS], ga[C::KS];
 #pragma unroll
-      for (int st = 0; st < C::KS; ++st) {
-        s = mfma16h(row_frag_h<C::SV>(qimg, 16 * t, st), kf[st], s);
-        dp = mfma16h(row_frag_h<C::SV>(gimg, 16 * t, st), vf[st], dp);
+      for (int st = 0; st < C::KS; ++st) { qa[st] = row_frag_h<C::SV>(qimg, 16 * t, st); ga[st] = row_frag_h<C::SV>(gimg, 16 * t, st); }
+      float L2[4], dl[4];
+      bool qok[4];
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {       // (fetching these a tile ahead measured SLOWER: 901 vs 779 us at T = 4096)
+        const int qrow = it * KV + 16 * t + 4 * g + e;
+        qok[e] = qrow < p.Tq;
+        L2[e] = qok[e] ? lse[qrow] : 0.f;
+        dl[e] = qok[e] ? dlt[qrow] : 0.f;
       }
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {
-        const int qrow = it * KV + 16 * t + 4 * g + e;
-        const bool qok = qrow < p.Tq;
-        const float pe = qok ? ex2(s[e] - cl[t][e]) : 0.f;
-        pr[t][e] = pe;
-        ds[t][e] = pe * (dp[e] - cd[t][e]);
+      for (int u = 0; u < NU; ++u) {
+        f32x4 s = f32x4{0.f, 0.f, 0.f, 0.f}, dp = f32x4{0.f, 0.f, 0.f, 0.f};
+#pragma unroll
+        for (int st = 0; st < C::KS; ++st) {
+          s = mfma16h(qa[st], kf[u][st], s);
+          dp = mfma16h(ga[st], vf[u][st], dp);
+        }
+#pragma unroll
+        for (int e = 0; e < 4; ++e) {
+          const float pe = qok[e] ? ex2(s[e] - L2[e]) : 0.f;
+          pr[u][t][e] = pe;
+          ds[u][t][e] = pe * (dp[e] - dl[e]);
+        }
       }
     }
-    const bf16x8_t pb = pack8(pr[0], pr[1]), dsb = pack8(ds[0], ds[1]);
+    bf16x8_t pb[NU], dsb[NU];
+#pragma unroll
+    for (int u = 0; u < NU; ++u) { pb[u] = pack8(pr[u][0], pr[u][1]); dsb[u] = pack8(ds[u][0], ds[u][1]); }
 #pragma unroll
     for (int i = 0; i < C::NDV; ++i) {
-      dv[i] = mfma16h(col_frag_h<C::SV>(gimg, 0, 16 * i), pb, dv[i]);
-      dk[i] = mfma16h(col_frag_h<C::SV>(qimg, 0, 16 * i), dsb, dk[i]);
+      const bf16x8_t gc = col_frag_h<C::SV>(gimg, 0, 16 * i), qc = col_frag_h<C::SV>(qimg, 0, 16 * i);
+#pragma unroll
+      for (int u = 0; u < NU; ++u) {
+        dv[u][i] = mfma16h(gc, pb[u], dv[u][i]);
+        dk[u][i] = mfma16h(qc, dsb[u], dk[u][i]);
+      }
     }
     if (more) {
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
@@ -1475,18 +1504,20 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
     }
     __syncthreads();
   }
-  if (kok) {
-    T* DK = reinterpret_cast<T*>(p.dk) + b * p.sdk + h * D + (long)key * p.lddk;
-    T* DV = reinterpret_cast<T*>(p.dv) + b * p.sdv + h * D + (long)key * p.lddv;
 #pragma unroll
-    for (int i = 0; i < C::NDV; ++i) {
-      const int kk = 16 * i + 4 * g;
-      if (kk < D) {
-        store4(DK + kk, dk[i] * p.scale);
-        store4(DV + kk, dv[i]);
+  for (int u = 0; u < NU; ++u)
+    if (kok[u]) {
+      T* DK = reinterpret_cast<T*>(p.dk) + b * p.sdk + h * D + (long)key[u] * p.lddk;
+      T* DV = reinterpret_cast<T*>(p.dv) + b * p.sdv + h * D + (long)key[u] * p.lddv;
+#pragma unroll
+      for (int i = 0; i < C::NDV; ++i) {
+        const int kk = 16 * i + 4 * g;
+        if (kk < D) {
+          store4(DK + kk, dk[u][i] * p.scale);
+          store4(DV + kk, dv[u][i]);
+        }
       }
     }
-  }
 }
 
 // Kernels that want more than 64 KiB of dynamic LDS need the attribute once per kernel instance and device - not per
@@ -1723,10 +1754,32 @@ static int launch_bwd_hio(AttnDev d, float* delta, hipStream_t st) {
       set_lds(attn_bwd_dkv_bf16_kernel<D, true>, bytes, "gad_h_attention_bwd", &lds_set_kv)) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
   hipLaunchKernelGGL((attn_delta_h_kernel<D>), dim3((unsigned)gad_ceil_div(total, 256)), dim3(256), 0, st, d, delta);
-  dim3 grid = grid_of(d, d.Tq, 64);
-  hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
-  grid = grid_of(d, d.Tk, 64);
-  hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
+  // 32 rows per wave (128 per workgroup) while the grid still fills the chip twice over (head dims up to 64: three waves per SIMD still fit)
+  bool two_q = false, two_k = false;
+  if constexpr (D <= 64) {
+    two_q = gad_ceil_div(d.Tq, 128) * d.B * d.heads >= 512;
+    two_k = gad_ceil_div(d.Tk, 128) * d.B * d.heads >= 512;
+  }
+  if constexpr (D <= 64) {
+    if (two_q) {
+      const dim3 grid = grid_of(d, d.Tq, 128);
+      hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D, true, 2>), grid, dim3(NT), bytes, st, d);
+    }
+  }
+  if (!two_q) {
+    const dim3 grid = grid_of(d, d.Tq, 64);
+    hipLaunchKernelGGL((attn_bwd_dq_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
+  }
+  if constexpr (D <= 64) {
+    if (two_k) {
+      const dim3 grid = grid_of(d, d.Tk, 128);
+      hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D, true, 2>), grid, dim3(NT), bytes, st, d);
+    }
+  }
+  if (!two_k) {
+    const dim3 grid = grid_of(d, d.Tk, 64);
+    hipLaunchKernelGGL((attn_bwd_dkv_bf16_kernel<D, true>), grid, dim3(NT), bytes, st, d);
+  }
   return 0;
 }
 template <int D>

@@ -245,7 +245,7 @@ def test_h_geglu_fwd_bwd():
 
 
 @pytest.mark.parametrize("B,Tq,Tk,heads,d", [(2, 256, 256, 8, 40), (2, 64, 77, 4, 40), (1, 200, 200, 5, 64), (2, 64, 64, 8, 160), (2, 128, 77, 4, 16),
-                                             (1, 1024, 1024, 2, 80)])
+                                             (1, 1024, 1024, 2, 80), (8, 1024, 1024, 8, 40), (8, 1000, 1000, 8, 40)])   # (the last two: 32 rows per wave in the backward)
 def test_h_attention_fwd_bwd(B, Tq, Tk, heads, d):
     """bf16 q / k / v / dO in, bf16 o / dq / dk / dv out; the products run on bf16-rounded probabilities, so the comparison with
     an fp64 evaluation of the same inputs carries the operand rounding of P and dS (2^-8 relative per product term)."""
