@@ -384,6 +384,7 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
     summ = prof.summary()
     kern = {f"{k[0]}_t{k[1]}_sk{k[2]}_v{k[3]}": dict(launches=v["launches"], avg_us=v["ms"] / v["launches"] * 1e3,
                                                    tflops=v["executed"] / v["ms"] / 1e9, frac=v["executed"] / v["ms"] / 1e9 / peak_tf,
+                                                   algorithmic_bytes_per_launch=v["bytes"] / v["launches"],
                                                    **({"tflops_algorithmic": v["flops"] / v["ms"] / 1e9} if v["executed"] != v["flops"] else {}))
             for k, v in summ.items()}
     dom_key = max(summ, key=lambda k: summ[k]["ms"])
