@@ -34,6 +34,8 @@ def _reqh(t, name):
 
 
 def _empty(shape, device, dtype=BF16):
+    if ops.OUT_ALLOC_DT is not None:             # out-of-bounds canaries (tests/test_gpu_half.py): outputs between poisoned bands
+        return ops.OUT_ALLOC_DT(tuple(shape), device, dtype)
     return torch.empty(tuple(shape), device=device, dtype=dtype)
 
 
@@ -86,7 +88,9 @@ def transpose_raw(x2d):
     if x2d.stride(1) != 1:
         raise _capi.GadError("transpose_raw: columns must be contiguous")
     R8 = (R + 7) // 8 * 8
-    y = _empty((Cc, R8), x2d.device) if R8 == R else torch.zeros((Cc, R8), device=x2d.device, dtype=BF16)
+    y = _empty((Cc, R8), x2d.device)
+    if R8 != R:
+        y.zero_()
     check(_capi.load().gad_h_transpose(x2d.data_ptr(), y.data_ptr(), R, Cc, x2d.stride(0), R8, int(x2d.dtype == torch.float32), _st()),
           "gad_h_transpose")
     return y
@@ -398,7 +402,7 @@ class HLoraLinearFn(torch.autograd.Function):
             # G = dy^T x (fp32, [N][K]):  dB = s G A^T,  dA = s B^T G  - the same sums reassociated.  One contraction over the
             # token axis instead of two (2 M N K against 2 M r (N + K) FLOPs), one operand transpose (dy; x's is shared by the
             # projections of an attention) instead of three; the two [N x K x r] products that follow are small fp32 GEMMs.
-            G = torch.empty((N, K), device=dy2.device, dtype=torch.float32)
+            G = _empty((N, K), dy2.device, torch.float32)
             wgrad_raw(dy2, x2, G, accumulate=False)
             du = _small_grad32(up, lambda o, acc: ops.gemm_raw(G, down.detach(), o, ops.A_KC, ops.B_KC, N, r, K, K, K, r, alpha=s,
                                                              residual=(o if acc else None), ldr=r, force_f32=True))
@@ -419,7 +423,7 @@ def _param_grad32(param, dy2d, x2d):
     if v is not None:
         wgrad_raw(dy2d, x2d, v.view(param.shape), accumulate=not first)
         return None
-    out = torch.empty(param.shape, device=dy2d.device, dtype=torch.float32)
+    out = _empty(param.shape, dy2d.device, torch.float32)
     wgrad_raw(dy2d, x2d, out, accumulate=False)
     return out
 
@@ -431,7 +435,7 @@ def _small_grad32(param, launch):
     if v is not None:
         launch(v, not first)
         return None
-    out = torch.empty(param.shape, device=param.device, dtype=torch.float32)
+    out = _empty(param.shape, param.device, torch.float32)
     launch(out, False)
     return out
 
@@ -458,8 +462,8 @@ def group_norm_raw(x, x2, gamma, beta, G, eps, silu):
     _reqh(x, "half groupnorm x")
     C_ = x.shape[-1] + (x2.shape[-1] if x2 is not None else 0)
     y = _empty((*x.shape[:-1], C_), x.device)
-    mean = torch.empty((x.shape[0], G), device=x.device, dtype=torch.float32)
-    rstd = torch.empty_like(mean)
+    mean = _empty((x.shape[0], G), x.device, torch.float32)
+    rstd = _empty((x.shape[0], G), x.device, torch.float32)
     a = _gn_args(x, x2, y, gamma, beta, mean, rstd, G, eps, silu)
     check(_capi.load().gad_h_groupnorm_silu_fwd(C.byref(a), _st()), "gad_h_groupnorm_silu_fwd")
     return y, mean, rstd
@@ -483,7 +487,7 @@ class HGroupNormFn(torch.autograd.Function):
         x, mean, rstd = ctx.saved_tensors
         gamma, beta, G, eps, silu = ctx.cfg
         dy = dy.contiguous()
-        dx = torch.empty_like(x)
+        dx = _empty(x.shape, x.device)
         a = _gn_args(x, None, dx, gamma, beta, mean, rstd, G, eps, silu)
         a.dy = dy.data_ptr()
         if dbypass is not None:
@@ -499,9 +503,9 @@ class HLayerNormFn(torch.autograd.Function):
         _frozen(gamma, beta)
         C_ = x.shape[-1]
         rows = x.numel() // C_
-        y = torch.empty_like(x)
-        mean = torch.empty(rows, device=x.device, dtype=torch.float32)
-        rstd = torch.empty_like(mean)
+        y = _empty(x.shape, x.device)
+        mean = _empty((rows,), x.device, torch.float32)
+        rstd = _empty((rows,), x.device, torch.float32)
         check(_capi.load().gad_h_layernorm_fwd(x.data_ptr(), y.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(),
                                                rstd.data_ptr(), rows, C_, eps, _st()), "gad_h_layernorm_fwd")
         ctx.save_for_backward(x, mean, rstd)
@@ -517,7 +521,7 @@ class HLayerNormFn(torch.autograd.Function):
         x, mean, rstd = ctx.saved_tensors
         dy = dy.contiguous()
         C_ = x.shape[-1]
-        dx = torch.empty_like(x)
+        dx = _empty(x.shape, x.device)
         add = _reqh(dbypass.contiguous(), "half layernorm bypass gradient") if dbypass is not None else None
         check(_capi.load().gad_h_layernorm_bwd(x.data_ptr(), dy.data_ptr(), dx.data_ptr(), add.data_ptr() if add is not None else None,
                                                ctx.gamma.data_ptr(), mean.data_ptr(), rstd.data_ptr(), x.numel() // C_, C_, _st()),
@@ -540,7 +544,7 @@ class HGegluFn(torch.autograd.Function):
         (h,) = ctx.saved_tensors
         dout = dout.contiguous()
         F2 = h.shape[-1]
-        dh = torch.empty_like(h)
+        dh = _empty(h.shape, h.device)
         check(_capi.load().gad_h_geglu_bwd(h.data_ptr(), dout.data_ptr(), dh.data_ptr(), h.numel() // F2, F2 // 2, _st()), "gad_h_geglu_bwd")
         return dh
 
@@ -569,7 +573,7 @@ class HAttentionFn(torch.autograd.Function):
         Bn, Tq, Cq = q.shape
         Tk, d = k.shape[1], Cq // heads
         o = _empty((Bn, Tq, Cq), q.device)
-        lse = torch.empty((Bn, heads, Tq), device=q.device, dtype=torch.float32)
+        lse = _empty((Bn, heads, Tq), q.device, torch.float32)
         a = _attn_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, scale)
         fn = _capi.load().gad_h_attention_fwd
         if ops.PROFILER is not None:
@@ -587,8 +591,8 @@ class HAttentionFn(torch.autograd.Function):
         do = do.contiguous()
         Bn, Tq, Cq = q.shape
         Tk, d = k.shape[1], Cq // heads
-        dq, dk, dv = torch.empty_like(q), torch.empty_like(k), torch.empty_like(v)
-        delta = torch.empty_like(lse)
+        dq, dk, dv = _empty(q.shape, q.device), _empty(k.shape, k.device), _empty(v.shape, v.device)
+        delta = _empty(lse.shape, lse.device, torch.float32)
         a = _attn_args(q, k, v, o, lse, Bn, heads, Tq, Tk, d, ctx.scale)
         a.d_o, a.delta, a.dq, a.dk, a.dv = do.data_ptr(), delta.data_ptr(), dq.data_ptr(), dk.data_ptr(), dv.data_ptr()
         a.ld_do = a.ld_dq = a.ld_dk = a.ld_dv = Cq

@@ -193,6 +193,7 @@ class kernel_flags:
 # provides output tensors.  The tests hand out views between poisoned guard bands and check the bands afterwards.
 SCRATCH_ALLOC = None
 OUT_ALLOC = None
+OUT_ALLOC_DT = None          # the same for the half path's outputs: (shape, device, dtype) -> tensor (gad/half.py::_empty)
 
 
 def _scratch(kind, nbytes, device):

@@ -245,7 +245,7 @@ def test_h_geglu_fwd_bwd():
 
 
 @pytest.mark.parametrize("B,Tq,Tk,heads,d", [(2, 256, 256, 8, 40), (2, 64, 77, 4, 40), (1, 200, 200, 5, 64), (2, 64, 64, 8, 160), (2, 128, 77, 4, 16),
-                                             (1, 1024, 1024, 2, 80), (8, 1024, 1024, 8, 40), (8, 1000, 1000, 8, 40)])   # (the last two: 32 rows per wave in the backward)
+                                             (1, 1024, 1024, 2, 80), (8, 1024, 1024, 8, 40), (8, 1000, 1000, 8, 40), (16, 1024, 1024, 8, 40), (8, 1024, 1024, 8, 80)])   # (32 rows per wave in the backward; 64 queries per wave forward; d = 80 with 32 rows)
 def test_h_attention_fwd_bwd(B, Tq, Tk, heads, d):
     """bf16 q / k / v / dO in, bf16 o / dq / dk / dv out; the products run on bf16-rounded probabilities, so the comparison with
     an fp64 evaluation of the same inputs carries the operand rounding of P and dS (2^-8 relative per product term)."""
@@ -379,3 +379,132 @@ def test_sd_unet_half_activations_vs_fp32():
         a, b = g16[n].double().flatten(), g32[n].double().flatten()
         if b.norm() > 1e-3 * math.sqrt(den / len(g32)):
             assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.97, n
+
+
+# ---------------------------------------------------------------------------------------------------------------
+# out-of-bounds canaries (as tests/test_gpu_guards.py does for the fp32-storage kernels): every output of the half path at its exact
+# shape and every caller-owned scratch region at EXACTLY the size the C ABI's query returns, each between poisoned bands
+# ---------------------------------------------------------------------------------------------------------------
+PAD, POISON = 8192, 0x5A
+
+
+class HGuards:
+    def __init__(self):
+        self.regions = []
+
+    def _alloc(self, kind, nbytes, device):
+        buf = torch.full((nbytes + 2 * PAD,), POISON, dtype=torch.uint8, device=device)
+        self.regions.append((kind, buf, nbytes))
+        return buf[PAD:PAD + nbytes]
+
+    def scratch(self, kind, nbytes, device):
+        return self._alloc(kind, nbytes, device)
+
+    def out(self, shape, device, dtype):
+        n = math.prod(shape) * torch.empty((), dtype=dtype).element_size()
+        return self._alloc(f"out{tuple(shape)}", n, device).view(dtype).view(shape)
+
+    def check(self):
+        assert self.regions, "no guarded allocation was made"
+        for kind, buf, n in self.regions:
+            lo, hi = buf[:PAD], buf[PAD + n:]
+            assert bool((lo == POISON).all()) and bool((hi == POISON).all()), \
+                f"guard band of {kind} ({n} bytes) was written ({int((lo != POISON).sum())} bytes below, {int((hi != POISON).sum())} above)"
+
+
+def hguarded(fn):
+    from gad import ops
+    g = HGuards()
+    ops.SCRATCH_ALLOC, ops.OUT_ALLOC_DT = g.scratch, g.out
+    try:
+        r = fn()
+        torch.cuda.synchronize()
+    finally:
+        ops.SCRATCH_ALLOC = ops.OUT_ALLOC_DT = None
+    g.check()
+    return r, g
+
+
+@pytest.mark.parametrize("M,N,K,tile,sk", [(130, 72, 40, 0, 0), (300, 320, 328, 2, 0), (300, 320, 328, 5, 0), (257, 640, 1288, 5, 3), (129, 321, 72, 1, 2),
+                                           (1000, 256, 320, 0, 0), (64, 4, 2880, 0, 0), (513, 960, 64, 2, 0)])
+def test_hgemm_guard_bands(M, N, K, tile, sk):
+    from gad import half
+    a, b = rnd(M, K, seed=1).to(BF).to(dev), rnd(N, K, seed=2).to(BF).to(dev)
+    res = rnd(M, N, seed=3).to(BF).to(dev)
+
+    def run():
+        out = half._empty((M, N), dev)
+        half.hgemm_raw(a, b, out, M, N, K, K, K, N, residual=res, ldr=N, tile_hint=tile, splitk_hint=sk)
+        o32 = half._empty((M, N), dev, torch.float32)
+        half.hgemm_raw(a, b, o32, M, N, K, K, K, N, out_f32=True, tile_hint=tile, splitk_hint=sk)
+        return out, o32
+    (g_out, g_32), g = hguarded(run)
+    out, o32 = run()
+    assert torch.equal(g_out, out) and torch.equal(g_32, o32)
+    if sk > 1:
+        assert any(k == "ws" for k, _, _ in g.regions)
+
+
+@pytest.mark.parametrize("B,H,W,Cin,Cout,k,stride,pad,ups", CONVS[:5] + CONVS[6:])
+def test_hconv_autograd_guard_bands(B, H, W, Cin, Cout, k, stride, pad, ups):
+    from gad import ops
+    x = _nhwc(rnd(B, Cin, H, W, seed=1)).to(BF).to(dev)
+    wp = torch.nn.Parameter(rnd(Cout, Cin, k, k, seed=2, scale=0.05).to(dev).contiguous(memory_format=torch.channels_last), requires_grad=False)
+    Ho = ((2 * H if ups else H) + 2 * pad - k) // stride + 1
+    dy = rnd(B, Ho, Ho if H == W else ((2 * W if ups else W) + 2 * pad - k) // stride + 1, Cout, seed=3).to(BF).to(dev)
+
+    def run():
+        xg = x.clone().requires_grad_(True)
+        y = ops.conv2d(xg, wp, None, None, None, stride, (pad,) * 4, ups)
+        y.backward(dy)
+        return y.detach(), xg.grad
+    (gy, gdx), _ = hguarded(run)
+    y, dx = run()
+    assert torch.equal(gy, y) and torch.equal(gdx, dx)
+
+
+def test_half_block_ops_guard_bands():
+    """GroupNorm (+ bypass), LayerNorm, GEGLU, the LoRA linear (both gradient forms) and ragged attention, forward + backward"""
+    from gad import ops
+
+    def P(t, grad=False):
+        return torch.nn.Parameter(t.to(dev), requires_grad=grad)
+    x = rnd(2, 100, 320, seed=1).to(BF).to(dev)
+    dy = rnd(2, 100, 320, seed=2).to(BF).to(dev)
+    gam, bet = P(rnd(320, seed=3) * 0.1 + 1), P(rnd(320, seed=4) * 0.1)
+    w = P(rnd(320, 320, seed=5, scale=0.05))
+    h4 = rnd(200, 2 * 320, seed=6).to(BF).to(dev)
+    q, k, v = (rnd(2, 200, 160, seed=i, scale=0.5).to(BF).to(dev) for i in (7, 8, 9))
+    kc, vc = (rnd(2, 77, 160, seed=i, scale=0.5).to(BF).to(dev) for i in (10, 11))
+
+    def run():
+        outs = []
+        for silu in (True, False):
+            xg = x.clone().requires_grad_(True)
+            o, al = ops.group_norm_bypass(xg, gam, bet, 32, 1e-5, silu)
+            torch.autograd.backward([o, al], [dy, dy])
+            outs += [o.detach(), xg.grad]
+        xg = x.clone().requires_grad_(True)
+        o, al = ops.layer_norm_bypass(xg, gam, bet, 1e-5)
+        torch.autograd.backward([o, al], [dy, dy])
+        outs += [o.detach(), xg.grad]
+        hg = h4.clone().requires_grad_(True)
+        o = ops.geglu(hg)
+        o.backward(dy.view(200, 320))
+        outs += [o.detach(), hg.grad]
+        for r in (256, 12):
+            down, up = P(rnd(r, 320, seed=12, scale=0.1), True), P(rnd(320, r, seed=13, scale=0.1), True)
+            xg = x.view(200, 320).clone().requires_grad_(True)
+            o = ops.lora_linear(xg, w, None, down, up, 0.5, None)
+            o.backward(dy.view(200, 320))
+            outs += [o.detach(), xg.grad, down.grad, up.grad]
+        for kk, vv in ((k, v), (kc, vc)):
+            gq, gk, gv = (t.clone().requires_grad_(True) for t in (q, kk, vv))
+            o = ops.attention_core(gq, gk, gv, 4)
+            o.backward(q)
+            outs += [o.detach(), gq.grad, gk.grad, gv.grad]
+        return outs
+    got, g = hguarded(run)
+    want = run()
+    assert len(got) == len(want) and all(torch.equal(a, b) for a, b in zip(got, want))
+    assert any(k == "ws" for k, _, _ in g.regions)
