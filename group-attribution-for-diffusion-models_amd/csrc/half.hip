@@ -363,6 +363,119 @@ __global__ __launch_bounds__(WM* WN * 64, (NST == 2 || WM * WN == 8) ? 2 : 1) vo
 }
 
 
+// ---------------------------------------------------------------------------------------------------------------
+// hgemm_tn_kernel: C[m][n] = sum_k A[k][m] B[k][n] - both operands stored with the CONTRACTION index as their row (activations
+// [tokens][channels]): the LoRA parameter gradients dB = dy^T mid, dA = dmid^T x, G = dy^T x read in place, no transposed copies.
+// An MFMA operand wants 8 consecutive k per lane; from a [k][column] image that is a transposing LDS read: ds_read_tr16_b64 hands
+// each lane of a 16-lane group one column of a 4-row x 16-column block, so two of them make the 8-deep fragment of
+// v_mfma_f32_16x16x32_bf16 (k slots (g, j < 4) -> row 4 g + j, (g, j >= 4) -> row 16 + 4 g + j - 4 for BOTH operands: the contraction
+// order is permuted identically on the two sides).  Images are [32 k][128 columns] (256-byte rows, lane-linear for the LDS-DMA) with
+// the 16-byte chunk index XOR-ed by (k & 7) << 1 on the DMA's source and on the read: the eight rows a 32-lane half touches then
+// fall in eight different 32-byte slots of the bank row.  128 x 128 outputs per workgroup (4 waves x 4 x 4 tiles of 16 x 16),
+// two stage buffers, fp32 output (direct, accumulating, or split-K slabs reduced by hgemm_reduce_kernel).
+// ---------------------------------------------------------------------------------------------------------------
+typedef short s16x4 __attribute__((ext_vector_type(4)));
+typedef short s16x8 __attribute__((ext_vector_type(8)));
+__device__ __forceinline__ bf16x8 tn_frag(const unsigned char* img, int c0) {      // columns c0 .. c0 + 15 of a [32][128] image, 32 k
+  const int lane = threadIdx.x & 63, g = lane >> 4, q = (lane & 15) >> 2, pp = lane & 3;
+  const int row = 4 * g + q;                                                          // (row + 16 has the same low three bits)
+  const int chunk = ((c0 >> 3) + (pp >> 1)) ^ ((row & 7) << 1);
+  const unsigned char* a0 = img + row * 256 + chunk * 16 + (pp & 1) * 8;
+  const s16x4 lo = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)a0);
+  const s16x4 hi = __builtin_amdgcn_ds_read_tr16_b64_v4i16((__attribute__((address_space(3))) s16x4*)(a0 + 16 * 256));
+  const s16x8 both = {lo[0], lo[1], lo[2], lo[3], hi[0], hi[1], hi[2], hi[3]};
+  return __builtin_bit_cast(bf16x8, both);
+}
+__global__ __launch_bounds__(256, 2) void hgemm_tn_kernel(const HDev p) {           // p.len1 = K (rows of A and B); p.M x p.N outputs
+  constexpr int IMG = 32 * 256, STAGE = 2 * IMG;
+  __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
+  const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
+  const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
+  const int row0 = tile_m * 128, col0 = tile_n * 128;
+  const int z = blockIdx.y;
+  const int tid = threadIdx.x, lane = tid & 63;
+  const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
+  const int wm = wave >> 1, wn = wave & 1;
+  // DMA: instruction ii (0 .. 7 per operand) covers image rows 4 ii .. 4 ii + 3; wave w issues ii = w and w + 4 of both operands
+  const int dr = lane >> 4, pos = lane & 15;
+  int ka[2], offa[2], offb[2];
+  bool oka[2], okb[2];
+#pragma unroll
+  for (int i = 0; i < 2; ++i) {
+    const int kr = (wave + 4 * i) * 4 + dr;                   // image row = k within the step
+    const int ch = (pos ^ ((kr & 7) << 1)) * 8;               // source chunk (elements)
+    ka[i] = kr;
+    oka[i] = row0 + ch < p.M;
+    okb[i] = col0 + ch < p.N;
+    offa[i] = kr * p.lda + row0 + ch;
+    offb[i] = kr * p.ldb + col0 + ch;
+  }
+  const u16* const zero = p.zero;
+  const int t0 = z * p.steps_per_split, t1 = min(p.steps, t0 + p.steps_per_split);
+  auto stage = [&](int step, int buf) {
+    const int k0 = step * 32;
+    unsigned char* dst = lds + buf * STAGE;
+#pragma unroll
+    for (int i = 0; i < 2; ++i) {
+      const bool kin = k0 + ka[i] < p.len1 && !p.dbg_zero;
+      const u16* sa = (kin && oka[i]) ? p.A + ((long)k0 * p.lda + offa[i]) : zero;
+      const u16* sb = (kin && okb[i]) ? p.B + ((long)k0 * p.ldb + offb[i]) : zero;
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
+                                       (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+      __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
+                                       (__attribute__((address_space(3))) void*)(dst + IMG + (wave + 4 * i) * 1024), 16, 0, 0);
+    }
+  };
+  f32x4 acc[4][4];
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) acc[i][j] = f32x4{0.f, 0.f, 0.f, 0.f};
+  if (t0 < t1) {
+    stage(t0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+  for (int st = t0; st < t1; ++st) {
+    const int buf = (st - t0) & 1;
+    if (st + 1 < t1) stage(st + 1, buf ^ 1);
+    const unsigned char* ia = lds + buf * STAGE;
+    const unsigned char* ib = ia + IMG;
+    bf16x8 af[4], bfr[4];
+#pragma unroll
+    for (int i = 0; i < 4; ++i) af[i] = tn_frag(ia, wm * 64 + 16 * i);
+#pragma unroll
+    for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(ib, wn * 64 + 16 * j);
+#pragma unroll
+    for (int i = 0; i < 4; ++i)
+#pragma unroll
+      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    __builtin_amdgcn_s_waitcnt(0x0F70);
+    __syncthreads();
+  }
+  // C / D of the 16 x 16 MFMA: column = lane & 15, rows 4 (lane >> 4) + register
+  float* slab = p.splitk > 1 ? p.ws + (long)z * p.M * p.N : nullptr;
+  const int c = lane & 15, g = lane >> 4;
+#pragma unroll
+  for (int i = 0; i < 4; ++i)
+#pragma unroll
+    for (int j = 0; j < 4; ++j) {
+      const int n = col0 + wn * 64 + 16 * j + c;
+#pragma unroll
+      for (int e = 0; e < 4; ++e) {
+        const int m = row0 + wm * 64 + 16 * i + 4 * g + e;
+        if (m < p.M && n < p.N) {
+          if (slab) slab[(long)m * p.N + n] = acc[i][j][e];
+          else {
+            float* cd = reinterpret_cast<float*>(p.C) + (long)m * p.ldc + n;
+            const float v = acc[i][j][e] * p.alpha;
+            *cd = p.accumulate ? *cd + v : v;
+          }
+        }
+      }
+    }
+}
+
 // split-K: sum the slabs in a fixed order and run the epilogue (8 columns per thread where the operands allow 16-byte vectors)
 __global__ __launch_bounds__(256) void hgemm_reduce_kernel(const HDev p) {
   const long total = (long)p.M * p.N;
@@ -640,8 +753,9 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const u16* __restrict__ x, 
 }
 
 // ---------------------------------------------------------------------------------------------------------------
-// GroupNorm (+ SiLU), NHWC bf16.  Three launches: per-channel partial sums over row chunks | per-(image, group) statistics |
-// apply.  A thread owns ONE channel octet (blockDim = NO * RP with NO = C / 8 octets, RP row phases), so its per-channel
+// GroupNorm (+ SiLU), NHWC bf16.  Two launches: per-(image, row chunk, group) partial sums | apply, whose prologue reduces the
+// chunks' partials to the image's statistics in LDS (every workgroup of an image does the same few KB of L2 reads: cheaper than a
+// third launch).  A thread owns ONE channel octet (blockDim = NO * RP with NO = C / 8 octets, RP row phases), so its per-channel
 // coefficients are loop invariants and every access is a 16-B vector.
 //   forward  partials: (sum x, sum x^2)            statistics: mean, rstd
 //   backward partials: (sum g, sum g xhat), g = dy silu'(pre) gamma     statistics: s1 / n, s2 / n   (dx = rstd (g - s1/n - xhat s2/n))
@@ -649,8 +763,7 @@ __global__ __launch_bounds__(256) void ln_bwd_kernel(const u16* __restrict__ x, 
 struct GnDev {
   const u16* x; const u16* x2; int C1; const u16* dy; const u16* dx_add; u16* y;
   const float* gamma; const float* beta; float* mean; float* rstd;
-  float* part;              // [B][chunks][C][2]
-  float* gsum;              // backward: [B][G][2]
+  float* part;              // [B][chunks][G][2]
   int B, HW, C, G, silu, chunks, rows_per_chunk, NO, RP;
   float eps;
 };
@@ -710,46 +823,53 @@ __global__ void gn_part_kernel(const GnDev p) {
 #pragma unroll
       for (int k = 0; k < 8; ++k) { a0[k] += other[k]; a1[k] += other[8 + k]; }
     }
-    float* dst = p.part + (((long)b * p.chunks + chunk) * p.C + o * 8) * 2;
+  }
+  __syncthreads();                       // every row phase's partials are read: the array is reused as [C][2] channel sums
+  if (rp == 0) {
 #pragma unroll
-    for (int k = 0; k < 8; ++k) { dst[2 * k] = a0[k]; dst[2 * k + 1] = a1[k]; }
+    for (int k = 0; k < 8; ++k) { red[(o * 8 + k) * 2] = a0[k]; red[(o * 8 + k) * 2 + 1] = a1[k]; }
   }
-}
-template <bool BWD>
-__global__ void gn_final_kernel(const GnDev p) {
-  const int bg = blockIdx.x, b = bg / p.G, g = bg - b * p.G, cpg = p.C / p.G;
-  float s0 = 0.f, s1 = 0.f;
-  for (int i = threadIdx.x; i < p.chunks * cpg; i += 64) {
-    const int ch = i / cpg, c = g * cpg + (i - ch * cpg);
-    const float* src = p.part + (((long)b * p.chunks + ch) * p.C + c) * 2;
-    s0 += src[0];
-    s1 += src[1];
-  }
-  s0 = wave_sum(s0);
-  s1 = wave_sum(s1);
-  if (threadIdx.x == 0) {
-    const float n = (float)p.HW * cpg;
-    if (!BWD) {
-      const float mu = s0 / n, var = fmaxf(s1 / n - mu * mu, 0.f);
-      p.mean[bg] = mu;
-      p.rstd[bg] = rsqrtf(var + p.eps);
-    } else {
-      p.gsum[2 * bg] = s0 / n;
-      p.gsum[2 * bg + 1] = s1 / n;
-    }
+  __syncthreads();
+  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int c = g * cpg; c < (g + 1) * cpg; ++c) { s0 += red[2 * c]; s1 += red[2 * c + 1]; }
+    float* dst = p.part + (((long)b * p.chunks + chunk) * p.G + g) * 2;
+    dst[0] = s0;
+    dst[1] = s1;
   }
 }
 template <bool BWD>
 __global__ void gn_apply_kernel(const GnDev p) {
+  extern __shared__ float stat[];         // [G][2]: forward (mean, rstd); backward (sum g / n, sum g xhat / n)
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int o = threadIdx.x % p.NO, rp = threadIdx.x / p.NO;
   const int cpg = p.C / p.G;
+  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int ch = 0; ch < p.chunks; ++ch) {                  // fixed order: every workgroup of the image gets the same bits
+      const float* src = p.part + (((long)b * p.chunks + ch) * p.G + g) * 2;
+      s0 += src[0];
+      s1 += src[1];
+    }
+    const float n = (float)p.HW * cpg;
+    if (!BWD) {
+      const float mu = s0 / n, var = fmaxf(s1 / n - mu * mu, 0.f), rs = rsqrtf(var + p.eps);
+      stat[2 * g] = mu;
+      stat[2 * g + 1] = rs;
+      if (chunk == 0) { p.mean[b * p.G + g] = mu; p.rstd[b * p.G + g] = rs; }     // kept for the backward pass
+    } else {
+      stat[2 * g] = s0 / n;
+      stat[2 * g + 1] = s1 / n;
+    }
+  }
+  __syncthreads();
   float mu[8], rs[8], ga[8], be[8], s1[8], s2[8];
 #pragma unroll
   for (int k = 0; k < 8; ++k) {
     const int c = o * 8 + k, g = c / cpg;
-    mu[k] = p.mean[b * p.G + g]; rs[k] = p.rstd[b * p.G + g]; ga[k] = p.gamma[c]; be[k] = p.beta[c];
-    if (BWD) { s1[k] = p.gsum[2 * (b * p.G + g)]; s2[k] = p.gsum[2 * (b * p.G + g) + 1]; }
+    ga[k] = p.gamma[c]; be[k] = p.beta[c];
+    if (!BWD) { mu[k] = stat[2 * g]; rs[k] = stat[2 * g + 1]; }
+    else { mu[k] = p.mean[b * p.G + g]; rs[k] = p.rstd[b * p.G + g]; s1[k] = stat[2 * g]; s2[k] = stat[2 * g + 1]; }
   }
   const int r0 = chunk * p.rows_per_chunk, r1 = min(p.HW, r0 + p.rows_per_chunk);
   for (int r = r0 + rp; r < r1; r += p.RP) {
@@ -936,7 +1056,6 @@ static GnDev gn_dev(const gad_groupnorm_args* a) {
   d.B = a->B; d.HW = a->HW; d.C = a->C; d.G = a->G; d.silu = a->silu; d.eps = a->eps;
   d.chunks = (int)gn_chunks(a, &d.rows_per_chunk, &d.NO, &d.RP);
   d.part = (float*)a->ws;
-  d.gsum = d.part + (long)d.B * d.chunks * d.C * 2;
   return d;
 }
 
@@ -1076,7 +1195,7 @@ extern "C" int64_t gad_h_groupnorm_workspace_bytes(const gad_groupnorm_args* a) 
   if (!a || a->C <= 0 || a->C % 8 || a->B <= 0 || a->HW <= 0 || a->G <= 0) return -1;
   int rpc, no, rp;
   const int64_t chunks = gn_chunks(a, &rpc, &no, &rp);
-  return ((int64_t)a->B * chunks * a->C * 2 + (int64_t)a->B * a->G * 2) * 4;
+  return (int64_t)a->B * chunks * a->G * 2 * 4;
 }
 template <bool BWD>
 static int gn_run(const gad_groupnorm_args* a, hipStream_t st, const char* who) {
@@ -1085,9 +1204,7 @@ static int gn_run(const gad_groupnorm_args* a, hipStream_t st, const char* who) 
   const dim3 grid(d.chunks, d.B), block(d.NO * d.RP);
   hipLaunchKernelGGL(gn_part_kernel<BWD>, grid, block, (size_t)d.RP * d.NO * 16 * 4, st, d);
   GAD_LAUNCH_CHECK("h_gn_part");
-  hipLaunchKernelGGL(gn_final_kernel<BWD>, dim3(d.B * d.G), dim3(64), 0, st, d);
-  GAD_LAUNCH_CHECK("h_gn_final");
-  hipLaunchKernelGGL(gn_apply_kernel<BWD>, grid, block, 0, st, d);
+  hipLaunchKernelGGL(gn_apply_kernel<BWD>, grid, block, (size_t)d.G * 2 * 4, st, d);
   GAD_LAUNCH_CHECK("h_gn_apply");
   return 0;
 }
@@ -1099,4 +1216,63 @@ extern "C" int gad_h_groupnorm_silu_bwd(const gad_groupnorm_args* a, void* strea
   GAD_CHECK(!a->dgamma && !a->dbeta, "gad_h_groupnorm_silu_bwd: the half path computes dx only (frozen norm)");
   GAD_CHECK(!a->x2, "gad_h_groupnorm_silu_bwd: single source only");
   return gn_run<true>(a, (hipStream_t)stream, "gad_h_groupnorm_silu_bwd");
+}
+
+// ---- token-axis contraction (both operands [k][.]) ----
+static int tn_check(const gad_hgemm_args* a) {
+  GAD_CHECK(a && a->A && a->B && a->C, "gad_hgemm_tn: null operand");
+  GAD_CHECK(a->M > 0 && a->N > 0 && a->K > 0, "gad_hgemm_tn: empty problem %d x %d x %d", a->M, a->N, a->K);
+  GAD_CHECK(a->lda % 8 == 0 && a->ldb % 8 == 0 && a->lda >= (a->M + 7) / 8 * 8 && a->ldb >= (a->N + 7) / 8 * 8,
+            "gad_hgemm_tn: row strides must be multiples of 8 covering M / N rounded up to 8 (rows are read in 16-byte chunks)");
+  GAD_CHECK(gad_aligned16(a->A) && gad_aligned16(a->B), "gad_hgemm_tn: operands must be 16-byte aligned");
+  GAD_CHECK((long)a->K * (a->lda > a->ldb ? a->lda : a->ldb) < (1L << 40), "gad_hgemm_tn: operand too large");
+  GAD_CHECK(a->out_f32 && !a->bias && !a->rowadd && !a->residual && !a->A2 && !a->B2 && !a->conv,
+            "gad_hgemm_tn: fp32 output, no epilogue operands, no second operand pair, no gather");
+  GAD_CHECK(a->ldc >= a->N, "gad_hgemm_tn: ldc < N");
+  return 0;
+}
+static int tn_splitk(const gad_hgemm_args* a, int* steps_out) {
+  const int steps = (a->K + 31) / 32;
+  const long tiles = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
+  int sk = a->splitk_hint > 0 ? a->splitk_hint : (int)(512 / tiles);
+  if (a->splitk_hint <= 0 && sk > steps / 8) sk = steps / 8;            // at least 256 of K per slice
+  if (sk > 128) sk = 128;
+  if (sk > steps) sk = steps;
+  if (sk < 1) sk = 1;
+  const int per = (steps + sk - 1) / sk;
+  *steps_out = steps;
+  return (steps + per - 1) / per;
+}
+extern "C" int64_t gad_hgemm_tn_workspace_bytes(const gad_hgemm_args* a) {
+  if (tn_check(a)) return -1;
+  int steps;
+  const int sk = tn_splitk(a, &steps);
+  return sk > 1 ? (int64_t)sk * a->M * a->N * 4 : 0;
+}
+extern "C" int gad_hgemm_tn(const gad_hgemm_args* a, void* stream) {
+  if (tn_check(a)) return 1;
+  int steps;
+  const int sk = tn_splitk(a, &steps);
+  if (sk > 1) GAD_CHECK(a->ws && a->ws_bytes >= (int64_t)sk * a->M * a->N * 4, "gad_hgemm_tn: split-K workspace too small");
+  HDev d{};
+  d.A = (const u16*)a->A; d.B = (const u16*)a->B;
+  d.M = a->M; d.N = a->N; d.lda = a->lda; d.ldb = a->ldb; d.len1 = a->K;
+  d.alpha = a->alpha; d.C = a->C; d.ldc = a->ldc; d.out_f32 = 1; d.accumulate = a->accumulate;
+  d.ws = (float*)a->ws;
+  d.tiles_m = (a->M + 127) / 128; d.tiles_n = (a->N + 127) / 128; d.splitk = sk; d.steps = steps;
+  d.steps_per_split = (steps + sk - 1) / sk;
+  d.vec_out = a->N % 8 == 0 && gad_aligned16(a->C) && a->ldc % 4 == 0 && (sk == 1 || gad_aligned16(a->ws));
+  d.vec = d.vec_out;
+  d.dbg_zero = a->tile_hint >= 100;
+  d.zero = zero_block();
+  GAD_CHECK(d.zero != nullptr, "gad_hgemm_tn: cannot resolve the zero block's device address");
+  hipStream_t st = (hipStream_t)stream;
+  hipLaunchKernelGGL(hgemm_tn_kernel, dim3(d.tiles_m * d.tiles_n, sk), dim3(256), 0, st, d);
+  GAD_LAUNCH_CHECK("hgemm_tn_kernel");
+  if (sk > 1) {
+    const long total = d.vec_out ? (long)a->M * a->N / 8 : (long)a->M * a->N;
+    hipLaunchKernelGGL(hgemm_reduce_kernel, dim3((unsigned)((total + 255) / 256)), dim3(256), 0, st, d);
+    GAD_LAUNCH_CHECK("hgemm_reduce_kernel");
+  }
+  return 0;
 }

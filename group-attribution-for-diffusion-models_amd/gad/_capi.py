@@ -149,6 +149,8 @@ SIGNATURES = {
     "gad_hgemm_workspace_bytes": (_i64, [C.POINTER(HGemmArgs)]),
     "gad_hgemm_plan": (C.c_int, [C.POINTER(HGemmArgs), C.POINTER(_i32), C.POINTER(_i32)]),
     "gad_hgemm": (C.c_int, [C.POINTER(HGemmArgs), _vp]),
+    "gad_hgemm_tn_workspace_bytes": (_i64, [C.POINTER(HGemmArgs)]),
+    "gad_hgemm_tn": (C.c_int, [C.POINTER(HGemmArgs), _vp]),
     "gad_h_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gad_h_cast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
     "gad_h_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),

@@ -158,26 +158,6 @@ def _half_of(w):
     return to_half(w.detach())
 
 
-_TCACHE = {"epoch": -1}
-
-
-def _transposed_cached(x2d):
-    """x^T for the parameter gradients of one backward pass: the projections of an attention share their input (to_q / to_k /
-    to_v read the same h; to_k / to_v the same context), so its transpose is made once per step.  Only while a FusedTrainer
-    backward is running (ops.begin_backward_step): entries hold their source tensor, so an address cannot be reused under them."""
-    if not ops._SINK_ACTIVE[0]:
-        return transpose_raw(x2d)
-    if _TCACHE["epoch"] != ops._SINK_EPOCH[0]:
-        _TCACHE.clear()
-        _TCACHE["epoch"] = ops._SINK_EPOCH[0]
-    key = (x2d.data_ptr(), tuple(x2d.shape), x2d.stride(0))
-    hit = _TCACHE.get(key)
-    if hit is None:
-        hit = (x2d, transpose_raw(x2d))
-        _TCACHE[key] = hit
-    return hit[1]
-
-
 def lora_half(down, up):
     """bf16 shadows of a LoRA pair, the rank padded with zeros to a multiple of 8 (ragged pruned ranks,
     text_to_image/prune_lora.py:173-180): (down [r8][K], up [N][r8], down^T [K][r8], up^T [r8][N]); refreshed when either
@@ -274,14 +254,29 @@ def linear_raw(x2d, wh, bias=None, residual=None, alpha=1.0, A2=None, B2=None, o
     return y
 
 
-def wgrad_raw(dy2d, x2d, out, accumulate):
-    """out[N][K] (fp32) (+)= dy2d[M][:N]^T x2d[M][:K]: the LoRA parameter gradients (N, K = out's shape: the operands may
-    carry zero pad columns).  Both operands are transposed into [.][M] bf16 copies and contracted over the token axis M by the
-    same engine (split-K)."""
+def wgrad_raw(dy2d, x2d, out, accumulate, alpha=1.0):
+    """out[N][K] (fp32) (+)= alpha * dy2d[M][:N]^T x2d[M][:K]: the LoRA parameter gradients (N, K = out's shape; the operands may
+    carry zero pad columns).  A contraction over the token axis M with both operands read in place (gad_hgemm_tn: transposing LDS
+    reads), split along M."""
+    lib = _capi.load()
     N, K = out.shape
-    dyt = transpose_raw(dy2d)[:N]
-    xt = _transposed_cached(x2d)[:K]
-    linear_raw(dyt, xt, out=out, out_f32=True, accumulate=accumulate)
+    a = HGemmArgs()
+    a.A, a.B, a.C = dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr()
+    a.M, a.N, a.K = N, K, dy2d.shape[0]
+    a.lda, a.ldb, a.ldc = dy2d.stride(0), x2d.stride(0), out.stride(0)
+    a.alpha, a.out_f32, a.accumulate = alpha, 1, int(accumulate)
+    need = lib.gad_hgemm_tn_workspace_bytes(C.byref(a))
+    if need < 0:
+        raise _capi.GadError(f"gad_hgemm_tn: {lib.gad_last_error().decode()}")
+    if need:
+        ws = ops._scratch("ws", need, dy2d.device) if ops.SCRATCH_ALLOC is not None else ops.workspace(dy2d.device)
+        if ws.numel() < need:
+            ws = torch.empty(need, dtype=torch.uint8, device=dy2d.device)
+        a.ws, a.ws_bytes = ws.data_ptr(), ws.numel()
+    if ops.PROFILER is not None:
+        ops.PROFILER.hgemm(lib, a, tn=True)
+        return
+    check(lib.gad_hgemm_tn(C.byref(a), _st()), "gad_hgemm_tn")
 
 
 # ----------------------------------------------------------------------------------

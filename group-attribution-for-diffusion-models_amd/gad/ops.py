@@ -80,11 +80,6 @@ def begin_backward_step():
 
 def end_backward_step():
     _SINK_ACTIVE[0] = False
-    import sys
-    h = sys.modules.get(__package__ + ".half")
-    if h is not None:                      # the per-backward transposes hold activations: release them with the step
-        h._TCACHE.clear()
-        h._TCACHE["epoch"] = -1
 
 
 def _sink(param):
@@ -332,11 +327,19 @@ class GemmProfiler:
             stage = (mid, 4.0 * a_elems + v_bytes if mid is not None else 0.0, v_bytes + 4.0 * (b_elems * npos / 9.0 + a.M * a.N + extra))
         self.records.append((key, flops, nbytes, s, e, executed, stage))
 
-    def hgemm(self, lib, a):
-        """Bracket a half-precision-path contraction (gad_hgemm): bf16 operands and output (fp32 output for parameter gradients)."""
+    def hgemm(self, lib, a, tn=False):
+        """Bracket a half-precision-path contraction (gad_hgemm / gad_hgemm_tn): bf16 operands and output (fp32 output for parameter gradients)."""
+        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
+        if tn:
+            s.record()
+            check(lib.gad_hgemm_tn(C.byref(a), _stream()), "gad_hgemm_tn")
+            e.record()
+            nbytes = 2.0 * a.K * (a.M + a.N) + 4.0 * a.M * a.N
+            flops = 2.0 * a.M * a.N * a.K
+            self.records.append((("hgemm_tn_wgrad", 128, 0, 8), flops, nbytes, s, e, flops, None))
+            return
         tile, sk = C.c_int32(), C.c_int32()
         check(lib.gad_hgemm_plan(C.byref(a), C.byref(tile), C.byref(sk)), "gad_hgemm_plan")
-        s, e = torch.cuda.Event(enable_timing=True), torch.cuda.Event(enable_timing=True)
         s.record()
         check(lib.gad_hgemm(C.byref(a), _stream()), "gad_hgemm")
         e.record()

@@ -420,6 +420,13 @@ typedef struct gad_hgemm_args {
 int64_t gad_hgemm_workspace_bytes(const gad_hgemm_args* a);
 int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: 1 / 2 / 5 as tile_hint */
 int gad_hgemm(const gad_hgemm_args* a, void* stream);
+/* The token-axis contraction of the LoRA parameter gradients (dB = dy^T mid, dA = dmid^T x, G = dy^T x:
+ * train_text_to_image_lora.py:1305 loss.backward() through LoRALinearLayer): C[m][n] = alpha * sum_k A[k][m] B[k][n], BOTH operands
+ * stored with the contraction index k (the token) as their row - A: K rows of lda >= M, B: K rows of ldb >= N - so the activations
+ * are read in place (transposing LDS reads), no transposed copies.  fp32 output only (out_f32 = 1; accumulate as in gad_hgemm);
+ * lda, ldb multiples of 8 and >= M, N rounded up to 8 (rows are read in 16-byte chunks; columns >= M / N feed no output); of gad_hgemm_args only A, B, C, M, N, K, lda, ldb, ldc, alpha, accumulate, ws, splitk_hint are read. */
+int64_t gad_hgemm_tn_workspace_bytes(const gad_hgemm_args* a);
+int gad_hgemm_tn(const gad_hgemm_args* a, void* stream);
 /* dst[c][r] = bf16(src[r][c]) for `batch` matrices (strides in elements); src fp32 (src_f32 != 0) or bf16; the operand
  * transposes of the LoRA parameter gradients (dUp = dy^T mid, dDown = dmid^T x) and of the per-step bf16 shadows of the
  * LoRA matrices' transposes */

@@ -79,6 +79,25 @@ def test_hgemm_k_concat(M, N, K, r, tile):
     close_h(out, xd @ wd.T + midd @ upd.T, extra=2e-5 * math.sqrt(K + r), what="k-concat")
 
 
+@pytest.mark.parametrize("T,M,N,sk", [(256, 128, 128, 0), (1000, 320, 256, 0), (77 * 2, 96, 136, 0), (4096, 320, 320, 0), (300, 6, 72, 0), (640, 264, 8, 3)])
+def test_hgemm_tn(T, M, N, sk):
+    """C = A^T B with both operands [tokens][channels] (the LoRA parameter gradients), fp32 output, overwrite then accumulate;
+    output dims that are not multiples of 8 read zero pad columns of operands allocated 8-aligned"""
+    from gad import half
+    M8, N8 = (M + 7) // 8 * 8, (N + 7) // 8 * 8
+    a, b = torch.zeros(T, M8), torch.zeros(T, N8)
+    a[:, :M], b[:, :N] = rnd(T, M, seed=1), rnd(T, N, seed=2)
+    ah, ad = hb(a)
+    bh, bd = hb(b)
+    want = ad[:, :M].T @ bd[:, :N]
+    out = torch.full((M, N), 7.0, device=dev)
+    half.wgrad_raw(ah, bh, out, accumulate=False)
+    tol = 2e-5 * math.sqrt(T) * max(1.0, want.abs().max().item())
+    assert (out.cpu().double() - want).abs().max() < tol
+    half.wgrad_raw(ah, bh, out, accumulate=True, alpha=0.5)
+    assert (out.cpu().double() - 1.5 * want).abs().max() < 2 * tol
+
+
 def test_hgemm_rejects_misaligned():
     from gad import _capi, half
     a = torch.zeros((64, 40), device=dev, dtype=BF)
