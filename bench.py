@@ -423,7 +423,9 @@ def kernel_report(prof, dt, peak_tf, precision, workload):
         kname = kname.replace("_f32_kernel", "_bf16_kernel<.., HIO>").replace("attn_bwd1", "attn_bwd_dq + attn_bwd_dkv")
     traffic, traffic_src = None, None
     pmc = os.path.join(ROOT, "profiles", "pmc_summary.json" if workload == "cifar20" else f"pmc_summary_{workload}.json")
-    if precision == "f32" and os.path.exists(pmc):
+    if precision == "bf16":                       # the half-precision activation path has its own counter passes
+        pmc = os.path.join(ROOT, "profiles", f"pmc_summary_{workload}_bf16.json")
+    if precision in ("f32", "bf16") and os.path.exists(pmc):
         j = json.load(open(pmc))
         if j.get("dominant_key") in (None, "_".join(str(x) for x in dom_key)):      # a stored pass of another kernel says nothing here
             traffic = j.get("dominant_kernel_hbm_bytes_per_launch")

@@ -20,7 +20,8 @@ for c in FETCH_SIZE WRITE_SIZE; do
   echo "pmc $c done"
 done
 python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "" "hgemm_kernel<4, 2, 2, 5, 32, 4, true, 1>" > $O/${TAG}_pmc_summary_sd512_bf16_conv.json
-python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "" "attn_bwd_dkv_bf16_kernel<40, true, 2>" "attn_bwd_dq_bf16_kernel<40, true, 2>" "attn_delta_h_kernel<40>" > $O/${TAG}_pmc_summary_sd512_bf16_attn_bwd.json
+# (the dominant family of the sd512 bf16 line: bench.py's bracket spans delta + dQ + dK/dV; Tk = 77 launches of the same dQ kernel are in the sum)
+python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "attn_bwd_d40_4096_4096_2" "attn_bwd_dkv_bf16_kernel<40, true, 2>" "attn_bwd_dq_bf16_kernel<40, true, 2>" "attn_delta_h_kernel<40>" > $O/${TAG}_pmc_summary_sd512_bf16_attn_bwd.json
 rm -rf $O/pmch
 cd tools
 python3 ab_hgemm.py 2>&1 | grep -v amdgpu.ids > $O/${TAG}_ab_hgemm.txt
