@@ -32,7 +32,7 @@ CONV = [  # B, H, Cin, Cout
     (16, 64, 320, 320), (16, 64, 640, 320), (16, 64, 960, 320), (16, 32, 640, 640), (16, 32, 1280, 640), (16, 32, 1920, 640),
     (16, 16, 1280, 1280), (16, 16, 2560, 1280), (16, 8, 1280, 1280), (16, 8, 2560, 1280),
 ]
-FORMS = [(1, 1), (2, 1), (5, 1), (0, 0)]          # (tile_hint, splitk_hint); (0, 0) = planner
+FORMS = [(2, 1), (7, 1), (5, 1), (6, 1), (0, 0)]          # (tile_hint, splitk_hint); (0, 0) = planner
 
 if __name__ == "__main__":
     print("dense: us (TF/s) per form  [tile,sk]:", FORMS)
@@ -42,7 +42,7 @@ if __name__ == "__main__":
         out = torch.empty(M, N, device=dev, dtype=BF)
         row = []
         for tile, sk in FORMS:
-            if tile in (2, 3, 5) and N < 160:
+            if tile in (2, 5, 6, 7) and N < 160:
                 row.append("      -      ")
                 continue
             t = timeit(lambda: half.hgemm_raw(a, b, out, M, N, K, K, K, N, tile_hint=tile, splitk_hint=sk))
@@ -56,7 +56,7 @@ if __name__ == "__main__":
         geom = (H, H, Cin, H, H, 3, 3, 1, 1, 1, 0)
         y = torch.empty(Bn, H, H, Cout, device=dev, dtype=BF)
         row = []
-        for tile, sk in FORMS + [(2, 2), (2, 4), (5, 2), (5, 4)]:
+        for tile, sk in FORMS + [(5, 2), (6, 2), (5, 4), (6, 4)]:
             t = timeit(lambda: half.hgemm_raw(x, w, y, M, Cout, K, Cin, K, Cout, conv=1, geom=geom, k_split=Cin, tile_hint=tile, splitk_hint=sk))
             row.append("%7.1f (%4.0f)" % (t, 2.0 * M * Cout * K / t / 1e6))
         print("B %2d %2dx%2d Cin %4d Cout %4d | " % (Bn, H, H, Cin, Cout) + " | ".join(row), flush=True)
