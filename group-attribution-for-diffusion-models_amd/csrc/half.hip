@@ -422,7 +422,8 @@ __device__ __forceinline__ bf16x8 tn_frag(const unsigned char* img, int c0) {   
   return __builtin_bit_cast(bf16x8, both);
 }
 __global__ __launch_bounds__(256, 2) void hgemm_tn_kernel(const HDev p) {           // p.len1 = K (rows of A and B); p.M x p.N outputs
-  constexpr int IMG = 32 * 256, STAGE = 2 * IMG;
+  constexpr int KB = 2;                                  // 32-row sub-images per stage: 64 rows of K per barrier
+  constexpr int IMG = 32 * 256, OPER = KB * IMG, STAGE = 2 * OPER;
   __shared__ __attribute__((aligned(1024))) unsigned char lds[2 * STAGE];
   const int t = xcd_remap(blockIdx.x, p.tiles_m * p.tiles_n);
   const int tile_m = t / p.tiles_n, tile_n = t - tile_m * p.tiles_n;
@@ -431,34 +432,29 @@ __global__ __launch_bounds__(256, 2) void hgemm_tn_kernel(const HDev p) {       
   const int tid = threadIdx.x, lane = tid & 63;
   const int wave = __builtin_amdgcn_readfirstlane(tid >> 6);
   const int wm = wave >> 1, wn = wave & 1;
-  // DMA: instruction ii (0 .. 7 per operand) covers image rows 4 ii .. 4 ii + 3; wave w issues ii = w and w + 4 of both operands
+  // DMA: instruction ii (0 .. 8 KB - 1 per operand) covers stage rows 4 ii .. 4 ii + 3; wave w issues ii = w + 4 i
+  constexpr int NI = 2 * KB;
   const int dr = lane >> 4, pos = lane & 15;
-  int ka[2], offa[2], offb[2];
-  bool oka[2], okb[2];
-#pragma unroll
-  for (int i = 0; i < 2; ++i) {
-    const int kr = (wave + 4 * i) * 4 + dr;                   // image row = k within the step
-    const int ch = (pos ^ ((kr & 7) << 1)) * 8;               // source chunk (elements)
-    ka[i] = kr;
-    oka[i] = row0 + ch < p.M;
-    okb[i] = col0 + ch < p.N;
-    offa[i] = kr * p.lda + row0 + ch;
-    offb[i] = kr * p.ldb + col0 + ch;
-  }
+  // (ii = w + 4 i -> row 4 w + 16 i + dr: its low three bits, hence the swizzle, do not depend on i)
+  const int kr0 = wave * 4 + dr;
+  const int ch = (pos ^ ((kr0 & 7) << 1)) * 8;           // source chunk (elements)
+  const bool oka = row0 + ch < p.M, okb = col0 + ch < p.N;
+  const int offa = kr0 * p.lda + row0 + ch, offb = kr0 * p.ldb + col0 + ch;
   const u16* const zero = p.zero;
   const int t0 = z * p.steps_per_split, t1 = min(p.steps, t0 + p.steps_per_split);
   auto stage = [&](int step, int buf) {
-    const int k0 = step * 32;
-    unsigned char* dst = lds + buf * STAGE;
+    const int k0 = step * (32 * KB);
+    unsigned char* dst = lds + buf * STAGE + wave * 1024;
 #pragma unroll
-    for (int i = 0; i < 2; ++i) {
-      const bool kin = k0 + ka[i] < p.len1 && !p.dbg_zero;
-      const u16* sa = (kin && oka[i]) ? p.A + ((long)k0 * p.lda + offa[i]) : zero;
-      const u16* sb = (kin && okb[i]) ? p.B + ((long)k0 * p.ldb + offb[i]) : zero;
+    for (int i = 0; i < NI; ++i) {
+      const int kr = k0 + kr0 + 16 * i;
+      const bool kin = kr < p.len1 && !p.dbg_zero;
+      const u16* sa = (kin && oka) ? p.A + ((long)(k0 + 16 * i) * p.lda + offa) : zero;
+      const u16* sb = (kin && okb) ? p.B + ((long)(k0 + 16 * i) * p.ldb + offb) : zero;
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sa,
-                                       (__attribute__((address_space(3))) void*)(dst + (wave + 4 * i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + i * 4096), 16, 0, 0);
       __builtin_amdgcn_global_load_lds((const __attribute__((address_space(1))) void*)sb,
-                                       (__attribute__((address_space(3))) void*)(dst + IMG + (wave + 4 * i) * 1024), 16, 0, 0);
+                                       (__attribute__((address_space(3))) void*)(dst + OPER + i * 4096), 16, 0, 0);
     }
   };
   f32x4 acc[4][4];
@@ -474,17 +470,20 @@ __global__ __launch_bounds__(256, 2) void hgemm_tn_kernel(const HDev p) {       
   for (int st = t0; st < t1; ++st) {
     const int buf = (st - t0) & 1;
     if (st + 1 < t1) stage(st + 1, buf ^ 1);
-    const unsigned char* ia = lds + buf * STAGE;
-    const unsigned char* ib = ia + IMG;
-    bf16x8 af[4], bfr[4];
 #pragma unroll
-    for (int i = 0; i < 4; ++i) af[i] = tn_frag(ia, wm * 64 + 16 * i);
+    for (int kb = 0; kb < KB; ++kb) {
+      const unsigned char* ia = lds + buf * STAGE + kb * IMG;
+      const unsigned char* ib = ia + OPER;
+      bf16x8 af[4], bfr[4];
 #pragma unroll
-    for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(ib, wn * 64 + 16 * j);
+      for (int i = 0; i < 4; ++i) af[i] = tn_frag(ia, wm * 64 + 16 * i);
 #pragma unroll
-    for (int i = 0; i < 4; ++i)
+      for (int j = 0; j < 4; ++j) bfr[j] = tn_frag(ib, wn * 64 + 16 * j);
 #pragma unroll
-      for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+      for (int i = 0; i < 4; ++i)
+#pragma unroll
+        for (int j = 0; j < 4; ++j) acc[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc[i][j], 0, 0, 0);
+    }
     __builtin_amdgcn_s_waitcnt(0x0F70);
     __syncthreads();
   }
@@ -976,17 +975,18 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
   const bool fits32 = amax < (1L << 31) && (long)a->N * (a->ldb > a->ldb2 ? a->ldb : a->ldb2) < (1L << 31);
   const long tiles8 = ((a->M + 255) / 256) * ((a->N + 319) / 320);
   const int hint = a->tile_hint % 100;
-  if (hint == 1 || hint == 2 || (hint >= 5 && hint <= 7)) tile = hint;
+  if (hint == 1 || hint == 2 || (hint >= 5 && hint <= 8)) tile = hint;
   else if (a->N % 320 != 0) tile = 1;
   else if (long_k) tile = tiles8 >= 48 ? 6 : 7;                    // 3x3 convolutions: the eight-wave form (one round of tiles, or of K slices); 8x8 maps: 128 x 320 split
   else if (tiles2 >= 400) tile = 7;                                // Linears with a full round of 128 x 320 tiles
   else tile = tiles1 * 2 > tiles2 * 3 ? 1 : 7;
+  if (tile == 1 && hint == 0 && tiles1 >= 512 && a->K <= 4096) tile = 8;     // enough 128 x 128 tiles for four workgroups per CU: the 32 KB form
   // (forms 6 / 7 = the 256 x 320 / 128 x 320 tiles on v_mfma_f32_16x16x32_bf16: +6-12 % over the 32x32x16 forms 5 / 2 on the convolutions,
   //  +3-8 % on the Linears - profiles/r04_ab_hgemm.txt; 5 / 2 stay for A/B)
   pl.tile = tile;
   pl.fits32 = fits32;
-  const bool t320 = tile == 2 || tile >= 5;
-  pl.bk = t320 ? 32 : 64;
+  const bool t320 = tile == 2 || (tile >= 5 && tile <= 7);
+  pl.bk = (t320 || tile == 8) ? 32 : 64;
   pl.bm = (tile == 5 || tile == 6) ? 256 : 128;
   pl.bn = t320 ? 320 : 128;
   const int groups = a->conv ? a->KH * a->KW : 1;
@@ -1145,7 +1145,8 @@ extern "C" int gad_hgemm(const gad_hgemm_args* a, void* stream) {
   else if (pl.tile == 2) rc = hgemm_launch<2, 2, 2, 5, 32, 2, false>(d, st);
   else if (pl.tile == 5) rc = hgemm_launch<4, 2, 2, 5, 32, 4, true>(d, st);
   else if (pl.tile == 6) rc = hgemm_launch<4, 2, 2, 5, 32, 4, true, true>(d, st);       // A/B: the eight-wave form on 16x16x32 MFMAs
-  else if (pl.tile == 7) rc = hgemm_launch<2, 2, 2, 5, 32, 2, false, true>(d, st);      // A/B: 128 x 320 on 16x16x32 MFMAs
+  else if (pl.tile == 7) rc = hgemm_launch<2, 2, 2, 5, 32, 2, false, true>(d, st);      // 128 x 320 on 16x16x32 MFMAs
+  else if (pl.tile == 8) rc = hgemm_launch<2, 2, 2, 2, 32, 2, false, true>(d, st);      // 128 x 128, 32-deep steps, 16x16x32 MFMAs: 32 KB of LDS, four workgroups per CU
   else { gad_set_error("gad_hgemm: tile_hint %d", pl.tile); return 1; }
   if (rc) return rc;
   if (pl.splitk > 1) {
@@ -1269,10 +1270,10 @@ static int tn_check(const gad_hgemm_args* a) {
   return 0;
 }
 static int tn_splitk(const gad_hgemm_args* a, int* steps_out) {
-  const int steps = (a->K + 31) / 32;
+  const int steps = (a->K + 63) / 64;
   const long tiles = (long)((a->M + 127) / 128) * ((a->N + 127) / 128);
   int sk = a->splitk_hint > 0 ? a->splitk_hint : (int)(512 / tiles);
-  if (a->splitk_hint <= 0 && sk > steps / 8) sk = steps / 8;            // at least 256 of K per slice
+  if (a->splitk_hint <= 0 && sk > steps / 4) sk = steps / 4;            // at least 256 of K per slice
   if (sk > 128) sk = 128;
   if (sk > steps) sk = steps;
   if (sk < 1) sk = 1;

@@ -25,6 +25,7 @@ def timeit(fn, iters=20):
 
 
 DENSE = [  # M, N, K
+    (16384, 640, 1280), (4096, 1280, 640), (16384, 256, 1280), (4096, 256, 1280), (4096, 1280, 256),
     (65536, 320, 320), (65536, 2560, 320), (65536, 320, 1280), (16384, 640, 640), (16384, 5120, 640), (16384, 640, 2560),
     (4096, 1280, 1280), (4096, 10240, 1280), (4096, 1280, 5120), (65536, 256, 320), (16384, 256, 640), (65536, 320, 576), (1232, 320, 768),
 ]
@@ -32,7 +33,7 @@ CONV = [  # B, H, Cin, Cout
     (16, 64, 320, 320), (16, 64, 640, 320), (16, 64, 960, 320), (16, 32, 640, 640), (16, 32, 1280, 640), (16, 32, 1920, 640),
     (16, 16, 1280, 1280), (16, 16, 2560, 1280), (16, 8, 1280, 1280), (16, 8, 2560, 1280),
 ]
-FORMS = [(2, 1), (7, 1), (5, 1), (6, 1), (0, 0)]          # (tile_hint, splitk_hint); (0, 0) = planner
+FORMS = [(1, 1), (8, 1), (7, 1), (6, 1), (0, 0)]          # (tile_hint, splitk_hint); (0, 0) = planner
 
 if __name__ == "__main__":
     print("dense: us (TF/s) per form  [tile,sk]:", FORMS)
@@ -42,12 +43,14 @@ if __name__ == "__main__":
         out = torch.empty(M, N, device=dev, dtype=BF)
         row = []
         for tile, sk in FORMS:
-            if tile in (2, 5, 6, 7) and N < 160:
+            if tile in (2, 5, 6, 7) and N % 320:
                 row.append("      -      ")
                 continue
             t = timeit(lambda: half.hgemm_raw(a, b, out, M, N, K, K, K, N, tile_hint=tile, splitk_hint=sk))
             row.append("%7.1f (%4.0f)" % (t, 2.0 * M * N * K / t / 1e6))
         print("M %6d N %5d K %5d | " % (M, N, K) + " | ".join(row), flush=True)
+    if "dense" in sys.argv[1:]:
+        sys.exit(0)
     print("conv3x3: us (TF/s)")
     for Bn, H, Cin, Cout in CONV:
         x = (torch.randn(Bn, H, H, Cin, device=dev) * 0.5).to(BF)
