@@ -878,13 +878,25 @@ __global__ void gn_apply_kernel(const GnDev p) {
   const int b = blockIdx.y, chunk = blockIdx.x;
   const int o = threadIdx.x % p.NO, rp = threadIdx.x / p.NO;
   const int cpg = p.C / p.G;
-  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+  // the image's statistics from the chunks' partials: thread (g, part) sums every PARTS-th chunk of group g, LDS combines the parts in a
+  // fixed order (every workgroup of the image gets the same bits)
+  float* parts = stat + 2 * p.G;                           // [PARTS][G][2]
+  const int PARTS = max(1, (int)blockDim.x / p.G);
+  for (int idx = threadIdx.x; idx < PARTS * p.G; idx += blockDim.x) {
+    const int g = idx % p.G, part = idx / p.G;
     float s0 = 0.f, s1 = 0.f;
-    for (int ch = 0; ch < p.chunks; ++ch) {                  // fixed order: every workgroup of the image gets the same bits
+    for (int ch = part; ch < p.chunks; ch += PARTS) {
       const float* src = p.part + (((long)b * p.chunks + ch) * p.G + g) * 2;
       s0 += src[0];
       s1 += src[1];
     }
+    parts[(part * p.G + g) * 2] = s0;
+    parts[(part * p.G + g) * 2 + 1] = s1;
+  }
+  __syncthreads();
+  for (int g = threadIdx.x; g < p.G; g += blockDim.x) {
+    float s0 = 0.f, s1 = 0.f;
+    for (int part = 0; part < PARTS; ++part) { s0 += parts[(part * p.G + g) * 2]; s1 += parts[(part * p.G + g) * 2 + 1]; }
     const float n = (float)p.HW * cpg;
     if (!BWD) {
       const float mu = s0 / n, var = fmaxf(s1 / n - mu * mu, 0.f), rs = rsqrtf(var + p.eps);
@@ -1242,7 +1254,8 @@ static int gn_run(const gad_groupnorm_args* a, hipStream_t st, const char* who) 
   const dim3 grid(d.chunks, d.B), block(d.NO * d.RP);
   hipLaunchKernelGGL(gn_part_kernel<BWD>, grid, block, (size_t)d.RP * d.NO * 16 * 4, st, d);
   GAD_LAUNCH_CHECK("h_gn_part");
-  hipLaunchKernelGGL(gn_apply_kernel<BWD>, grid, block, (size_t)d.G * 2 * 4, st, d);
+  const int parts = d.NO * d.RP / d.G > 0 ? d.NO * d.RP / d.G : 1;
+  hipLaunchKernelGGL(gn_apply_kernel<BWD>, grid, block, (size_t)(1 + parts) * d.G * 2 * 4, st, d);
   GAD_LAUNCH_CHECK("h_gn_apply");
   return 0;
 }

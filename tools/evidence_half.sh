@@ -19,7 +19,7 @@ for c in FETCH_SIZE WRITE_SIZE; do
   rocprofv3 --kernel-trace --pmc $c --output-format csv -d $O/pmch/pmc_$c -- python3 bench.py --workload sd512 --precision bf16 --steps 2 --warmup 1 --no-cpu-baseline --no-kernel-timing > /dev/null 2> $O/${TAG}_pmc_${c}_sd512_bf16.err
   echo "pmc $c done"
 done
-python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "" "hgemm_kernel<4, 2, 2, 5, 32, 4, true, 1>" > $O/${TAG}_pmc_summary_sd512_bf16_conv.json
+python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "" "hgemm_kernel<4, 2, 2, 5, 32, 4, true, 1, true>" > $O/${TAG}_pmc_summary_sd512_bf16_conv.json
 # (the dominant family of the sd512 bf16 line: bench.py's bracket spans delta + dQ + dK/dV; Tk = 77 launches of the same dQ kernel are in the sum)
 python3 tools/pmc_route_summary.py $O/pmch "sd512 --precision bf16" "attn_bwd_d40_4096_4096_2" "attn_bwd_dkv_bf16_kernel<40, true, 2>" "attn_bwd_dq_bf16_kernel<40, true, 2>" "attn_delta_h_kernel<40>" > $O/${TAG}_pmc_summary_sd512_bf16_attn_bwd.json
 rm -rf $O/pmch
