@@ -1439,11 +1439,28 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
 
   zero_lds(ldsh, 2 * BUF + 64);
   __syncthreads();
+  // the tile's log-sum-exp / delta rows travel with the tile: threads 0-63 fetch one value each (lse | delta) beside the tile's
+  // loads and commit it to LDS with the images - read from global memory at their point of use they were eight dependent L2 loads per
+  // lane in front of every tile's exponentials (and a register-side prefetch cost occupancy: measured slower)
+  float* stt = reinterpret_cast<float*>(ldsh + 2 * BUF + 64);          // [2 stages][lse | delta][KV]
+  const int st_which = (threadIdx.x >> 5) & 1, st_r = threadIdx.x & 31;
+  float sv = 0.f;
+  auto fetch_stats = [&](int tile) {
+    if (threadIdx.x < 64) {
+      const int qrow = tile * KV + st_r;
+      sv = qrow < p.Tq ? (st_which ? dlt[qrow] : lse[qrow]) : 0.f;
+    }
+  };
+  auto commit_stats = [&](int stage) {
+    if (threadIdx.x < 64) stt[stage * 2 * KV + st_which * KV + st_r] = sv;
+  };
   TileIO<D, HIO> rq, rg;
   rq.fetch(Q, p.ldq, 0, p.Tq);
   rg.fetch(DO, p.lddo, 0, p.Tq);
+  fetch_stats(0);
   rq.template commit<C::SV>(ldsh);
   rg.template commit<C::SV>(ldsh + IMG);
+  commit_stats(0);
   __syncthreads();
   const int ntiles = (p.Tq + KV - 1) / KV;
   for (int it = 0; it < ntiles; ++it) {
@@ -1453,7 +1470,9 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
     if (more) {
       rq.fetch(Q, p.ldq, (it + 1) * KV, p.Tq);
       rg.fetch(DO, p.lddo, (it + 1) * KV, p.Tq);
+      fetch_stats(it + 1);
     }
+    const float* cst = stt + (it & 1) * 2 * KV;
     f32x4 pr[NU][2], ds[NU][2];
 #pragma unroll
     for (int t = 0; t < 2; ++t) {
@@ -1463,11 +1482,11 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
       float L2[4], dl[4];
       bool qok[4];
 #pragma unroll
-      for (int e = 0; e < 4; ++e) {       // (fetching these a tile ahead measured SLOWER: 901 vs 779 us at T = 4096)
-        const int qrow = it * KV + 16 * t + 4 * g + e;
-        qok[e] = qrow < p.Tq;
-        L2[e] = qok[e] ? lse[qrow] : 0.f;
-        dl[e] = qok[e] ? dlt[qrow] : 0.f;
+      for (int e = 0; e < 4; ++e) {
+        const int r = 16 * t + 4 * g + e;
+        qok[e] = it * KV + r < p.Tq;
+        L2[e] = cst[r];
+        dl[e] = cst[KV + r];
       }
 #pragma unroll
       for (int u = 0; u < NU; ++u) {
@@ -1501,6 +1520,7 @@ __global__ __launch_bounds__(NT) void attn_bwd_dkv_bf16_kernel(const AttnDev p) 
       unsigned short* nb = ldsh + ((it + 1) & 1) * BUF;
       rq.template commit<C::SV>(nb);
       rg.template commit<C::SV>(nb + IMG);
+      commit_stats((it + 1) & 1);
     }
     __syncthreads();
   }
@@ -1704,7 +1724,7 @@ template <int D>
 static int launch_bwd_h(AttnDev d, float* delta, hipStream_t st) {
   using C = CfgH<D>;
   static unsigned lds_set_q = 0, lds_set_kv = 0;
-  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short);
+  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short) + 4 * KV * (int)sizeof(float);     // (+ the dK/dV kernel's lse / delta rows)
   if (set_lds(attn_bwd_dq_bf16_kernel<D>, bytes, "gad_attention_bwd", &lds_set_q) ||
       set_lds(attn_bwd_dkv_bf16_kernel<D>, bytes, "gad_attention_bwd", &lds_set_kv)) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
@@ -1749,7 +1769,7 @@ template <int D>
 static int launch_bwd_hio(AttnDev d, float* delta, hipStream_t st) {
   using C = CfgH<D>;
   static unsigned lds_set_q = 0, lds_set_kv = 0;
-  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short);
+  const int bytes = (4 * KV * C::SV + 64) * (int)sizeof(unsigned short) + 4 * KV * (int)sizeof(float);     // (+ the dK/dV kernel's lse / delta rows)
   if (set_lds(attn_bwd_dq_bf16_kernel<D, true>, bytes, "gad_h_attention_bwd", &lds_set_q) ||
       set_lds(attn_bwd_dkv_bf16_kernel<D, true>, bytes, "gad_h_attention_bwd", &lds_set_kv)) return 1;
   const long total = (long)d.B * d.Tq * d.heads;
