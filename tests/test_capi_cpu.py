@@ -131,3 +131,44 @@ def test_kernel_family_selection_is_a_pure_host_decision():
     assert kid(lin) == 1 and lib.gad_gemm_uses_bf16(ctypes.byref(lin)) == 1
     lin.K = lin.lda = lin.ldb = 27                                           # no aligned float4 path: stays fp32
     assert kid(lin) == 0 and lib.gad_gemm_uses_bf16(ctypes.byref(lin)) == 0
+
+
+def test_half_path_host_side_checks_and_planner_without_gpu():
+    """gad_hgemm's argument validation and its planner are host code: misuse is rejected before anything is launched, and the
+    tile / split-K choices for the SD step's shapes are the ones DESIGN.md §4.4 states (no GPU needed)."""
+    lib = _capi.load()
+    a = _capi.HGemmArgs()
+    assert lib.gad_hgemm(ctypes.byref(a), None) != 0 and b"null" in lib.gad_last_error()
+    a.A = a.B = a.C = 4096
+    a.M, a.N, a.K, a.lda, a.ldb, a.ldc, a.k_split = 64, 64, 36, 40, 40, 64, 36
+    assert lib.gad_hgemm(ctypes.byref(a), None) != 0 and b"multiples of 8" in lib.gad_last_error()      # K % 8
+    a.K = a.k_split = 40
+    a.A = 4098
+    assert lib.gad_hgemm(ctypes.byref(a), None) != 0 and b"aligned" in lib.gad_last_error()
+    assert lib.gad_hgemm_workspace_bytes(ctypes.byref(a)) < 0
+
+    def plan(M, N, K, conv=False, out_f32=False):
+        g = _capi.HGemmArgs()
+        g.A = g.B = g.C = 4096
+        g.M, g.N, g.K, g.ldb, g.ldc, g.out_f32 = M, N, K, K, N, int(out_f32)
+        if conv:
+            cin = K // 9
+            hw = int(round((M // 16) ** 0.5))
+            g.conv, g.KH, g.KW, g.Cin, g.H, g.W, g.Ho, g.Wo, g.stride, g.pad_t, g.pad_l = 1, 3, 3, cin, hw, hw, hw, hw, 1, 1, 1
+            g.lda, g.k_split = cin, cin
+        else:
+            g.lda, g.k_split = K, K
+        tile, sk = ctypes.c_int32(), ctypes.c_int32()
+        assert lib.gad_hgemm_plan(ctypes.byref(g), ctypes.byref(tile), ctypes.byref(sk)) == 0, lib.gad_last_error()
+        need = lib.gad_hgemm_workspace_bytes(ctypes.byref(g))
+        assert need == (sk.value * M * N * 4 if sk.value > 1 else 0)
+        return tile.value, sk.value
+    assert plan(65536, 320, 2880, conv=True) == (6, 1)             # 64x64 maps: one round of 256 x 320 tiles on eight waves
+    assert plan(16384, 640, 5760, conv=True) == (6, 2)             # 32x32 maps: the same form, two K slices
+    assert plan(4096, 1280, 11520, conv=True) == (6, 4)
+    t, sk = plan(1024, 1280, 11520, conv=True)                     # 8x8 maps: 128 x 320 tiles, split
+    assert t == 7 and sk >= 8
+    assert plan(65536, 2560, 320) == (7, 1)                        # GEGLU projection: full rounds of 128 x 320
+    assert plan(65536, 256, 320) == (8, 1)                         # LoRA rank products: 128 x 128, four workgroups per CU
+    assert plan(4096, 1280, 1280) == (1, 1)                        # 16x16 level Linear: more 128 x 128 tiles than 128 x 320 ones
+    assert plan(65536, 4, 2880, conv=True)[0] in (1, 8)            # conv_out
