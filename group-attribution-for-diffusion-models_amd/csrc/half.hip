@@ -613,6 +613,33 @@ __global__ __launch_bounds__(256) void transpose16_kernel(const u16* __restrict_
   }
 }
 
+// bf16 shadows of every 2-D matrix resident in a flat fp32 parameter buffer, in ONE launch per optimizer step: dst[off + r * cols + c] =
+// bf16(src[off + r * cols + c]) and dst_t[off + c * rows + r] = the same value (the transpose at the same offset).  table rows of five
+// int64 {off, rows, cols, r0, c0}: one 64 x 64 tile each.  The LoRA matrices: down / up for the forward products, their transposes for
+// the data gradients (dmid = dy up, dx += dmid down read them as [n][k] operands).
+__global__ __launch_bounds__(256) void shadow_pair_kernel(const float* __restrict__ src, u16* __restrict__ dst, u16* __restrict__ dst_t,
+                                                          const long* __restrict__ table) {
+  __shared__ u16 tile[64][66];
+  const long* row = table + 5L * blockIdx.x;
+  const long off = row[0];
+  const int rows = (int)row[1], cols = (int)row[2], r0 = (int)row[3], c0 = (int)row[4];
+  const int tx = threadIdx.x & 63, ty = threadIdx.x >> 6;
+  for (int i = ty; i < 64; i += 4) {
+    const int r = r0 + i, c = c0 + tx;
+    u16 v = 0;
+    if (r < rows && c < cols) {
+      v = f2bf(src[off + (long)r * cols + c]);
+      dst[off + (long)r * cols + c] = v;
+    }
+    tile[i][tx] = v;
+  }
+  __syncthreads();
+  for (int i = ty; i < 64; i += 4) {
+    const int c = c0 + i, r = r0 + tx;
+    if (c < cols && r < rows) dst_t[off + (long)c * rows + r] = tile[tx][i];
+  }
+}
+
 __global__ void cast_to_bf16_kernel(const float* __restrict__ src, u16* __restrict__ dst, long n) {
   long i = ((long)blockIdx.x * blockDim.x + threadIdx.x) * 8;
   const long stride = (long)gridDim.x * blockDim.x * 8;
@@ -1188,6 +1215,13 @@ static unsigned ew_grid(long work) {
   if (g > 8192) g = 8192;
   if (g < 1) g = 1;
   return (unsigned)g;
+}
+extern "C" int gad_h_shadow_pairs(const float* src, void* dst, void* dst_t, const int64_t* table, int32_t n_tiles, void* stream) {
+  GAD_CHECK(src && dst && dst_t && table && n_tiles > 0, "gad_h_shadow_pairs: bad arguments");
+  static_assert(sizeof(long) == sizeof(int64_t), "table rows are 64-bit");
+  hipLaunchKernelGGL(shadow_pair_kernel, dim3((unsigned)n_tiles), dim3(256), 0, (hipStream_t)stream, src, (u16*)dst, (u16*)dst_t, (const long*)table);
+  GAD_LAUNCH_CHECK("h_shadow_pairs");
+  return 0;
 }
 extern "C" int gad_h_cast(const void* src, void* dst, int64_t n, int32_t to_f32, void* stream) {
   GAD_CHECK(src && dst && n > 0 && gad_aligned16(src) && gad_aligned16(dst), "gad_h_cast: bad arguments");

@@ -153,6 +153,7 @@ SIGNATURES = {
     "gad_hgemm_tn": (C.c_int, [C.POINTER(HGemmArgs), _vp]),
     "gad_h_transpose": (C.c_int, [_vp, _vp, _i32, _i32, _i32, _i32, _i32, _vp]),
     "gad_h_cast": (C.c_int, [_vp, _vp, _i64, _i32, _vp]),
+    "gad_h_shadow_pairs": (C.c_int, [_vp, _vp, _vp, _vp, _i32, _vp]),
     "gad_h_add": (C.c_int, [_vp, _vp, _vp, _i64, _vp]),
     "gad_h_groupnorm_workspace_bytes": (_i64, [C.POINTER(GroupNormArgs)]),
     "gad_h_groupnorm_silu_fwd": (C.c_int, [C.POINTER(GroupNormArgs), _vp]),

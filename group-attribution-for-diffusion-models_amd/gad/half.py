@@ -139,23 +139,39 @@ def half_weight_rot(w):
     return _cached(w, "_gad_hrot", make)
 
 
-def _flat_half(flat):
-    """ONE bf16 cast of a whole flat parameter buffer per optimizer step (the LoRA matrices all live in one:
-    training.flatten_params); slices of it serve every projection."""
+def _flat_pairs(flat):
+    """(bf16 shadow, bf16 shadow of the transposes) of every 2-D matrix resident in a flat parameter buffer, refreshed by ONE launch
+    per optimizer step (gad_h_shadow_pairs); the table of 64 x 64 tiles is built once per buffer."""
     key = (flat._version, ops.WEIGHT_EPOCH[0], getattr(flat, "_gad_epoch", 0))
-    c = getattr(flat, "_gad_hflat", None)
-    if c is None or c[0] != key:
-        c = (key, to_half(flat.detach()))
-        flat._gad_hflat = c
-    return c[1]
+    c = getattr(flat, "_gad_hpairs", None)
+    if c is None:
+        rows = [(off, p_.shape[0], p_.shape[1], a, b) for p_, off, _ in getattr(flat, "_gad_params", ()) if p_.ndim == 2
+                for a in range(0, p_.shape[0], 64) for b in range(0, p_.shape[1], 64)]
+        table = torch.tensor(rows, dtype=torch.int64, device=flat.device)
+        c = [None, torch.zeros(flat.numel(), device=flat.device, dtype=BF16), torch.zeros(flat.numel(), device=flat.device, dtype=BF16),
+             table, len(rows), {}]
+        flat._gad_hpairs = c
+    versions = {o_: p_._version for p_, o_, _ in getattr(flat, "_gad_params", ())}
+    if c[0] != key or c[5] != versions:
+        check(_capi.load().gad_h_shadow_pairs(flat.data_ptr(), c[1].data_ptr(), c[2].data_ptr(), c[3].data_ptr(), c[4], _st()), "gad_h_shadow_pairs")
+        c[0], c[5] = key, versions
+    return c[1], c[2]
 
 
 def _half_of(w):
     """bf16 copy of a 2-D parameter: a slice of its flat buffer's shadow where it lives in one"""
     if ops._in_flat_buffer(w):
         flat, off, n = w._gad_flat
-        return _flat_half(flat)[off:off + n].view(w.shape)
+        return _flat_pairs(flat)[0][off:off + n].view(w.shape)
     return to_half(w.detach())
+
+
+def _half_t_of(w):
+    """bf16 transpose [cols][rows] of a 2-D parameter (slice of the flat buffer's transposed shadow where it lives in one)"""
+    if ops._in_flat_buffer(w):
+        flat, off, n = w._gad_flat
+        return _flat_pairs(flat)[1][off:off + n].view(w.shape[1], w.shape[0])
+    return transpose_raw(to_half(w.detach()))
 
 
 def lora_half(down, up):
@@ -168,8 +184,12 @@ def lora_half(down, up):
         r, K = down.shape
         N = up.shape[0]
         r8 = (r + 7) // 8 * 8
+        if r8 == r and N % 8 == 0 and K % 8 == 0:
+            c = (key, (_half_of(down), _half_of(up), _half_t_of(down), _half_t_of(up)))
+            down._gad_hlora = c
+            return c[1]
         if r8 == r:
-            dh, uh = _half_of(down), _half_of(up)
+            dh, uh = to_half(down.detach()), to_half(up.detach())
         else:
             dh = torch.zeros((r8, K), device=down.device, dtype=BF16)
             uh = torch.zeros((N, r8), device=down.device, dtype=BF16)

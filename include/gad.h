@@ -432,6 +432,11 @@ int gad_hgemm_tn(const gad_hgemm_args* a, void* stream);
  * LoRA matrices' transposes */
 int gad_h_transpose(const void* src, void* dst, int32_t rows, int32_t cols, int32_t ld_src, int32_t ld_dst, int32_t src_f32,
                     void* stream);
+/* bf16 shadows of the 2-D matrices resident in a flat fp32 parameter buffer (the LoRA matrices of training.flatten_params), ONE launch
+ * per optimizer step: dst[off + r*cols + c] = dst_t[off + c*rows + r] = bf16(src[off + r*cols + c]).  table (device, int64[n_tiles][5]) =
+ * {off, rows, cols, r0, c0}: one 64 x 64 tile of one matrix per row.  The copies feed the forward products, the transposes the data
+ * gradients (text_to_image/train_text_to_image_lora.py:1305 loss.backward() through LoRALinearLayer). */
+int gad_h_shadow_pairs(const float* src, void* dst, void* dst_t, const int64_t* table, int32_t n_tiles, void* stream);
 /* dst = bf16(src) (to_f32 == 0: src fp32) or dst = fp32(src) (to_f32 != 0: src bf16) */
 int gad_h_cast(const void* src, void* dst, int64_t n, int32_t to_f32, void* stream);
 /* GroupNorm (+ SiLU) with bf16 x / y / dy / dx, fp32 gamma / beta / mean / rstd: the fields of gad_groupnorm_args read as
