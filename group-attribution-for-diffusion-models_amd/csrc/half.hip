@@ -149,7 +149,6 @@ __device__ __forceinline__ void barrier_vm() {          // all but this wave's N
 // ---------------------------------------------------------------------------------------------------------------
 template <int WM, int WN, int TM, int TN, int BKT, int NST, bool ROLES, int GATHER, bool MF16 = false>
 __global__ __launch_bounds__(WM* WN * 64, (NST == 2 || WM * WN == 8) ? 2 : 1) void hgemm_kernel(const HDev p) {
-  static_assert(!MF16 || BKT == 32, "the 16x16x32 form is built for 32-deep K steps");
   constexpr int NW = WM * WN, BM = WM * TM * 32, BN = WN * TN * 32;
   constexpr int CPR = BKT / 8, RPI = 64 / CPR;             // 16-B chunks per tile row; tile rows per DMA wave-instruction
   constexpr int NWA = ROLES ? NW / 2 : NW, NWB = NWA;      // waves that issue A / B DMAs
@@ -297,17 +296,20 @@ __global__ __launch_bounds__(WM* WN * 64, (NST == 2 || WM * WN == 8) ? 2 : 1) vo
   auto compute = [&](int buf) {
     const unsigned char* sb = lds + buf * STAGE;
     if constexpr (MF16) {
-      // lane = (row l & 15, 8 k of chunk l >> 4): one ds_read_b128 per 16-row fragment and 32-deep step; rows 16 apart share the swizzle
-      const int off = (g4 ^ swl) * 16;
-      bf16x8 af[2 * TM], bfr[2 * TN];
+      // lane = (row l & 15, 8 k of chunk l >> 4 of a 32-deep block): one ds_read_b128 per 16-row fragment and block; rows 16 apart share the swizzle
 #pragma unroll
-      for (int i = 0; i < 2 * TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 16 * BKT * 2 + off);
+      for (int kb = 0; kb < BKT / 32; ++kb) {
+        const int off = ((4 * kb + g4) ^ swl) * 16;
+        bf16x8 af[2 * TM], bfr[2 * TN];
 #pragma unroll
-      for (int j = 0; j < 2 * TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * 16 * BKT * 2 + off);
+        for (int i = 0; i < 2 * TM; ++i) af[i] = *reinterpret_cast<const bf16x8*>(sb + a_base + i * 16 * BKT * 2 + off);
 #pragma unroll
-      for (int i = 0; i < 2 * TM; ++i)
+        for (int j = 0; j < 2 * TN; ++j) bfr[j] = *reinterpret_cast<const bf16x8*>(sb + b_base + j * 16 * BKT * 2 + off);
 #pragma unroll
-        for (int j = 0; j < 2 * TN; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc4[i][j], 0, 0, 0);
+        for (int i = 0; i < 2 * TM; ++i)
+#pragma unroll
+          for (int j = 0; j < 2 * TN; ++j) acc4[i][j] = __builtin_amdgcn_mfma_f32_16x16x32_bf16(af[i], bfr[j], acc4[i][j], 0, 0, 0);
+      }
     } else {
 #pragma unroll
       for (int kk = 0; kk < BKT / 16; ++kk) {
@@ -1014,12 +1016,13 @@ static HPlan hgemm_plan(const gad_hgemm_args* a) {
   const bool fits32 = amax < (1L << 31) && (long)a->N * (a->ldb > a->ldb2 ? a->ldb : a->ldb2) < (1L << 31);
   const long tiles8 = ((a->M + 255) / 256) * ((a->N + 319) / 320);
   const int hint = a->tile_hint % 100;
-  if (hint == 1 || hint == 2 || (hint >= 5 && hint <= 8)) tile = hint;
+  if (hint == 1 || hint == 2 || (hint >= 5 && hint <= 9)) tile = hint;
   else if (a->N % 320 != 0) tile = 1;
   else if (long_k) tile = tiles8 >= 48 ? 6 : 7;                    // 3x3 convolutions: the eight-wave form (one round of tiles, or of K slices); 8x8 maps: 128 x 320 split
   else if (tiles2 >= 400) tile = 7;                                // Linears with a full round of 128 x 320 tiles
   else tile = tiles1 * 2 > tiles2 * 3 ? 1 : 7;
   if (tile == 1 && hint == 0 && tiles1 >= 512 && a->K <= 4096) tile = 8;     // enough 128 x 128 tiles for four workgroups per CU: the 32 KB form
+  else if (tile == 1 && hint == 0 && a->N >= 640) tile = 9;                   // 16x16 level Linears: the 64-deep form on 16x16x32 MFMAs (+5-10 %)
   // (forms 6 / 7 = the 256 x 320 / 128 x 320 tiles on v_mfma_f32_16x16x32_bf16: +6-12 % over the 32x32x16 forms 5 / 2 on the convolutions,
   //  +3-8 % on the Linears - profiles/r04_ab_hgemm.txt; 5 / 2 stay for A/B)
   pl.tile = tile;
@@ -1185,6 +1188,7 @@ extern "C" int gad_hgemm(const gad_hgemm_args* a, void* stream) {
   else if (pl.tile == 5) rc = hgemm_launch<4, 2, 2, 5, 32, 4, true>(d, st);
   else if (pl.tile == 6) rc = hgemm_launch<4, 2, 2, 5, 32, 4, true, true>(d, st);       // A/B: the eight-wave form on 16x16x32 MFMAs
   else if (pl.tile == 7) rc = hgemm_launch<2, 2, 2, 5, 32, 2, false, true>(d, st);      // 128 x 320 on 16x16x32 MFMAs
+  else if (pl.tile == 9) rc = hgemm_launch<2, 2, 2, 2, 64, 2, false, true>(d, st);      // 128 x 128, 64-deep steps, 16x16x32 MFMAs
   else if (pl.tile == 8) rc = hgemm_launch<2, 2, 2, 2, 32, 2, false, true>(d, st);      // 128 x 128, 32-deep steps, 16x16x32 MFMAs: 32 KB of LDS, four workgroups per CU
   else { gad_set_error("gad_hgemm: tile_hint %d", pl.tile); return 1; }
   if (rc) return rc;

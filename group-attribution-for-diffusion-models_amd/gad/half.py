@@ -274,7 +274,7 @@ def linear_raw(x2d, wh, bias=None, residual=None, alpha=1.0, A2=None, B2=None, o
     return y
 
 
-def wgrad_raw(dy2d, x2d, out, accumulate, alpha=1.0):
+def wgrad_raw(dy2d, x2d, out, accumulate, alpha=1.0, splitk_hint=0):
     """out[N][K] (fp32) (+)= alpha * dy2d[M][:N]^T x2d[M][:K]: the LoRA parameter gradients (N, K = out's shape; the operands may
     carry zero pad columns).  A contraction over the token axis M with both operands read in place (gad_hgemm_tn: transposing LDS
     reads), split along M."""
@@ -284,7 +284,7 @@ def wgrad_raw(dy2d, x2d, out, accumulate, alpha=1.0):
     a.A, a.B, a.C = dy2d.data_ptr(), x2d.data_ptr(), out.data_ptr()
     a.M, a.N, a.K = N, K, dy2d.shape[0]
     a.lda, a.ldb, a.ldc = dy2d.stride(0), x2d.stride(0), out.stride(0)
-    a.alpha, a.out_f32, a.accumulate = alpha, 1, int(accumulate)
+    a.alpha, a.out_f32, a.accumulate, a.splitk_hint = alpha, 1, int(accumulate), splitk_hint
     need = lib.gad_hgemm_tn_workspace_bytes(C.byref(a))
     if need < 0:
         raise _capi.GadError(f"gad_hgemm_tn: {lib.gad_last_error().decode()}")

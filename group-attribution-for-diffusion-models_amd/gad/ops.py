@@ -351,7 +351,7 @@ class GemmProfiler:
             a_elems = a.M * a.K
         nbytes = 2.0 * (a_elems + a.N * a.K + (a.M * a.N if a.residual else 0)) + (4.0 if a.out_f32 else 2.0) * a.M * a.N
         flops = 2.0 * a.M * a.N * a.K
-        self.records.append(((name, {1: 128, 2: 320, 5: 256320, 6: 256320, 7: 320, 8: 128}[tile.value], sk.value, 8), flops, nbytes, s, e, flops, None))
+        self.records.append(((name, {1: 128, 2: 320, 5: 256320, 6: 256320, 7: 320, 8: 128, 9: 128}[tile.value], sk.value, 8), flops, nbytes, s, e, flops, None))
 
     def attention(self, fn, a, what, elem_bytes=4):
         """Bracket a fused attention launch.  Algorithmic FLOPs: forward 4 B h Tq Tk d (Q K^T and P V), backward

@@ -414,11 +414,11 @@ typedef struct gad_hgemm_args {
   int32_t ldr;
   int32_t out_f32, accumulate;
   void* ws; int64_t ws_bytes;
-  int32_t tile_hint;        /* 0 auto; 1: 128 x 128; 2 / 7: 128 x 320 on 32x32x16 / 16x16x32 MFMAs; 5 / 6: 256 x 320, eight waves (tests, A/B) */
+  int32_t tile_hint;        /* 0 auto; 1 / 9 / 8: 128 x 128 (32x32x16 / 16x16x32 MFMAs / 32-deep steps); 2 / 7: 128 x 320; 5 / 6: 256 x 320, eight waves */
   int32_t splitk_hint;      /* 0 auto; > 0 force                                                                */
 } gad_hgemm_args;
 int64_t gad_hgemm_workspace_bytes(const gad_hgemm_args* a);
-int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: 1 / 2 / 5 / 6 / 7 as tile_hint */
+int gad_hgemm_plan(const gad_hgemm_args* a, int32_t* tile, int32_t* splitk);   /* tile: as tile_hint */
 int gad_hgemm(const gad_hgemm_args* a, void* stream);
 /* The token-axis contraction of the LoRA parameter gradients (dB = dy^T mid, dA = dmid^T x, G = dy^T x:
  * train_text_to_image_lora.py:1305 loss.backward() through LoRALinearLayer): C[m][n] = alpha * sum_k A[k][m] B[k][n], BOTH operands

@@ -42,7 +42,7 @@ DENSE = [  # M, N, K, tile_hint, splitk_hint
     (256, 320, 320, 0, 0), (300, 320, 328, 0, 0), (128, 640, 64, 2, 0), (1000, 256, 320, 0, 0), (130, 72, 40, 0, 0),
     (77 * 2, 128, 96, 0, 0), (512, 320, 1280, 0, 3), (256, 128, 2048, 1, 4), (129, 321, 72, 1, 0), (640, 960, 192, 2, 2),
     (64, 4, 2880, 0, 0), (512, 320, 320, 5, 0), (700, 640, 328, 5, 0), (256, 960, 1280, 5, 3), (1000, 320, 64, 5, 0),
-    (700, 640, 328, 6, 0), (300, 320, 328, 7, 0), (256, 960, 1280, 6, 3), (1000, 256, 328, 8, 0), (130, 72, 40, 8, 2),
+    (700, 640, 328, 6, 0), (300, 320, 328, 7, 0), (256, 960, 1280, 6, 3), (1000, 256, 328, 8, 0), (130, 72, 40, 8, 2), (1000, 256, 328, 9, 0), (129, 321, 72, 9, 2),
 ]
 
 
