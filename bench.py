@@ -549,7 +549,7 @@ def measure(a, name, steps, warmup, env, headline):
             dist.barrier()
         torch.cuda.synchronize(dev)
 
-    prof, dt_train, n_tr, run = None, 0.0, 0, None
+    prof, dt_train, n_tr, run, dt_prof = None, 0.0, 0, None, None
     if a.full_coalition:
         for i in range(warmup):
             engine.run_coalition(10_000 + rank)
@@ -579,7 +579,13 @@ def measure(a, name, steps, warmup, env, headline):
             run.slice()
         log("timed region")
         barrier()
-        if not a.no_kernel_timing:
+        # The half-precision SD step is launch-bound on the host side (2 900 short launches per step): two events + a plan query around
+        # every contraction cost ~10 ms of host time per step there and would be what the timed region measures.  Its timed region
+        # therefore runs the product path as it is, and the SAME K steps are run once more right after it with the brackets on
+        # (`dt_prof`): the per-kernel table and the roofline come from that pass (as the CIFAR workloads' one_stream_* keys do).
+        separate_pass = wl["kind"] == "sd" and a.precision == "bf16" and not a.no_kernel_timing
+        dt_prof = None
+        if not a.no_kernel_timing and not separate_pass:
             prof = ops.GemmProfiler()
             ops.PROFILER = prof
         t0 = time.time()
@@ -589,6 +595,16 @@ def measure(a, name, steps, warmup, env, headline):
         dt = time.time() - t0
         log(f"timed region done: {dt:.2f}s for {steps} steps")
         ops.PROFILER = None
+        if separate_pass:
+            prof = ops.GemmProfiler()
+            ops.PROFILER = prof
+            t1 = time.time()
+            for _ in range(steps):
+                run.slice()
+            barrier()
+            dt_prof = time.time() - t1
+            ops.PROFILER = None
+            log(f"instrumented pass done: {dt_prof:.2f}s for {steps} steps")
         if wl["kind"] == "cifar":
             units = steps * world / float(GD_STEPS)
             # second half of BASELINE's metric: U-Net training steps/s (B=128, fwd+bwd+clip+Adam+EMA), outside the timed region
@@ -701,7 +717,13 @@ def measure(a, name, steps, warmup, env, headline):
         out["vs_baseline"] = None
     if prof is not None:
         torch.cuda.synchronize(dev)
-        out["roofline"], out["contraction_kernels"], all_fl, all_ex = kernel_report(prof, dt, peak_tf, a.precision, name)
+        out["roofline"], out["contraction_kernels"], all_fl, all_ex = kernel_report(prof, dt_prof if dt_prof else dt, peak_tf, a.precision, name)
+        if dt_prof:
+            out["roofline"]["measured"] = ("per-launch HIP-event brackets in a SEPARATE pass of the same K steps right after the timed region: this step is "
+                                           "launch-bound on the host, and the brackets (two events + a plan query per contraction) cost about 10 ms of host "
+                                           "time per step - the timed region (`value`, `ms_per_step`) runs the product path without them; shares are of the "
+                                           "instrumented pass's step time")
+            out["instrumented_pass"] = {"ms_per_step": dt_prof / steps * 1e3, "steps": steps}
         out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs (direct-form count) of every contraction / attention launch
         out["unet_tflops_executed_per_gpu"] = all_ex / dt / 1e12   # the MFMA work issued (Winograd launches: 36/144 or 16/36 of the direct count)
         out["path_mfma_frac"] = out["unet_tflops_executed_per_gpu"] / peak_tf        # whole path, executed work / step time / peak: <= 1

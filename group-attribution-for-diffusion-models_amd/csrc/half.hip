@@ -10,8 +10,9 @@
 //     (rotated weights), a stride-2 / upsample-fused convolution and a dense GEMM are the same kernel;
 //   * LDS tile images are [row][BK] bf16 with the 16-B chunk index XOR-swizzled by the row (applied to the DMA's SOURCE chunk
 //     and to the fragment read), which makes every ds_read_b128 of a 32-row fragment conflict-free;
-//   * tiles: 128 x 320 (SD channel counts 320 / 640 / 960 / 1280 / 1920 / 2560 are all multiples of 320: no column waste)
-//     and 128 x 128 (everything else: LoRA ranks, 4-channel conv_out, ragged shapes); two workgroups per CU.
+//   * tiles: 256 x 320 on eight waves / 128 x 320 (SD channel counts 320 / 640 / 960 / 1280 / 1920 / 2560 are all multiples of 320: no
+//     column waste) and 128 x 128 (everything else: LoRA ranks, 4-channel conv_out, the 16x16 level's Linears, ragged shapes);
+//   * hgemm_tn_kernel contracts over the TOKEN axis with both operands read in place (the LoRA parameter gradients).
 #include "gad_common.h"
 
 namespace gadh {
@@ -19,7 +20,6 @@ namespace gadh {
 typedef unsigned short u16;
 typedef __bf16 bf16x8 __attribute__((ext_vector_type(8)));
 typedef unsigned int u32x4 __attribute__((ext_vector_type(4)));
-typedef unsigned int u32x2 __attribute__((ext_vector_type(2)));
 
 static __device__ __attribute__((aligned(64))) unsigned int g_zero[16];   // the DMA source of padding / out-of-range chunks
 
@@ -990,6 +990,7 @@ static int hgemm_check(const gad_hgemm_args* a) {
   if (a->conv) {
     GAD_CHECK(a->conv == 1 || a->conv == 2, "gad_hgemm: conv mode %d", a->conv);
     GAD_CHECK(a->KH > 0 && a->KW > 0 && a->Cin > 0 && a->K == a->KH * a->KW * a->Cin, "gad_hgemm: K != KH*KW*Cin");
+    GAD_CHECK(a->H > 0 && a->W > 0 && a->Ho > 0 && a->Wo > 0 && a->stride > 0, "gad_hgemm: bad convolution geometry");
     GAD_CHECK(a->k_split > 0 && a->k_split <= a->Cin && (a->k_split == a->Cin || a->A2), "gad_hgemm: bad channel split");
     GAD_CHECK(a->M % (a->Ho * a->Wo) == 0, "gad_hgemm: M is not a whole number of %d x %d maps", a->Ho, a->Wo);
     GAD_CHECK((long)(a->M / (a->Ho * a->Wo)) * a->H * a->W * (long)(a->lda > a->lda2 ? a->lda : a->lda2) < (1L << 40), "gad_hgemm: tensor too large");

@@ -29,11 +29,16 @@ def _stream():
     return C.c_void_p(torch.cuda.current_stream().cuda_stream)
 
 
+_raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
+
+
 def workspace(device) -> torch.Tensor:
     """One caller-owned scratch buffer per device AND stream (split-K partials, reduction partials): launches on one stream are
     ordered, so they can share it; two coalitions in flight on two streams (a training phase beside a sampling phase,
     coalition.run_pipelined) must not.  Allocated once per stream so that hipGraph replays see a fixed address."""
-    key = (device.type, device.index, torch.cuda.current_stream(device).cuda_stream)
+    stream = _raw_stream(device.index if device.index is not None else torch.cuda.current_device()) if _raw_stream is not None \
+        else torch.cuda.current_stream(device).cuda_stream
+    key = (device.type, device.index, stream)
     ws = _WS.get(key)
     if ws is None:
         ws = torch.empty(WS_BYTES, dtype=torch.uint8, device=device)

@@ -401,6 +401,28 @@ def test_sd_unet_half_activations_vs_fp32():
             assert torch.dot(a, b) / (a.norm() * b.norm()) > 0.97, n
 
 
+def test_sd_unet_half_sampling_of_a_trainable_model_and_refusal_to_train_the_base():
+    """A model whose base parameters still require grad samples fine under no_grad on the half path (nothing wants their
+    gradients); asking autograd for them is an error, never a silent zero gradient."""
+    import gad
+    from gad import _capi
+    from test_gpu_sd import SMALL
+    torch.manual_seed(0)
+    net = gad.UNet2DConditionModel(**SMALL).to(dev)
+    assert all(p.requires_grad for p in net.parameters())
+    x, ctx, t = rnd(2, 4, 16, 16, seed=1).to(dev), rnd(2, 77, 96, seed=2).to(dev), torch.tensor([5, 800]).to(dev)
+    y32 = net(x, t, ctx).sample.detach()
+    try:
+        gad.set_operand_precision("bf16")
+        with torch.no_grad():
+            y16 = net(x, t, ctx).sample
+        with pytest.raises(_capi.GadError):
+            net(x, t, ctx)
+    finally:
+        gad.set_operand_precision("no")
+    assert ((y16 - y32).norm() / y32.norm()).item() < 3e-2
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # out-of-bounds canaries (as tests/test_gpu_guards.py does for the fp32-storage kernels): every output of the half path at its exact
 # shape and every caller-owned scratch region at EXACTLY the size the C ABI's query returns, each between poisoned bands
