@@ -229,8 +229,11 @@ class SDRunner:
         self.n_lora = sum(p.numel() for p in lora)
         self.n_base = sum(p.numel() for p in self.net.parameters()) - self.n_lora
         sched = gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+        from gad import ops
+        # the half-precision step is launch-bound on the host (~2 900 launches): replay it from a hipGraph (same kernels, same order)
         self.trainer = gad.FusedTrainer(self.net, sched, None, lr=3e-4, weight_decay=1e-6, adamw=True, max_grad_norm=1.0,
-                                        params=lora, lr_schedule=gad.lr_lambda("cosine", 200, 0))
+                                        params=lora, lr_schedule=gad.lr_lambda("cosine", 200, 0),
+                                        use_graph=ops.half_activations() and not os.environ.get("GAD_NO_TRAIN_GRAPH"))
         g = torch.Generator(device=dev).manual_seed(seed)
         n_cache = 8 * batch                          # latent cache + per-sample text embeddings, resident in HBM
         self.latents = torch.randn(n_cache, 4, latent, latent, device=dev, generator=g) * 0.8
@@ -596,6 +599,7 @@ def measure(a, name, steps, warmup, env, headline):
         log(f"timed region done: {dt:.2f}s for {steps} steps")
         ops.PROFILER = None
         if separate_pass:
+            graphed, run.trainer.use_graph = run.trainer.use_graph, False          # the brackets need eager launches
             prof = ops.GemmProfiler()
             ops.PROFILER = prof
             t1 = time.time()
@@ -604,6 +608,7 @@ def measure(a, name, steps, warmup, env, headline):
             barrier()
             dt_prof = time.time() - t1
             ops.PROFILER = None
+            run.trainer.use_graph = graphed
             log(f"instrumented pass done: {dt_prof:.2f}s for {steps} steps")
         if wl["kind"] == "cifar":
             units = steps * world / float(GD_STEPS)
@@ -724,6 +729,7 @@ def measure(a, name, steps, warmup, env, headline):
                                            "time per step - the timed region (`value`, `ms_per_step`) runs the product path without them; shares are of the "
                                            "instrumented pass's step time")
             out["instrumented_pass"] = {"ms_per_step": dt_prof / steps * 1e3, "steps": steps}
+            config["train_step_graph"] = bool(getattr(run.trainer, "_graph", None)) and not run.trainer._graph_failed
         out["unet_tflops_per_gpu"] = all_fl / dt / 1e12            # algorithmic FLOPs (direct-form count) of every contraction / attention launch
         out["unet_tflops_executed_per_gpu"] = all_ex / dt / 1e12   # the MFMA work issued (Winograd launches: 36/144 or 16/36 of the direct count)
         out["path_mfma_frac"] = out["unet_tflops_executed_per_gpu"] / peak_tf        # whole path, executed work / step time / peak: <= 1

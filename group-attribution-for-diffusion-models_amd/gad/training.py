@@ -227,8 +227,13 @@ class FusedTrainer:
     the caller (so the RNG policy stays in the entry point)."""
 
     def __init__(self, model, scheduler, ema: EMAModel | None, lr=1e-4, betas=(0.9, 0.999), eps=1e-8,
-                 weight_decay=0.0, adamw=False, max_grad_norm=1.0, loss_sign=1.0, params=None, lr_schedule=None):
+                 weight_decay=0.0, adamw=False, max_grad_norm=1.0, loss_sign=1.0, params=None, lr_schedule=None, use_graph=False):
+        """`use_graph`: capture add_noise -> forward -> loss -> backward of one step into a hipGraph after `GRAPH_WARMUP` eager steps and
+        replay it from then on (the optimizer launch stays eager: its step count and learning rate are host scalars).  For steps that are
+        launch-bound on the host - the half-precision SD LoRA step issues ~2 900 short launches - : the same kernels in the same order,
+        bit-identical results, no per-launch host work.  Shapes must not change between steps; a capture that fails falls back to eager."""
         self.model, self.scheduler, self.ema = model, scheduler, ema
+        self.use_graph, self._graph, self._graph_failed = use_graph, None, False
         if params is None:                      # train everything (DDPM); else only `params` (LoRA: base frozen)
             self.flat, self.gflat = model.flatten_parameters() if model._flat is None else model.flat
             self.params = list(model.parameters())
@@ -248,9 +253,20 @@ class FusedTrainer:
         self._sumsq = torch.zeros(1, device=self.flat.device)
         self.last_loss = None
 
+    GRAPH_WARMUP = 2
+
     def step(self, image_nchw, noise_nchw, timesteps, *model_args, loss_weights=None):
         """`loss_weights` [B]: per-sample weights of the squared error (min-SNR-gamma weighting,
         train_text_to_image_lora.py:1276-1298): loss = mean_b w_b * mean_chw (eps_hat - eps)^2."""
+        if (self.use_graph and not self._graph_failed and self.step_count >= self.GRAPH_WARMUP
+                and all(torch.is_tensor(a_) for a_ in model_args)):
+            out = self._step_graphed(image_nchw, noise_nchw, timesteps, model_args, loss_weights)
+            if out is not None:
+                return out
+        return self._step_eager(image_nchw, noise_nchw, timesteps, *model_args, loss_weights=loss_weights)
+
+    def _forward_backward(self, image_nchw, noise_nchw, timesteps, model_args, loss_weights):
+        """add_noise -> U-Net -> loss (+ gradient) -> backward into the flat gradient buffer; -> loss [1]"""
         model = self.model
         noisy = self.scheduler.add_noise(image_nchw, noise_nchw, timesteps)
         eps = model(noisy, timesteps, *model_args).sample
@@ -270,9 +286,56 @@ class FusedTrainer:
             self._sinks_checked = True
         for v in self._unwritten:
             v.zero_()
+        return loss
+
+    def _step_eager(self, image_nchw, noise_nchw, timesteps, *model_args, loss_weights=None):
+        loss = self._forward_backward(image_nchw, noise_nchw, timesteps, model_args, loss_weights)
         self.optimizer_step()
         self.last_loss = loss
         return loss
+
+    def _step_graphed(self, image_nchw, noise_nchw, timesteps, model_args, loss_weights):
+        g = self._graph
+        sig = (tuple(image_nchw.shape), tuple(timesteps.shape), tuple(tuple(a_.shape) for a_ in model_args), loss_weights is not None)
+        if g is not None and g["sig"] != sig:
+            return None                                  # shapes changed: this step runs eagerly
+        if g is None:
+            try:
+                st = dict(sig=sig, image=torch.empty_like(image_nchw), noise=torch.empty_like(noise_nchw), t=torch.empty_like(timesteps),
+                          args=[torch.empty_like(a_) for a_ in model_args],
+                          w=torch.empty_like(loss_weights) if loss_weights is not None else None)
+                for dst, src in ((st["image"], image_nchw), (st["noise"], noise_nchw), (st["t"], timesteps), *zip(st["args"], model_args)):
+                    dst.copy_(src)
+                if st["w"] is not None:
+                    st["w"].copy_(loss_weights)
+                # derived weights (bf16 shadows of the LoRA buffer, ...) are refreshed by launches that key on the buffer's epoch: bump it so
+                # that the refresh is captured - a replay must re-derive them from the CURRENT weights
+                self.flat._gad_epoch = getattr(self.flat, "_gad_epoch", 0) + 1
+                graph = torch.cuda.CUDAGraph()
+                with torch.cuda.graph(graph):
+                    st["loss"] = self._forward_backward(st["image"], st["noise"], st["t"], st["args"], st["w"])
+                st["graph"] = graph
+                self._graph = g = st
+                # (the capture recorded the launches without running them: this step is done by the first replay below)
+            except Exception as e:                       # noqa: BLE001 - any capture failure means "run eagerly", never a lost step
+                self._graph_failed = True
+                self._graph = None
+                import warnings
+                warnings.warn(f"FusedTrainer: hipGraph capture of the training step failed ({type(e).__name__}: {e}); running eagerly")
+                torch.cuda.synchronize()
+                return None
+        else:
+            g["image"].copy_(image_nchw)
+            g["noise"].copy_(noise_nchw)
+            g["t"].copy_(timesteps)
+            for dst, src in zip(g["args"], model_args):
+                dst.copy_(src)
+            if g["w"] is not None:
+                g["w"].copy_(loss_weights)
+        g["graph"].replay()
+        self.optimizer_step()
+        self.last_loss = g["loss"]
+        return g["loss"]
 
     def optimizer_step(self):
         self.step_count += 1

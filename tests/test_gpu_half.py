@@ -423,6 +423,41 @@ def test_sd_unet_half_sampling_of_a_trainable_model_and_refusal_to_train_the_bas
     assert ((y16 - y32).norm() / y32.norm()).item() < 3e-2
 
 
+def test_graphed_training_step_equals_eager():
+    """FusedTrainer(use_graph=True): the half-path LoRA step replayed from a hipGraph leaves bit-identical weights, optimizer state and
+    losses to the eager launches (same kernels, same order), step after step with changing inputs and learning rate."""
+    import gad
+    from gad import ops
+    from test_gpu_sd import SMALL
+    sch = gad.DDPMScheduler(beta_start=0.00085, beta_end=0.012, beta_schedule="scaled_linear", num_train_timesteps=1000)
+    xs = [rnd(4, 4, 16, 16, seed=10 + i).to(dev) for i in range(6)]
+    ns = [rnd(4, 4, 16, 16, seed=20 + i).to(dev) for i in range(6)]
+    ts = [torch.randint(0, 1000, (4,), generator=torch.Generator().manual_seed(30 + i)).to(dev) for i in range(6)]
+    cs = [rnd(4, 77, 96, seed=40 + i).to(dev) for i in range(6)]
+
+    def run(use_graph):
+        torch.manual_seed(0)
+        net = gad.UNet2DConditionModel(**SMALL).to(dev)
+        lora = net.inject_lora(rank=8)
+        with torch.no_grad():
+            for n, p in net.named_parameters():
+                if n.endswith("lora_layer.up.weight"):
+                    p.copy_(rnd(*p.shape, seed=hash(n) % 1000, scale=0.02).to(dev))
+        tr = gad.FusedTrainer(net, sch, None, lr=3e-4, weight_decay=1e-6, adamw=True, max_grad_norm=1.0, params=lora,
+                              lr_schedule=gad.lr_lambda("cosine", 50, 0), use_graph=use_graph)
+        losses = [float(tr.step(xs[i], ns[i], ts[i], cs[i]).item()) for i in range(6)]
+        return tr, losses
+    try:
+        gad.set_operand_precision("bf16")
+        eager, le = run(False)
+        graphed, lg = run(True)
+    finally:
+        gad.set_operand_precision("no")
+    assert graphed._graph is not None and not graphed._graph_failed, "the step was not captured"
+    assert le == lg
+    assert torch.equal(eager.flat, graphed.flat) and torch.equal(eager.m, graphed.m) and torch.equal(eager.v, graphed.v)
+
+
 # ---------------------------------------------------------------------------------------------------------------
 # out-of-bounds canaries (as tests/test_gpu_guards.py does for the fp32-storage kernels): every output of the half path at its exact
 # shape and every caller-owned scratch region at EXACTLY the size the C ABI's query returns, each between poisoned bands
