@@ -230,7 +230,10 @@ def main(a, backend=None):
     trainer = backend.FusedTrainer(unet, sched, None, lr=a.learning_rate, betas=(a.adam_beta1, a.adam_beta2),
                                    eps=a.adam_epsilon, weight_decay=a.adam_weight_decay, adamw=True,
                                    max_grad_norm=a.max_grad_norm, params=lora_params,
-                                   lr_schedule=backend.lr_lambda(a.lr_scheduler, max_steps, a.lr_warmup_steps))
+                                   lr_schedule=backend.lr_lambda(a.lr_scheduler, max_steps, a.lr_warmup_steps),
+                                   # GAD_TRAIN_GRAPH=1: replay the step from a hipGraph (gad.FusedTrainer; for the launch-bound
+                                   # half-precision step; the injected test backend does not take the keyword)
+                                   **({"use_graph": True} if os.environ.get("GAD_TRAIN_GRAPH") else {}))
     time_file = os.path.join(model_outdir, "time.csv")
     if not os.path.exists(time_file):
         with open(time_file, "w") as f:
