@@ -240,6 +240,9 @@ class SDRunner:
         self.text = torch.randn(n_cache, 77, 768, device=dev, generator=g) * 0.5
         self.batch, self.dev = batch, dev
         self.perm, self.pos = torch.randperm(n_cache, device=dev), 0
+        if self.trainer.use_graph:                    # the one-time capture (two eager steps, then the capturing one) belongs to building the
+            for _ in range(self.trainer.GRAPH_WARMUP + 1):      # runner, not to the W warm-up / K timed steps of the contract
+                self.slice()
 
     def slice(self):
         if self.pos + self.batch > self.perm.numel():
