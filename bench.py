@@ -24,6 +24,7 @@ Each rank works on its own coalition (removal_seed = rank); the only collective 
 the per-rank records ("scaling": "weak").
 """
 import argparse
+import contextlib
 import json
 import os
 import sys
@@ -159,6 +160,16 @@ class SliceRunner:
                 m_, e_ = engine.load_base()
                 self.trainers.append(engine.make_trainer(m_, e_))
             self.turn = 0
+        if self.trainer.use_graph:                              # the one-time captures belong to building the runner, not to the W + K steps
+            keep = self.trainer
+            for i, tr in enumerate(self.trainers if self.streams is not None else [self.trainer]):
+                self.trainer = tr
+                ctx = torch.cuda.stream(self.streams[1 + i]) if self.streams is not None else contextlib.nullcontext()
+                with ctx:
+                    for _ in range(tr.GRAPH_WARMUP + 1):
+                        self.train_step()
+            self.trainer = keep
+            torch.cuda.synchronize(self.dev)
 
     def train_step(self):
         try:

@@ -206,6 +206,9 @@ class CoalitionEngine:
         # coalitions in flight on this GPU: 1 = strictly one after the other; k > 1 = the sampling phase of one beside the training
         # phases of the next k - 1, each on its own HIP stream (run_pipelined; what run_sharded / gad.launch use)
         self.in_flight = int(os.environ.get("GAD_IN_FLIGHT", "3"))
+        # the training step's add_noise -> forward -> loss -> backward replayed from a hipGraph (FusedTrainer(use_graph=True): the step is ~1 500
+        # short launches at B = 128 - host-bound when enqueued one by one; same kernels, same order, bit-identical records)
+        self.train_graph = os.environ.get("GAD_TRAIN_GRAPH", "0") == "1"
         self.num_inference_steps, self.opt_seed, self.by_class, self.preview = num_inference_steps, opt_seed, by_class, preview
         self.dataset = create_dataset(dataset_name, train=True)
         self.n_groups = len(set(self.dataset.targets))
@@ -241,7 +244,8 @@ class CoalitionEngine:
     def make_trainer(self, model, ema):
         kw = self.opt_kwargs
         return FusedTrainer(model, self.train_scheduler, ema, lr=kw.get("lr", 1e-4),
-                            weight_decay=kw.get("weight_decay", 0.0), adamw=self.adamw, max_grad_norm=1.0)
+                            weight_decay=kw.get("weight_decay", 0.0), adamw=self.adamw, max_grad_norm=1.0,
+                            use_graph=getattr(self, "train_graph", False))
 
     def score(self, images01: torch.Tensor) -> dict:
         """fid_value, is, precision, recall (unlearn.py:807-837) under the stand-in feature net."""

@@ -32,10 +32,16 @@ def _stream():
 _raw_stream = getattr(torch._C, "_cuda_getCurrentRawStream", None)
 
 
+WS_OVERRIDE = [None]         # a caller-provided workspace that replaces the per-stream one (FusedTrainer's graph capture: the launches recorded
+#                              into a hipGraph must not share scratch with other streams' work, whatever stream the capture ran on)
+
+
 def workspace(device) -> torch.Tensor:
     """One caller-owned scratch buffer per device AND stream (split-K partials, reduction partials): launches on one stream are
     ordered, so they can share it; two coalitions in flight on two streams (a training phase beside a sampling phase,
     coalition.run_pipelined) must not.  Allocated once per stream so that hipGraph replays see a fixed address."""
+    if WS_OVERRIDE[0] is not None:
+        return WS_OVERRIDE[0]
     stream = _raw_stream(device.index if device.index is not None else torch.cuda.current_device()) if _raw_stream is not None \
         else torch.cuda.current_stream(device).cuda_stream
     key = (device.type, device.index, stream)

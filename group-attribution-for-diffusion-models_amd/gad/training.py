@@ -311,9 +311,15 @@ class FusedTrainer:
                 # derived weights (bf16 shadows of the LoRA buffer, ...) are refreshed by launches that key on the buffer's epoch: bump it so
                 # that the refresh is captured - a replay must re-derive them from the CURRENT weights
                 self.flat._gad_epoch = getattr(self.flat, "_gad_epoch", 0) + 1
+                # scratch of the recorded launches: this graph's own (two trainers' graphs may replay on two streams at once)
+                st["ws"] = torch.empty(ops.WS_BYTES, dtype=torch.uint8, device=self.flat.device)
                 graph = torch.cuda.CUDAGraph()
-                with torch.cuda.graph(graph):
-                    st["loss"] = self._forward_backward(st["image"], st["noise"], st["t"], st["args"], st["w"])
+                prev, ops.WS_OVERRIDE[0] = ops.WS_OVERRIDE[0], st["ws"]
+                try:
+                    with torch.cuda.graph(graph):
+                        st["loss"] = self._forward_backward(st["image"], st["noise"], st["t"], st["args"], st["w"])
+                finally:
+                    ops.WS_OVERRIDE[0] = prev
                 st["graph"] = graph
                 self._graph = g = st
                 # (the capture recorded the launches without running them: this step is done by the first replay below)
@@ -334,8 +340,8 @@ class FusedTrainer:
                 g["w"].copy_(loss_weights)
         g["graph"].replay()
         self.optimizer_step()
-        self.last_loss = g["loss"]
-        return g["loss"]
+        self.last_loss = g["loss"].clone()          # (the static tensor is overwritten by the next replay)
+        return self.last_loss
 
     def optimizer_step(self):
         self.step_count += 1
