@@ -3095,6 +3095,13 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     float* Wy = (float*)a->wino_ws;
     float* V = Wy + wq.wy_bytes / 4;
     float* dU = V + wq.v_bytes / 4;
+    // the forward launch of the same convolution already made B^T x B (its V, same geometry => same [36][T][Cin] image): a caller
+    // that kept it passes it as B_wino4 with GAD_GEMM_WINO_SKIP_INPUT and the input transform is not run again
+    const bool have_v = (a->flags & GAD_GEMM_WINO_SKIP_INPUT) && a->B_wino4 != nullptr;
+    if (have_v) {
+      GAD_CHECK(gad_aligned16(a->B_wino4), "gad_gemm: the kept Winograd input image (B_wino4 of a weight-gradient launch) must be 16-byte aligned");
+      V = const_cast<float*>(a->B_wino4);
+    }
     WinoIn wy;                                     // dy [B][Ho][Wo][Cout] -> Wy
     wy.x = a->A; wy.V = Wy;
     wy.H = g.Ho; wy.W = g.Wo; wy.C = a->M; wy.ldx = a->lda; wy.up = 0;
@@ -3106,7 +3113,7 @@ extern "C" int gad_gemm(const gad_gemm_args* a, void* stream) {
     const long iy = wq.T * (a->M / 4), ix = wq.T * (g.C / 4);
     GAD_CHECK(gad_ceil_div(iy, 256) < (1L << 31) && gad_ceil_div(ix, 256) < (1L << 31), "gad_gemm: Winograd transform grid too large");
     hipLaunchKernelGGL(wino4_dy_kernel, dim3((unsigned)gad_ceil_div(iy, 256)), dim3(256), 0, st, wy);
-    hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(ix, 256)), dim3(256), 0, st, wi);
+    if (!have_v) hipLaunchKernelGGL(wino4_input_kernel, dim3((unsigned)gad_ceil_div(ix, 256)), dim3(256), 0, st, wi);
     GAD_LAUNCH_CHECK("gad_gemm(winograd wgrad transforms)");
     gad_gemm_args sub;
     wino_wgrad_sub(a, wq, Wy, V, dU, &sub);

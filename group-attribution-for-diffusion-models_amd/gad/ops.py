@@ -10,6 +10,7 @@ from __future__ import annotations
 
 import ctypes as C
 import math
+import os
 from typing import Optional
 
 import torch
@@ -202,6 +203,9 @@ OUT_ALLOC = None
 OUT_ALLOC_DT = None          # the same for the half path's outputs: (shape, device, dtype) -> tensor (gad/half.py::_empty)
 
 
+KEEP_WINO_V = [os.environ.get("GAD_KEEP_WINO_V", "1") != "0"]      # training: the forward's Winograd input image serves the weight gradient
+
+
 def _scratch(kind, nbytes, device):
     if SCRATCH_ALLOC is not None:
         return SCRATCH_ALLOC(kind, nbytes, device)
@@ -217,8 +221,12 @@ def _out(shape, device):
 def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Optional[ConvGeom] = None, alpha=1.0,
              bias=None, rowadd=None, rows_per_group=1, residual=None, ldr=0, batch=1, batch_inner=1,
              sA=(0, 0), sB=(0, 0), sC=(0, 0), tile_hint=0, splitk_hint=0, A2=None, a_split=0, B_bf16=None,
-             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False, wino_input=None, force_f32=False):
-    """`force_f32`: exact fp32 products whatever the process-wide operand precision (small parameter-gradient products).
+             A_k2=None, B_k2=None, k_split=0, B_wino=None, B_wino4=None, wino_wgrad=False, wino_input=None, force_f32=False,
+             keep_v=None, wino_v=None):
+    """`keep_v` (a list): a forward convolution that takes an F(4x4) Winograd route appends its scratch - the transformed
+    input V at its start - for the weight gradient of the same convolution, which takes it as `wino_v` and skips its own
+    input transform (training: Conv2dFn).
+    `force_f32`: exact fp32 products whatever the process-wide operand precision (small parameter-gradient products).
     `wino_input(V)`: the caller supplies the F(4x4) Winograd input transform itself (GroupNorm writing V directly,
     `gn_silu_conv3x3_raw`): if the planner puts this launch on an F(4x4) route the callback is run on the route's scratch and
     the convolution starts behind its input stage (-> True); on any other route nothing is launched (-> False)."""
@@ -257,6 +265,8 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
         if need:
             V = _scratch("wino", need, A.device)      # stream-ordered: safe to drop after the launch
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
+            if keep_v is not None and a.B_wino4 and lib.gad_gemm_kernel_id(C.byref(a)) == 6:
+                keep_v.append(V)
         else:
             a.B_wino = a.B_wino4 = None
     if wino_wgrad:                   # 3x3 weight gradient: the F(4x4) Winograd form where the planner models it faster
@@ -265,6 +275,9 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
         if need:
             V = _scratch("wino", need, A.device)
             a.wino_ws, a.wino_ws_bytes = V.data_ptr(), need
+            if wino_v is not None and wino_v.numel() >= 36 * (K // 16) * geom.C * 4:      # the forward launch's V: [36][pixels / 16][Cin] fp32
+                a.B_wino4 = wino_v.data_ptr()
+                a.flags |= _capi.GEMM_WINO_SKIP_INPUT
         else:
             a.flags &= ~_capi.GEMM_WINO_WGRAD
     if wino_input is not None:
@@ -410,7 +423,7 @@ def _conv_out_size(h, k, stride, pad_lo, pad_hi):
 
 
 def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowadd=None, residual=None,
-                   tile_hint=0, splitk_hint=0, x2=None, wino_input=None):
+                   tile_hint=0, splitk_hint=0, x2=None, wino_input=None, keep_v=None):
     """x [B,H,W,Cin] -> y [B,Ho,Wo,Cout]; pad = (top, bottom, left, right).
     x2 [B,H,W,C2]: the conv input is cat([x, x2], channels) without materialising it (UpBlock2D's skip concat)."""
     _req(x, "conv x")
@@ -439,7 +452,7 @@ def conv2d_fwd_raw(x, w, bias, stride=1, pad=(1, 1, 1, 1), upsample=False, rowad
     f4_maps = Ho % 4 == 0 and Wo % 4 == 0 and not KERNEL_FLAGS.get("no_wino4")
     launched = gemm_raw(x, wk, y, A_CONV, B_KC, Bn * Ho * Wo, Cout, KH * KW * Cin, 0, KH * KW * Cin, Cout, geom=g,
              bias=bias, rowadd=rowadd, rows_per_group=Ho * Wo, residual=residual, ldr=Cout,
-             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1, wino_input=wino_input,
+             tile_hint=tile_hint, splitk_hint=splitk_hint, A2=x2, a_split=C1, wino_input=wino_input, keep_v=keep_v,
              B_wino=wino_weight(w, 2) if (wino_ok and (tile_hint == 7 or (tile_hint == 0 and not f4_maps))) else None,
              B_wino4=wino_weight(w, 4) if (wino_ok and tile_hint != 7 and f4_maps) else None,
              B_bf16=bf16_weight(w) if (OPERAND_PRECISION[0] >= 1 and KH == 3 and Cin % 32 == 0 and x2 is None
@@ -709,9 +722,10 @@ def conv2d_dgrad_raw(dy, w, x_shape, stride=1, pad=(1, 1, 1, 1), upsample=False,
     return dx
 
 
-def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0, out=None):
+def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, tile_hint=0, splitk_hint=0, out=None, wino_v=None):
     """dW with the parameter's logical shape [Cout,Cin,KH,KW] and channels_last storage; `out` = a
-    [Cout,Cin,KH,KW] view with that storage to write into (flat gradient slot)."""
+    [Cout,Cin,KH,KW] view with that storage to write into (flat gradient slot); `wino_v` = the scratch the forward launch of
+    this convolution kept (`conv2d_fwd_raw(keep_v=)`): the Winograd form then reads the transformed input from it."""
     _req(dy, "conv dy")
     _req(x, "conv x")
     Bn, H, W, Cin = x.shape
@@ -728,7 +742,7 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
             and not KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K
                                             | _capi.GEMM_GENERAL_LOADERS))
     gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
-             tile_hint=tile_hint, splitk_hint=splitk_hint, wino_wgrad=wino)
+             tile_hint=tile_hint, splitk_hint=splitk_hint, wino_wgrad=wino, wino_v=wino_v)
     return dwk.permute(0, 3, 1, 2)
 
 
@@ -793,7 +807,12 @@ class Conv2dFn(torch.autograd.Function):
         ctx.save_for_backward(x, w)
         ctx.bias_ref = bias
         ctx.cfg = (stride, pad, upsample, bias is not None, rowadd is not None, residual is not None)
-        return conv2d_fwd_raw(x, w, bias, stride, pad, upsample, rowadd, residual)
+        # an F(4x4) forward launch leaves the transformed input V in its scratch: kept for the weight gradient, which would make
+        # the same image from x again (KEEP_WINO_V off: the scratch is dropped after the launch as before)
+        keep = [] if (KEEP_WINO_V[0] and ctx.needs_input_grad[1]) else None
+        y = conv2d_fwd_raw(x, w, bias, stride, pad, upsample, rowadd, residual, keep_v=keep)
+        ctx.wino_v = keep[0] if keep else None
+        return y
 
     @staticmethod
     def backward(ctx, dy):
@@ -811,8 +830,9 @@ class Conv2dFn(torch.autograd.Function):
                                                           x.shape[3], _stream()), "gad_upsample2x_bwd")
             else:
                 dx = conv2d_dgrad_raw(dy, w, x.shape, stride, pad, upsample)
-        dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o)) \
+        dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o, wino_v=ctx.wino_v)) \
             if ctx.needs_input_grad[1] else None
+        ctx.wino_v = None
         db = dr = None
         b = ctx.bias_ref
         if has_r and ctx.needs_input_grad[3]:

@@ -138,7 +138,9 @@ enum gad_gemm_flags {
   GAD_GEMM_NO_WINO = 16,      /* never take the Winograd route even when B_wino is given                              */
   GAD_GEMM_WINO_WGRAD = 32,   /* a 3x3 / stride 1 / pad 1 weight gradient (A_MC x B_CONV, output maps multiples of 4) may run in Winograd
                                * F(4x4, 3x3) form: dW = G^T [sum_tiles (A dy A^T) (.) (B^T x B)] G; wino_ws = gad_gemm_wino_bytes(args) bytes
-                               * of scratch (transformed dy and x, the 36 product panels); the planner decides (tile_hint 8 forces) */
+                               * of scratch (transformed dy and x, the 36 product panels); the planner decides (tile_hint 8 forces).  With
+                               * GAD_GEMM_WINO_SKIP_INPUT and B_wino4 = the V image [36][B Ho Wo / 16][Cin] the F(4x4) FORWARD launch of the same
+                               * convolution left at the start of its wino_ws, the input is not transformed again (bit-identical result) */
   GAD_GEMM_NO_PATCH = 1,      /* never take the LDS-patch convolution kernels (generic im2col-gather engine instead) */
   GAD_GEMM_TAP_MAJOR_K = 2,   /* conv gathers walk K as (tap, channel chunk) instead of (channel chunk, tap)        */
   GAD_GEMM_SCALAR_EPILOGUE = 4, /* dword stores straight from the accumulators instead of the LDS-transposed float4 epilogue */

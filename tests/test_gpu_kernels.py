@@ -304,6 +304,47 @@ def test_conv_wgrad_winograd(ops, B, Cin, Cout, H, W, ups):
     assert torch.equal(slot, dw)
 
 
+@pytest.mark.parametrize("B,Cin,Cout,H,W,ups,hint", [(4, 64, 128, 16, 16, False, 9), (3, 96, 64, 8, 8, True, 10), (8, 128, 128, 32, 32, False, 8),
+                                                      (2, 32, 68, 16, 12, False, 10)])
+def test_conv_wgrad_winograd_takes_the_forward_input_image(ops, B, Cin, Cout, H, W, ups, hint):
+    """Training: the F(4x4) forward launch of a convolution keeps its transformed input V (`conv2d_fwd_raw(keep_v=)`, the start
+    of the route's scratch in the one-launch and three-launch forms alike) and the weight gradient of the same convolution reads
+    it (`GAD_GEMM_WINO_SKIP_INPUT` + `B_wino4` = V) instead of transforming x again: same kernels on the same image, bit-identical;
+    a forward launch on any other route keeps nothing; the autograd function does both by itself."""
+    x, w = rnd(B, Cin, H, W, seed=1), rnd(Cout, Cin, 3, 3, seed=2, scale=0.05)
+    xg, wg = nhwc(x), cl_weight(w)
+    keep = []
+    y = ops.conv2d_fwd_raw(xg, wg, None, 1, (1, 1, 1, 1), ups, tile_hint=hint, keep_v=keep)
+    assert len(keep) == 1 and keep[0].numel() >= 36 * (y.shape[0] * y.shape[1] * y.shape[2] // 16) * Cin * 4
+    dyg = nhwc(rnd(B, Cout, y.shape[1], y.shape[2], seed=6))
+    dw = ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups, tile_hint=8)
+    ops.PROFILER = prof = ops.GemmProfiler()
+    try:
+        dw_v = ops.conv2d_wgrad_raw(dyg, xg, wg, 1, (1, 1, 1, 1), ups, tile_hint=8, wino_v=keep[0])
+        torch.cuda.synchronize()
+    finally:
+        ops.PROFILER = None
+    assert [k[0] for k in prof.summary()] == ["conv_wgrad_wino4"]
+    assert torch.equal(dw_v, dw)
+    poisoned = torch.full_like(xg, float("nan"))                 # with V given the activation itself is not read
+    assert torch.equal(ops.conv2d_wgrad_raw(dyg, poisoned, wg, 1, (1, 1, 1, 1), ups, tile_hint=8, wino_v=keep[0]), dw)
+    none = []
+    with ops.kernel_flags(no_wino=True):
+        ops.conv2d_fwd_raw(xg, wg, None, 1, (1, 1, 1, 1), ups, keep_v=none)
+    assert none == []
+    # through autograd (planner's routes): the same gradient with and without the kept image
+    grads = []
+    for on in (True, False):
+        ops.KEEP_WINO_V[0] = on
+        try:
+            wp = wg.clone().requires_grad_(True)
+            ops.conv2d(xg, wp, None, None, None, 1, (1, 1, 1, 1), ups).backward(dyg)
+            grads.append(wp.grad)
+        finally:
+            ops.KEEP_WINO_V[0] = True
+    assert torch.equal(grads[0], grads[1])
+
+
 def test_winograd_planner_takes_the_large_launches(ops):
     """The planner's modelled times against the direct plan's: maps that are multiples of 4 go to F(4x4) down to small
     launches, other even maps to F(2x2) when the launch is large, tiny launches stay direct."""
