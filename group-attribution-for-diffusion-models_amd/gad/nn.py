@@ -133,14 +133,17 @@ class ResnetBlock2D(nn.Module):
             sc = self.conv_shortcut(x, x2=x2) if self.conv_shortcut is not None else x
             return ops.gn_silu_conv3x3_raw(h, None, n2.weight, n2.bias, n2.num_groups, n2.eps, self.conv2.weight, self.conv2.bias,
                                            residual=sc)
+        # training: each norm -> silu -> conv half is one autograd node (ops.GnSiluConv3x3Fn): on the Winograd F(4x4) route the norm
+        # writes the convolution's transformed input, which is also what the weight gradient reads - the normalised activation
+        # itself never exists; conv + bias + temb add / skip add are the convolution's epilogue either way
+        n1, n2 = self.norm1, self.norm2
         if x2 is None:
-            h, x = self.norm1.with_bypass(x, silu=True)              # x: this node's alias, for the shortcut below
+            h, x = ops.gn_silu_conv3x3(x, n1.weight, n1.bias, n1.num_groups, n1.eps, self.conv1.weight, self.conv1.bias,
+                                       rowadd=self.time_emb_proj(temb_act), bypass=True)     # x: this node's alias, for the shortcut below
         else:
-            h = self.norm1(x, silu=True, x2=x2)
-        h = self.conv1(h, rowadd=self.time_emb_proj(temb_act))       # conv + bias + temb add, one kernel
-        h = self.norm2(h, silu=True)
+            h = self.conv1(self.norm1(x, silu=True, x2=x2), rowadd=self.time_emb_proj(temb_act))
         sc = self.conv_shortcut(x, x2=x2) if self.conv_shortcut is not None else x
-        return self.conv2(h, residual=sc)                             # conv + bias + skip add, one kernel
+        return ops.gn_silu_conv3x3(h, n2.weight, n2.bias, n2.num_groups, n2.eps, self.conv2.weight, self.conv2.bias, residual=sc)
 
     def cat_in_place_ok(self, x, x2):
         """Inference only, and only when both consumers of the concatenation can gather from two sources."""

@@ -280,6 +280,8 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
                 a.flags |= _capi.GEMM_WINO_SKIP_INPUT
         else:
             a.flags &= ~_capi.GEMM_WINO_WGRAD
+    if isinstance(B, _ShapeOnly) and not (a.flags & _capi.GEMM_WINO_SKIP_INPUT):
+        return False                 # the activation exists only as the kept image and this launch would not read it: the caller re-makes it
     if wino_input is not None:
         if lib.gad_gemm_kernel_id(C.byref(a)) != 6 or not a.wino_ws:
             return False
@@ -727,7 +729,8 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
     [Cout,Cin,KH,KW] view with that storage to write into (flat gradient slot); `wino_v` = the scratch the forward launch of
     this convolution kept (`conv2d_fwd_raw(keep_v=)`): the Winograd form then reads the transformed input from it."""
     _req(dy, "conv dy")
-    _req(x, "conv x")
+    if not isinstance(x, _ShapeOnly):
+        _req(x, "conv x")
     Bn, H, W, Cin = x.shape
     Cout, _, KH, KW = w_like.shape
     _, Ho, Wo, _ = dy.shape
@@ -741,8 +744,9 @@ def conv2d_wgrad_raw(dy, x, w_like, stride=1, pad=(1, 1, 1, 1), upsample=False, 
             and Ho % 4 == 0 and Wo % 4 == 0 and OPERAND_PRECISION[0] == 0 and not KERNEL_FLAGS.get("no_wino4")
             and not KERNEL_FLAGS["gemm"] & (_capi.GEMM_NO_WINO | _capi.GEMM_NO_PATCH | _capi.GEMM_SCALAR_EPILOGUE | _capi.GEMM_TAP_MAJOR_K
                                             | _capi.GEMM_GENERAL_LOADERS))
-    gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
-             tile_hint=tile_hint, splitk_hint=splitk_hint, wino_wgrad=wino, wino_v=wino_v)
+    if gemm_raw(dy, x, dwk, A_MC, B_CONV, Cout, KH * KW * Cin, Bn * Ho * Wo, Cout, 0, KH * KW * Cin, geom=g,
+                tile_hint=tile_hint, splitk_hint=splitk_hint, wino_wgrad=wino, wino_v=wino_v) is False:
+        return None                  # (x given as a shape and no Winograd launch on the kept image: nothing ran)
     return dwk.permute(0, 3, 1, 2)
 
 
@@ -833,16 +837,114 @@ class Conv2dFn(torch.autograd.Function):
         dw = _param_grad(w, lambda o: conv2d_wgrad_raw(dy, x, w, stride, pad, upsample, out=o, wino_v=ctx.wino_v)) \
             if ctx.needs_input_grad[1] else None
         ctx.wino_v = None
-        db = dr = None
-        b = ctx.bias_ref
-        if has_r and ctx.needs_input_grad[3]:
-            dr = colsum_raw(dy.view(Bn * Ho * Wo, Cout), segments=Bn)
-            if has_b and ctx.needs_input_grad[2]:
-                db = _param_grad(b, lambda o: colsum_raw(dr, 1, out=o).view(Cout))
-        elif has_b and ctx.needs_input_grad[2]:
-            db = _param_grad(b, lambda o: colsum_raw(dy.view(Bn * Ho * Wo, Cout), 1, out=o).view(Cout))
+        db, dr = _conv_epilogue_grads(dy, ctx.bias_ref, has_b and ctx.needs_input_grad[2], has_r and ctx.needs_input_grad[3])
         dres = dy if (has_res and ctx.needs_input_grad[4]) else None
         return dx, dw, db, dr, dres, None, None, None
+
+
+def _conv_epilogue_grads(dy, bias, need_bias, need_rowadd):
+    """-> (d bias, d rowadd) of y = conv(x) + bias + rowadd[b]: column sums of dy, per image for the time-embedding row."""
+    Bn, Ho, Wo, Cout = dy.shape
+    db = dr = None
+    if need_rowadd:
+        dr = colsum_raw(dy.view(Bn * Ho * Wo, Cout), segments=Bn)
+        if need_bias:
+            db = _param_grad(bias, lambda o: colsum_raw(dr, 1, out=o).view(Cout))
+    elif need_bias:
+        db = _param_grad(bias, lambda o: colsum_raw(dy.view(Bn * Ho * Wo, Cout), 1, out=o).view(Cout))
+    return db, dr
+
+
+class GnSiluConv3x3Fn(torch.autograd.Function):
+    """Training form of a ResnetBlock2D half: (y [, alias of x]) = (conv3x3(SiLU(GroupNorm(x))) + bias + rowadd[b] + residual [, x]).
+    Where the convolution takes an F(4x4) Winograd route and the norm has a plan for it, GroupNorm writes the route's
+    transformed input V (`gad_groupnorm_silu_wino4`, as in sampling: `gn_silu_conv3x3_raw`) and V is ALL that is kept of the
+    normalised activation: the weight gradient reads it (`GAD_GEMM_WINO_SKIP_INPUT`), the data gradient and the norm's backward
+    never needed it - one pass less over the activation forward and backward, and no input-transform launch on either side.
+    On any other route: the two ordinary launches, the activation kept.  Backward = Conv2dFn's then GroupNormSiluFn's kernels."""
+
+    @staticmethod
+    def forward(ctx, x, gamma, beta, w, bias, rowadd, residual, G, eps, bypass):
+        _req(x, "groupnorm x")
+        Bn, H, W, Cin = x.shape
+        lib = _capi.load()
+        mean = torch.empty((Bn, G), device=x.device, dtype=torch.float32)
+        rstd = torch.empty_like(mean)
+        keep = [] if ctx.needs_input_grad[3] else None
+        y = h = None
+        if not (OPERAND_PRECISION[0] != 0 or KERNEL_FLAGS["gn"] or KERNEL_FLAGS.get("no_gn_wino") or H % 4 or W % 4 or not KEEP_WINO_V[0]
+                or keep is None):
+            a = GroupNormArgs()
+            a.x, a.gamma, a.beta, a.mean, a.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
+            a.B, a.HW, a.C, a.G, a.eps, a.silu = Bn, H * W, Cin, G, eps, 1
+            if lib.gad_groupnorm_wino4_ok(C.byref(a), W):
+                def fill(V):
+                    check(lib.gad_groupnorm_silu_wino4(C.byref(a), V.data_ptr(), W, _stream()), "gad_groupnorm_silu_wino4")
+                y = conv2d_fwd_raw(_ShapeOnly(x, (Bn, H, W, Cin)), w, bias, 1, (1, 1, 1, 1), False, rowadd=rowadd, residual=residual,
+                                   wino_input=fill, keep_v=keep)
+                if y is None:
+                    keep.clear()                         # (planned on another route: nothing was launched)
+        if y is None:
+            h = torch.empty_like(x)
+            check(lib.gad_groupnorm_silu_fwd(C.byref(_gn_args(x, h, gamma, beta, mean, rstd, G, eps, True)), _stream()), "gad_groupnorm_silu_fwd")
+            y = conv2d_fwd_raw(h, w, bias, 1, (1, 1, 1, 1), False, rowadd=rowadd, residual=residual, keep_v=keep)
+        ctx.save_for_backward(x, gamma, beta, mean, rstd, w, h if keep is not None else None)     # (a frozen weight: nothing reads h again)
+        ctx.wino_v = keep[0] if keep else None
+        ctx.bias_ref = bias
+        ctx.cfg = (G, eps, bias is not None, rowadd is not None, residual is not None)
+        return (y, x.view_as(x)) if bypass else y
+
+    @staticmethod
+    def backward(ctx, dy, dbypass=None):
+        x, gamma, beta, mean, rstd, w, h = ctx.saved_tensors
+        G, eps, has_b, has_r, has_res = ctx.cfg
+        need = ctx.needs_input_grad
+        if dy is None:                                   # only the alias of x was used downstream
+            return (dbypass, *([None] * 9))
+        dy = dy.contiguous()
+        V, ctx.wino_v = ctx.wino_v, None
+        dh = None
+        if need[0] or need[1] or need[2]:
+            dh = conv2d_fwd_raw(dy, rotated_weight(w), None) if dgrad_as_forward(w, 1, (1, 1, 1, 1)) \
+                else conv2d_dgrad_raw(dy, w, x.shape, 1, (1, 1, 1, 1), False)
+        dw = None
+        if need[3]:
+            def wgrad(o):
+                r = None
+                if h is None:                            # the activation exists only as V: the Winograd form on it
+                    r = conv2d_wgrad_raw(dy, _ShapeOnly(x, x.shape), w, 1, (1, 1, 1, 1), False, tile_hint=8, out=o, wino_v=V)
+                if r is None:
+                    hh = h
+                    if hh is None:                       # (the library declined: make the activation again)
+                        hh = torch.empty_like(x)
+                        check(_capi.load().gad_groupnorm_silu_fwd(C.byref(_gn_args(x, hh, gamma, beta, mean.clone(), rstd.clone(), G, eps, True)),
+                                                                  _stream()), "gad_groupnorm_silu_fwd")
+                    r = conv2d_wgrad_raw(dy, hh, w, 1, (1, 1, 1, 1), False, out=o, wino_v=V)
+                return r
+            dw = _param_grad(w, wgrad)
+        db, dr = _conv_epilogue_grads(dy, ctx.bias_ref, has_b and need[4], has_r and need[5])
+        dres = dy if (has_res and need[6]) else None
+        dx = dgamma = dbeta = None
+        if dh is not None:
+            dx, dgamma, dbeta = _gn_backward(x, gamma, beta, mean, rstd, G, eps, True, dh, dbypass, need[1] or need[2])
+        elif dbypass is not None:
+            dx = dbypass
+        return dx, dgamma, dbeta, dw, db, dr, dres, None, None, None
+
+
+def gn_silu_conv3x3(x, gamma, beta, G, eps, w, bias, rowadd=None, residual=None, bypass=False):
+    """Differentiable conv3x3(SiLU(GroupNorm(x))) + bias + rowadd + residual (GnSiluConv3x3Fn); with `bypass` also an alias of
+    x for the block's residual branch (as `group_norm_bypass`).  Half-precision activations and odd shapes: the two separate ops."""
+    if x.dtype == torch.bfloat16 or tuple(w.shape[2:]) != (3, 3) or w.shape[1] != x.shape[-1] or x.ndim != 4:
+        if bypass:
+            h, x = group_norm_bypass(x, gamma, beta, G, eps, True)
+        else:
+            h = group_norm(x, gamma, beta, G, eps, True)
+        y = conv2d(h, w, bias, rowadd, residual)
+        return (y, x) if bypass else y
+    if bypass and not (torch.is_grad_enabled() and x.requires_grad):
+        return GnSiluConv3x3Fn.apply(x, gamma, beta, w, bias, rowadd, residual, G, eps, False), x
+    return GnSiluConv3x3Fn.apply(x, gamma, beta, w, bias, rowadd, residual, G, eps, bypass)
 
 
 def _half():
@@ -962,6 +1064,35 @@ def _gn_args(x, y, gamma, beta, mean, rstd, G, eps, silu):
     return a
 
 
+def _gn_backward(x, gamma, beta, mean, rstd, G, eps, silu, dy, dbypass, affine_grads):
+    """-> (dx, dgamma, dbeta) of y = [SiLU](GroupNorm(x)); `dbypass` (the gradient of an alias of x) is summed in the kernel's
+    store; parameter gradients go to their flat-buffer slots where they have one (then returned as None)."""
+    dy = dy.contiguous()
+    dx = torch.empty_like(x)
+    a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
+    a.dy = dy.data_ptr()
+    if dbypass is not None:
+        a.dx_add = _req(dbypass.contiguous(), "groupnorm bypass gradient").data_ptr()
+    if not affine_grads:                                 # frozen norm (LoRA training): dx only
+        check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
+        return dx, None, None
+    (sg, fg), (sb, fb) = _sink(gamma), _sink(beta)
+    direct_g, direct_b = sg is not None and fg, sb is not None and fb
+    dgamma = sg if direct_g else torch.empty_like(gamma)
+    dbeta = sb if direct_b else torch.empty_like(beta)
+    a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
+    check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
+    if sg is not None:
+        if not fg:
+            sg.add_(dgamma)
+        dgamma = None
+    if sb is not None:
+        if not fb:
+            sb.add_(dbeta)
+        dbeta = None
+    return dx, dgamma, dbeta
+
+
 class GroupNormSiluFn(torch.autograd.Function):
     """y = [SiLU](GroupNorm(x)) on NHWC; x is [B, ..., C]."""
 
@@ -981,30 +1112,8 @@ class GroupNormSiluFn(torch.autograd.Function):
     def backward(ctx, dy, dbypass=None):
         x, gamma, beta, mean, rstd = ctx.saved_tensors
         G, eps, silu = ctx.cfg
-        dy = dy.contiguous()
-        dx = torch.empty_like(x)
-        a = _gn_args(x, dx, gamma, beta, mean, rstd, G, eps, silu)
-        a.dy = dy.data_ptr()
-        if dbypass is not None:                          # gradient of the bypass output: summed in the kernel's store
-            a.dx_add = _req(dbypass.contiguous(), "groupnorm bypass gradient").data_ptr()
-        if not (ctx.needs_input_grad[1] or ctx.needs_input_grad[2]):      # frozen norm (LoRA training): dx only
-            check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
-            return dx, None, None, None, None, None
-        (sg, fg), (sb, fb) = _sink(gamma), _sink(beta)
-        direct_g, direct_b = sg is not None and fg, sb is not None and fb
-        dgamma = sg if direct_g else torch.empty_like(gamma)
-        dbeta = sb if direct_b else torch.empty_like(beta)
-        a.dgamma, a.dbeta = dgamma.data_ptr(), dbeta.data_ptr()
-        check(_capi.load().gad_groupnorm_silu_bwd(C.byref(a), _stream()), "gad_groupnorm_silu_bwd")
-        if sg is not None:
-            if not fg:
-                sg.add_(dgamma)
-            dgamma = None
-        if sb is not None:
-            if not fb:
-                sb.add_(dbeta)
-            dbeta = None
-        return dx, dgamma, dbeta, None, None, None
+        return (*_gn_backward(x, gamma, beta, mean, rstd, G, eps, silu, dy, dbypass,
+                              ctx.needs_input_grad[1] or ctx.needs_input_grad[2]), None, None, None)
 
 
 class GroupNormBypassFn(GroupNormSiluFn):

@@ -345,6 +345,48 @@ def test_conv_wgrad_winograd_takes_the_forward_input_image(ops, B, Cin, Cout, H,
     assert torch.equal(grads[0], grads[1])
 
 
+@pytest.mark.parametrize("B,C,Cout,H,W,G,bypass", [(8, 128, 128, 32, 32, 32, True), (4, 64, 128, 16, 16, 16, False), (3, 256, 256, 8, 8, 32, True),
+                                                    (2, 32, 64, 6, 6, 8, False), (2, 128, 128, 64, 64, 32, True)])
+def test_gn_silu_conv3x3_training_node(ops, B, C, Cout, H, W, G, bypass):
+    """ResnetBlock2D's training halves as ONE autograd node (ops.GnSiluConv3x3Fn: GroupNorm writes the Winograd route's transformed
+    input, kept for the weight gradient; the normalised activation never exists) against the two separate nodes: every gradient
+    (input incl. the bypass alias's, norm affine, weight, bias, time-embedding row, residual) to fp32 rounding, and bit for bit
+    when the kept-image path is off (then both run the same launches)."""
+    dt = dict(device=dev)
+    x0, w0 = nhwc(rnd(B, C, H, W, seed=1)), cl_weight(rnd(Cout, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C)))
+    g0, b0, bias0 = (1 + 0.1 * rnd(C, seed=3)).to(dev), rnd(C, seed=4).to(dev), rnd(Cout, seed=5).to(dev)
+    row0, res0 = rnd(B, Cout, seed=6).to(dev), nhwc(rnd(B, Cout, H, W, seed=7))
+    dy, da = nhwc(rnd(B, Cout, H, W, seed=8)), nhwc(rnd(B, C, H, W, seed=9))
+
+    def run(fused):
+        leaves = [t.clone().requires_grad_(True) for t in (x0, g0, b0, w0, bias0, row0, res0)]
+        x, g, b, w, bias, row, res = leaves
+        xin = x * 1.0                                    # (a non-leaf input, as inside the U-Net)
+        if fused:
+            out = ops.gn_silu_conv3x3(xin, g, b, G, 1e-5, w, bias, rowadd=row, residual=res, bypass=bypass)
+            y, alias = out if bypass else (out, None)
+        else:
+            if bypass:
+                h, alias = ops.group_norm_bypass(xin, g, b, G, 1e-5, True)
+            else:
+                h, alias = ops.group_norm(xin, g, b, G, 1e-5, True), None
+            y = ops.conv2d(h, w, bias, row, res)
+        loss = (y * dy).sum() + ((alias * da).sum() if bypass else 0.0)
+        return [y.detach(), *torch.autograd.grad(loss, leaves)]
+
+    want = run(False)
+    got = run(True)
+    for a, b_ in zip(got, want):
+        close(a, b_)
+    ops.KEEP_WINO_V[0] = False
+    try:
+        same = run(True)
+    finally:
+        ops.KEEP_WINO_V[0] = True
+    for a, b_ in zip(same, want):
+        assert torch.equal(a, b_)
+
+
 def test_winograd_planner_takes_the_large_launches(ops):
     """The planner's modelled times against the direct plan's: maps that are multiples of 4 go to F(4x4) down to small
     launches, other even maps to F(2x2) when the launch is large, tiny launches stay direct."""
