@@ -203,6 +203,7 @@ OUT_ALLOC = None
 OUT_ALLOC_DT = None          # the same for the half path's outputs: (shape, device, dtype) -> tensor (gad/half.py::_empty)
 
 
+ROUTE_STATS = None         # a dict while tools/wino_route_stats.py counts which 3x3 launches take a Winograd route and who made their V
 KEEP_WINO_V = [os.environ.get("GAD_KEEP_WINO_V", "1") != "0"]      # training: the forward's Winograd input image serves the weight gradient
 
 
@@ -287,6 +288,9 @@ def gemm_raw(A, B, Cout, a_mode, b_mode, M, N, K, lda, ldb, ldc, *, geom: Option
             return False
         wino_input(V)
         a.flags |= _capi.GEMM_WINO_SKIP_INPUT
+    if ROUTE_STATS is not None and (a.B_wino4 or a.flags & _capi.GEMM_WINO_WGRAD):      # tools/wino_route_stats.py
+        key = (lib.gad_gemm_kernel_id(C.byref(a)), M, N, K, bool(a.flags & _capi.GEMM_WINO_SKIP_INPUT), torch.is_grad_enabled())
+        ROUTE_STATS[key] = ROUTE_STATS.get(key, 0) + 1
     if SCRATCH_ALLOC is not None:    # canary runs: the workspace at exactly the size the planner asks for this launch
         need = lib.gad_gemm_workspace_bytes(C.byref(a))
         ws = _scratch("ws", need, A.device) if need else None
