@@ -76,7 +76,7 @@ def parse():
                          "(ddpm_config.py:395-450), unpruned / head-grouped-pruned (prune.py:337-342).  Default: cifar20 + the "
                          "others as `secondary` lines")
     ap.add_argument("--no-secondary", action="store_true", help="headline only")
-    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3], default=3,
+    ap.add_argument("--in-flight", type=int, choices=[1, 2, 3, 4], default=3,
                     help="CIFAR workloads: coalitions in flight per GPU - k > 1 (default 3, what gad.launch / run_sharded run): one coalition's "
                          "sampling phase beside the training phases of the next k - 1, each on its own HIP stream; 1: strictly sequential")
     ap.add_argument("--secondary-steps", type=int, default=10)
