@@ -204,6 +204,10 @@ OUT_ALLOC_DT = None          # the same for the half path's outputs: (shape, dev
 
 
 ROUTE_STATS = None         # a dict while tools/wino_route_stats.py counts which 3x3 launches take a Winograd route and who made their V
+# Training: GroupNorm writing the Winograd input image itself (as in sampling).  OFF by default: at B = 128 it is no faster than GroupNorm + the
+# route's input transform (31.2 vs 31.3 ms per step: the activation round trip stays in the Infinity Cache) and it changes fp32 rounding, i.e. the
+# 1000-step trajectory; with it off the training step's results are bit-identical to the separate launches'.  GAD_TRAIN_GN_WINO=1 switches it on.
+TRAIN_GN_WINO = [os.environ.get("GAD_TRAIN_GN_WINO", "0") == "1"]
 KEEP_WINO_V = [os.environ.get("GAD_KEEP_WINO_V", "1") != "0"]      # training: the forward's Winograd input image serves the weight gradient
 
 
@@ -877,7 +881,7 @@ class GnSiluConv3x3Fn(torch.autograd.Function):
         keep = [] if ctx.needs_input_grad[3] else None
         y = h = None
         if not (OPERAND_PRECISION[0] != 0 or KERNEL_FLAGS["gn"] or KERNEL_FLAGS.get("no_gn_wino") or H % 4 or W % 4 or not KEEP_WINO_V[0]
-                or keep is None):
+                or keep is None or not TRAIN_GN_WINO[0]):
             a = GroupNormArgs()
             a.x, a.gamma, a.beta, a.mean, a.rstd = x.data_ptr(), gamma.data_ptr(), beta.data_ptr(), mean.data_ptr(), rstd.data_ptr()
             a.B, a.HW, a.C, a.G, a.eps, a.silu = Bn, H * W, Cin, G, eps, 1

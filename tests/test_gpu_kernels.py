@@ -350,8 +350,9 @@ def test_conv_wgrad_winograd_takes_the_forward_input_image(ops, B, Cin, Cout, H,
 def test_gn_silu_conv3x3_training_node(ops, B, C, Cout, H, W, G, bypass):
     """ResnetBlock2D's training halves as ONE autograd node (ops.GnSiluConv3x3Fn: GroupNorm writes the Winograd route's transformed
     input, kept for the weight gradient; the normalised activation never exists) against the two separate nodes: every gradient
-    (input incl. the bypass alias's, norm affine, weight, bias, time-embedding row, residual) to fp32 rounding, and bit for bit
-    when the kept-image path is off (then both run the same launches)."""
+    (input incl. the bypass alias's, norm affine, weight, bias, time-embedding row, residual) bit for bit by default (same launches;
+    the weight gradient reads the forward's kept image) and with the kept-image path off, to fp32 rounding with GroupNorm writing the
+    image itself (`GAD_TRAIN_GN_WINO=1`)."""
     dt = dict(device=dev)
     x0, w0 = nhwc(rnd(B, C, H, W, seed=1)), cl_weight(rnd(Cout, C, 3, 3, seed=2, scale=1 / math.sqrt(9 * C)))
     g0, b0, bias0 = (1 + 0.1 * rnd(C, seed=3)).to(dev), rnd(C, seed=4).to(dev), rnd(Cout, seed=5).to(dev)
@@ -375,7 +376,13 @@ def test_gn_silu_conv3x3_training_node(ops, B, C, Cout, H, W, G, bypass):
         return [y.detach(), *torch.autograd.grad(loss, leaves)]
 
     want = run(False)
-    got = run(True)
+    for a, b_ in zip(run(True), want):                   # default: the norm's own launch, the kept image for the weight gradient
+        assert torch.equal(a, b_)
+    ops.TRAIN_GN_WINO[0] = True                          # GroupNorm writes the image itself
+    try:
+        got = run(True)
+    finally:
+        ops.TRAIN_GN_WINO[0] = False
     for a, b_ in zip(got, want):
         close(a, b_)
     ops.KEEP_WINO_V[0] = False
