@@ -133,6 +133,26 @@ def test_kernel_family_selection_is_a_pure_host_decision():
     assert kid(lin) == 0 and lib.gad_gemm_uses_bf16(ctypes.byref(lin)) == 0
 
 
+def test_winograd_weight_gradient_plan_is_the_same_with_a_kept_input_image():
+    """A 3x3 weight gradient in Winograd F(4x4) form (GAD_GEMM_WINO_WGRAD) given the forward launch's transformed input
+    (GAD_GEMM_WINO_SKIP_INPUT + B_wino4 = V) is the same plan - kernel id 7, the same scratch request - as without it: only the
+    input-transform launch is dropped (host decisions, no GPU); a misaligned image is refused before anything is launched."""
+    lib = _capi.load()
+    wg = _conv_args(_capi.A_MC, _capi.B_CONV, 128, 9 * 128, 128 * 32 * 32, 32, 32, 128)
+    wg.A = wg.B = wg.C = 4096
+    wg.lda, wg.ldc, wg.alpha = 128, 9 * 128, 1.0
+    wg.flags = _capi.GEMM_WINO_WGRAD
+    assert lib.gad_gemm_kernel_id(ctypes.byref(wg)) == 7
+    need = lib.gad_gemm_wino_bytes(ctypes.byref(wg))
+    T = 128 * 32 * 32 // 16
+    assert need == 36 * 4 * (T * 128 + T * 128 + 128 * 128)                  # transformed dy, transformed x, the 36 product panels
+    wg.flags |= _capi.GEMM_WINO_SKIP_INPUT
+    wg.B_wino4 = 8192
+    assert lib.gad_gemm_kernel_id(ctypes.byref(wg)) == 7 and lib.gad_gemm_wino_bytes(ctypes.byref(wg)) == need
+    wg.wino_ws, wg.wino_ws_bytes, wg.B_wino4 = 1 << 20, need, 8196          # image not 16-byte aligned
+    assert lib.gad_gemm(ctypes.byref(wg), None) != 0 and b"kept Winograd input image" in lib.gad_last_error()
+
+
 def test_half_path_host_side_checks_and_planner_without_gpu():
     """gad_hgemm's argument validation and its planner are host code: misuse is rejected before anything is launched, and the
     tile / split-K choices for the SD step's shapes are the ones DESIGN.md §4.4 states (no GPU needed)."""
